@@ -1,0 +1,212 @@
+/*
+ * unet_hip.h -- C ABI of libunet_hip.so: the MI355X (gfx950) hot path of the
+ * U-Net segmentation train / predict step.
+ *
+ * The reference (LUP-LuftbildUmweltPlanung/UNet) has no FFI of its own: its hot
+ * path is two Python lines -- model construction (train.py:128-144) and
+ * learn.fit_one_cycle / learn.predict (train.py:247-250, predict.py:193) -- whose
+ * arithmetic is executed by fastai 2.5.1 + ATen.  Each entry point below replaces
+ * the ATen operator family that graph issues; the
+ * comment on each names the fastai module / reference call site it stands for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates);
+ *     the library never allocates, frees or synchronises;
+ *   - all tensors are fp32 NHWC; a tensor argument is (ptr, cs, co): base
+ *     pointer of the [N,H,W,cs] buffer, physical channel stride cs (multiple of
+ *     4) and channel offset co (multiple of 4) -- this is how torch.cat is
+ *     eliminated: producers write channel slices of one buffer;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued
+ *     asynchronously on it;
+ *   - return value: 0 = OK, <0 = UNET_E_*; unet_last_error() gives the text.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_OK 0
+#define UNET_E_BADARG (-1)
+#define UNET_E_UNSUPPORTED (-2)
+#define UNET_E_HIP (-3)
+
+#define UNET_ABI_VERSION 1
+
+int unet_abi_version(void);
+const char* unet_last_error(void);
+
+/* ------------------------------------------------------------------ conv --
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC,
+ * LDS-staged input halo tile + filter slab, no im2col.
+ * Replaces: every nn.Conv2d of fastai ConvLayer (layers.py) in XResNet
+ * (vision/models/xresnet.py), DynamicUnet.middle_conv / UnetBlock.conv1,conv2 /
+ * PixelShuffle_ICNR 1x1 / final ResBlock / head (vision/models/unet.py), as
+ * built by train.py:128-144, and their autograd input-gradients.
+ */
+
+/* flags for unet_conv2d */
+#define UNET_CONV_RELU 1          /* y = max(y, 0) after bias/residual */
+#define UNET_CONV_MASK 4          /* y = (maskref > 0) ? y : 0 (ReLU backward fused in dgrad) */
+
+/* kind */
+#define UNET_CONV_FWD 0           /* y = conv(x, W) stride S pad (ks-1)/2 */
+#define UNET_CONV_DGRAD 1         /* y = dL/dx given x := dL/d(conv out); wp packed by unet_pack_weights(mode DGRAD) */
+
+typedef struct {
+    const float* x; int x_cs, x_co;      /* input: FWD: activations [N,IH,IW]; DGRAD: output-gradient [N,IH,IW] */
+    const float* wp;                     /* packed weights (unet_pack_weights) */
+    const float* bias;                   /* [Cout] or NULL */
+    const float* res; int res_cs, res_co;      /* optional residual added before activation, same geometry as y */
+    const float* mask; int mask_cs, mask_co;   /* UNET_CONV_MASK reference, same geometry as y */
+    float* y; int y_cs, y_co;            /* output [N,OH,OW] */
+    int N, IH, IW, Cin;                  /* Cin = reduction channels of this launch */
+    int OH, OW, Cout;                    /* Cout = produced channels of this launch */
+    int ks, stride;                      /* kernel size 1|3, stride 1|2 of the FORWARD convolution */
+    int kind, flags;
+    float* colsum;                       /* optional [rows][Cout] per-wave partial column sums of y (bias-grad / BN stats), or NULL */
+    float* colsumsq;                     /* optional same shape, sums of y*y */
+} unet_conv_desc;
+
+/* number of partial rows the colsum buffers must hold for this desc */
+int unet_conv2d_colsum_rows(const unet_conv_desc* d);
+int unet_conv2d(const unet_conv_desc* d, void* stream);
+
+/* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].
+ * mode 0 (FWD):   wp[tap][chunk][coutPad][16]  reduction over Cin
+ * mode 1 (DGRAD): wp[tap][chunk][cinPad][16]   reduction over Cout
+ * pads are zero filled; chunk = 16 reduction channels; *Pad = roundup(.,128). */
+size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode); /* floats */
+int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream);
+
+/* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
+ * Replaces the autograd weight-gradient of the same nn.Conv2d modules.
+ * workspace holds split-K partials; query its size (floats) first. */
+typedef struct {
+    const float* x; int x_cs, x_co;      /* forward input  [N,IH,IW,Cin] */
+    const float* dy; int dy_cs, dy_co;   /* output grad    [N,OH,OW,Cout] */
+    float* dw;                           /* [Cout,Cin,ks,ks] */
+    float* dbias;                        /* [Cout] or NULL: also produce sum_pixels dy */
+    int N, IH, IW, Cin, OH, OW, Cout, ks, stride;
+    float* workspace; size_t workspace_floats;
+    int accumulate;                      /* 0: dw = result, 1: dw += result */
+} unet_wgrad_desc;
+size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d);
+int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream);
+
+/* ----------------------------------------------------------- batch norm --
+ * Replaces nn.BatchNorm2d(eps 1e-5, momentum 0.1) of fastai BatchNorm
+ * (layers.py) in train mode (batch statistics, wavefront reductions) and eval
+ * mode (running statistics), fused with residual add + ReLU of ResBlock.forward.
+ */
+/* per-channel partial sums of x and x*x over P pixels -> two planes partial[0:rows][C] (sums) and
+ * partial[rows:2*rows][C] (sums of squares); rows = unet_bn_stats_rows(P) */
+int unet_bn_stats_rows(long long P);
+int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream);
+/* train-mode finalize: from partial sums psum[rows][C], psumsq[rows][C] (unet_bn_stats planes or the
+ * colsum/colsumsq of a conv epilogue) compute mean / invstd, scale = gamma*invstd, shift = beta - mean*scale,
+ * and update running stats (unbiased var, momentum). */
+int unet_bn_finalize(const float* psum, const float* psumsq, int rows, long long count, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps,
+                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* eval-mode: scale/shift from running stats */
+int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+/* y = act(x*scale+shift [+ x2*scale2+shift2 | + x2]) ; scale2 NULL with x2 != NULL means plain add */
+int unet_affine_act(const float* x, int x_cs, int x_co, const float* scale, const float* shift,
+                    const float* x2, int x2_cs, int x2_co, const float* scale2, const float* shift2,
+                    float* y, int y_cs, int y_co, long long P, int C, int relu, void* stream);
+/* BN backward, train mode.  g = dout * (out > 0 if out != NULL).
+ * reduce: planes partial[0:rows][C] = sum g, partial[rows:2*rows][C] = sum g*xhat; rows = unet_bn_stats_rows(P) */
+int unet_bn_bwd_reduce(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co,
+                       const float* x, int x_cs, int x_co, const float* mean, const float* invstd,
+                       long long P, int C, float* partial, void* stream);
+/* finalize: dgamma, dbeta and coefficient vectors c1 = sum g / count, c2 = sum g xhat / count */
+int unet_bn_bwd_finalize(const float* partial, int rows, long long count, int C,
+                         float* dgamma, float* dbeta, float* c1, float* c2, void* stream);
+/* apply: dx = gamma*invstd*(g - c1 - xhat*c2) ; optionally also writes g to gout (for the residual branch) */
+int unet_bn_bwd_apply(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co,
+                      const float* x, int x_cs, int x_co, const float* mean, const float* invstd,
+                      const float* gamma, const float* c1, const float* c2,
+                      float* dx, int dx_cs, int dx_co, float* gout, int g_cs, int g_co, int g_accumulate,
+                      long long P, int C, void* stream);
+
+/* -------------------------------------------------------------- pooling --
+ * MaxPool2d(3,2,1) after the stem and AvgPool2d(2, ceil_mode=True) on strided
+ * identity paths (fastai xresnet.py / layers.py ResBlock). */
+int unet_maxpool3x3s2(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, uint8_t* idx,
+                      int N, int IH, int IW, int C, int OH, int OW, void* stream);
+int unet_maxpool3x3s2_bwd(const float* dy, int dy_cs, int dy_co, const uint8_t* idx, float* dx, int dx_cs, int dx_co,
+                          int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
+int unet_avgpool2_ceil(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
+                       int N, int IH, int IW, int C, int OH, int OW, void* stream);
+int unet_avgpool2_ceil_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co,
+                           int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
+
+/* -------------------------------------------------- decoder data movement --
+ * PixelShuffle_ICNR (layers.py) tail and UnetBlock.forward (vision/models/unet.py):
+ *   up = [blur](PixelShuffle(2)(yc)),  yc = relu(conv1x1(x)) of shape [N,h,w,4*Cu]
+ *   PixelShuffle: P[2h+i, 2w+j, c] = yc[h, w, 4c+2i+j]
+ *   blur = ReplicationPad2d((1,0,1,0)) + AvgPool2d(2, stride=1)
+ * writes X[N,2h,2w][X_co : X_co+Cu]; the skip half of torch.cat is written by
+ * unet_affine_act (relu(bn(skip))) into the neighbouring channel slice. */
+int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X, int X_cs, int X_co,
+                      int N, int h, int w, int Cu, int do_blur, void* stream);
+/* adjoint incl. the ReLU of the 1x1 conv: dyc = (yc > 0) * shuffle^T(blur^T(dX)) */
+int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, const float* yc, int yc_cs, int yc_co,
+                          float* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+/* F.interpolate(mode='nearest') and its adjoint (UnetBlock / ResizeToOrig when sizes differ) */
+int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
+                        int N, int IH, int IW, int OH, int OW, int C, void* stream);
+int unet_resize_nearest_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co,
+                            int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* layout conversion at the seam (torch side is NCHW): */
+int unet_nchw_to_nhwc(const float* x, float* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream);
+int unet_nhwc_to_nchw(const float* x, int x_cs, int x_co, float* y, int N, int C, int H, int W, void* stream);
+/* elementwise helpers on NHWC slices */
+int unet_copy_slice(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C,
+                    int accumulate, void* stream);
+int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_cs, int r_co,
+                   float* y, int y_cs, int y_co, long long P, int C, void* stream);
+int unet_colsum(const float* x, int x_cs, int x_co, long long P, int C, float* out, float* workspace, void* stream);
+size_t unet_colsum_workspace(long long P, int C);
+
+/* ----------------------------------------------------------------- loss --
+ * CrossEntropyLossFlat(axis=1, weight=w) (fastai losses.py; train.py:195,211):
+ * loss = sum w[y] * -log softmax(z)[y] / sum w[y]; activation softmax(dim=1),
+ * decodes argmax(dim=1) (predict.py:193,232).
+ * logits NHWC [P,C] (cs/co), targets int64 [P]. */
+size_t unet_ce_workspace(long long P);   /* floats */
+int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                float* loss /*[1]*/, float* denom /*[1]*/, float* workspace, void* stream);
+/* dz = gscale * w[y] * (softmax(z) - onehot(y)) / denom ; gscale multiplies (loss scaling / DDP averaging) */
+int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream);
+/* probs NCHW [N,C,H,W] (what Learner.predict returns, predict.py:196-203) and argmax uint8/int64 mask */
+int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, int H, int W, int C,
+                        float* probs_nchw /*or NULL*/, int64_t* argmax /*or NULL*/, void* stream);
+
+/* ------------------------------------------------------------ optimiser --
+ * fastai Adam (optimizer.py: weight_decay, average_grad(dampening), average_sqr_grad,
+ * step_stat, adam_step) with decoupled wd, per-group lr (train.py:78-80, 247-250).
+ * code[i] = group_id (bits 0-1) | do_wd << 2.  grad_scale multiplies g first. */
+int unet_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n,
+                   const float* lr /*[4] host*/, float mom, float sqr_mom, float eps, float wd, int step,
+                   float grad_scale, void* stream);
+
+/* ------------------------------------------------- overlap-merge (predict) --
+ * predict.py:284-326: sum softmax probabilities of overlapping tiles into a
+ * mosaic + hit counter, divide, argmax. */
+int unet_mosaic_accumulate(const float* probs_nchw, int C, int th, int tw, float* mosaic /*[C,MH,MW]*/,
+                           int32_t* count /*[MH,MW]*/, int MH, int MW, int y0, int x0, void* stream);
+int unet_mosaic_finalize(float* mosaic, const int32_t* count, int C, int MH, int MW, uint8_t* argmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

@@ -1,0 +1,410 @@
+"""Per-kernel parity: every C-ABI entry point against the plain torch-CPU fp32 op it replaces.
+
+Tolerances: fp32 everywhere.  Convolutions reduce over up to 9*1024 products in a
+different order than oneDNN, so they are compared at rtol 2e-4 of the tensor's max
+magnitude; data movement / pooling / masks are bit exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from unet_amd import ops as _ops
+    return _ops
+
+
+from tests.util import assert_close, empty_ts, from_ts, outside_untouched, to_ts  # noqa: E402
+
+CONV_CASES = [
+    # N, H,  W,  Cin, Cout, ks, stride
+    (2, 16, 16, 32, 32, 3, 1),
+    (1, 32, 32, 64, 64, 3, 1),
+    (2, 40, 48, 100, 100, 3, 1),      # final ResBlock width, ragged tiles
+    (1, 16, 16, 192, 96, 3, 1),
+    (1, 8, 8, 512, 1024, 3, 1),       # middle_conv, tiny spatial
+    (2, 13, 13, 128, 128, 3, 1),      # odd size (400-px tiles path)
+    (2, 32, 32, 4, 32, 3, 2),         # stem conv0
+    (1, 16, 16, 3, 32, 3, 2),         # 3-channel stem (channel stride 4)
+    (2, 26, 26, 64, 128, 3, 2),       # strided ResBlock conv
+    (1, 25, 25, 64, 128, 3, 2),       # odd input, stride 2
+    (2, 16, 16, 512, 1024, 1, 1),     # PixelShuffle_ICNR 1x1
+    (1, 64, 64, 96, 384, 1, 1),
+    (2, 32, 32, 100, 5, 1, 1),        # head
+    (1, 32, 32, 99, 2, 1, 1),         # 3-channel config head (99 = 96 + 3)
+    (1, 16, 16, 64, 128, 1, 1),       # identity-path 1x1
+]
+
+
+def _conv_ref(x, w, b, ks, stride):
+    return F.conv2d(x, w, b, stride=stride, padding=(ks - 1) // 2)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(ops, case):
+    N, H, W, Cin, Cout, ks, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = _conv_ref(x, w, b, ks, stride)
+    OH, OW = ref.shape[-2:]
+    xt = to_ts(x)
+    yt = empty_ts(N, OH, OW, Cout)
+    wp = ops.pack_weights(w.cuda(), 0)
+    ops.conv2d(xt, wp, yt, ks, stride, bias=b.cuda())
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), ref, rtol=2e-4, what=f"conv fwd {case}")
+
+
+def test_conv_fwd_slices_relu_res_colsum(ops):
+    """Channel-sliced input/output (concat elimination), bias+residual+ReLU epilogue, column sums."""
+    N, H, W, Cin, Cout = 2, 24, 40, 36, 100
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    pre = F.conv2d(x, w, b, padding=1) + r
+    ref = F.relu(pre)
+    xt = to_ts(x, cs=64, co=8)
+    rt = to_ts(r, cs=128, co=4)
+    yt = empty_ts(N, H, W, Cout, cs=160, co=32)
+    wp = ops.pack_weights(w.cuda(), 0)
+    rows = ops.conv_colsum_rows(xt, wp, yt, 3, 1, 0)
+    cs_ = torch.zeros(rows, Cout, device="cuda")
+    cq_ = torch.zeros(rows, Cout, device="cuda")
+    ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True, colsum=cs_, colsumsq=cq_)
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), ref, rtol=2e-4, what="conv+res+relu")
+    assert outside_untouched(yt)
+    assert_close(cs_.sum(0).cpu(), ref.sum((0, 2, 3)), rtol=2e-4, atol=1e-2, what="colsum")
+    assert_close(cq_.sum(0).cpu(), (ref * ref).sum((0, 2, 3)), rtol=2e-4, atol=1e-2, what="colsumsq")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(ops, case):
+    N, H, W, Cin, Cout, ks, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cout * ks * ks) ** 0.5
+    pad = (ks - 1) // 2
+    OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, stride=stride, padding=pad)
+    dyt = to_ts(dy)
+    dxt = empty_ts(N, H, W, Cin)
+    wp = ops.pack_weights(w.cuda(), 1)
+    ops.conv2d_dgrad(dyt, wp, dxt, ks, stride)
+    torch.cuda.synchronize()
+    assert_close(from_ts(dxt), ref, rtol=2e-4, what=f"conv dgrad {case}")
+
+
+def test_conv_dgrad_mask_res(ops):
+    N, H, W, Cin, Cout = 2, 20, 36, 96, 100
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cout * 9) ** 0.5
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    act = F.relu(torch.randn(N, Cin, H, W, generator=g))
+    extra = torch.randn(N, Cin, H, W, generator=g)
+    ref = (torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, padding=1) + extra) * (act > 0)
+    dxt = empty_ts(N, H, W, Cin)
+    ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(w.cuda(), 1), dxt, 3, 1, res=to_ts(extra), mask=to_ts(act))
+    torch.cuda.synchronize()
+    assert_close(from_ts(dxt), ref, rtol=2e-4, what="dgrad+res+mask")
+
+
+WGRAD_CASES = [
+    (2, 16, 16, 32, 32, 3, 1),
+    (2, 40, 48, 100, 100, 3, 1),
+    (1, 8, 8, 256, 128, 3, 1),
+    (2, 13, 13, 64, 64, 3, 1),
+    (2, 32, 32, 4, 32, 3, 2),
+    (1, 16, 16, 3, 32, 3, 2),
+    (2, 26, 26, 64, 128, 3, 2),
+    (1, 25, 25, 32, 64, 3, 2),
+    (2, 16, 16, 128, 256, 1, 1),
+    (2, 32, 32, 100, 5, 1, 1),
+    (4, 64, 64, 64, 64, 3, 1),        # several split-K partials
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(ops, case):
+    N, H, W, Cin, Cout, ks, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 2)
+    pad = (ks - 1) // 2
+    OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, ks, ks), dy, stride=stride, padding=pad)
+    xt, dyt = to_ts(x), to_ts(dy)
+    ws = torch.empty(ops.wgrad_workspace(xt, dyt, ks, stride, with_bias=True), device="cuda")
+    dw = torch.full((Cout, Cin, ks, ks), 3.0, device="cuda")
+    db = torch.full((Cout,), 3.0, device="cuda")
+    ops.conv2d_wgrad(xt, dyt, dw, ks, stride, ws, dbias=db)
+    torch.cuda.synchronize()
+    assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"wgrad {case}")
+    assert_close(db.cpu(), dy.sum((0, 2, 3)), rtol=3e-4, atol=1e-4, what=f"dbias {case}")
+    ops.conv2d_wgrad(xt, dyt, dw, ks, stride, ws, accumulate=True)
+    torch.cuda.synchronize()
+    assert_close(dw.cpu(), 2 * ref, rtol=3e-4, atol=2e-4, what=f"wgrad accumulate {case}")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 32, 9, 7), (1, 512, 4, 4), (2, 256, 40, 40)])
+def test_batchnorm_train_fwd_bwd(ops, shape):
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    res = torch.randn(shape, generator=g)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cc, generator=g).requires_grad_(True)
+    rm0, rv0 = torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    bn = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    out = F.relu(bn + res)
+    dout = torch.randn(shape, generator=g)
+
+    P = N * H * W
+    xt = to_ts(x.detach())
+    rows = ops.bn_stats_rows(P)
+    part = torch.empty(2 * rows * Cc, device="cuda")
+    ops.bn_stats(xt, part)
+    dev = lambda t: t.detach().clone().cuda()
+    scale, shift, smean, sinv = (torch.empty(Cc, device="cuda") for _ in range(4))
+    rmd, rvd = dev(rm0), dev(rv0)
+    ops.bn_finalize(part, part[rows * Cc:], rows, P, Cc, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, scale, shift, smean, sinv)
+    yt = empty_ts(N, H, W, Cc)
+    ops.affine_act(xt, yt, scale, shift, x2=to_ts(res), relu=True)
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), out.detach(), rtol=1e-5, atol=1e-5, what="bn fwd")
+    assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6, what="running_mean")
+    assert_close(rvd.cpu(), rv, rtol=1e-5, atol=1e-6, what="running_var")
+
+    # backward: g = dout * (out > 0); dx, dgamma, dbeta; residual branch gets g.  The reference uses the
+    # ReLU mask of the HIP forward output so that a sign flip of a ~1e-8 pre-activation cannot fail the test.
+    g_ref = dout * (from_ts(yt) > 0)
+    bn.backward(g_ref)
+    doutt = to_ts(dout)
+    bpart = torch.empty(2 * rows * Cc, device="cuda")
+    ops.bn_bwd_reduce(doutt, yt, xt, smean, sinv, bpart)
+    dgamma, dbeta, c1, c2 = (torch.empty(Cc, device="cuda") for _ in range(4))
+    ops.bn_bwd_finalize(bpart, rows, P, Cc, dgamma, dbeta, c1, c2)
+    dxt = empty_ts(N, H, W, Cc)
+    gt = empty_ts(N, H, W, Cc)
+    ops.bn_bwd_apply(doutt, yt, xt, smean, sinv, dev(gamma), c1, c2, dxt, gout=gt)
+    torch.cuda.synchronize()
+    assert_close(from_ts(dxt), x.grad, rtol=2e-4, atol=1e-5, what="bn dx")
+    assert_close(dgamma.cpu(), gamma.grad, rtol=2e-4, atol=1e-4, what="dgamma")
+    assert_close(dbeta.cpu(), beta.grad, rtol=2e-4, atol=1e-4, what="dbeta")
+    assert torch.equal(from_ts(gt), g_ref)
+
+
+def test_batchnorm_eval_coeffs(ops):
+    Cc = 64
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, Cc, 8, 8, generator=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm, rv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    ref = F.batch_norm(x, rm, rv, gamma, beta, training=False, eps=1e-5)
+    scale, shift = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    ops.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5, scale, shift)
+    yt = empty_ts(2, 8, 8, Cc)
+    ops.affine_act(to_ts(x), yt, scale, shift)
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), ref, rtol=1e-5, atol=1e-5, what="bn eval")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (1, 32, 25, 27), (2, 8, 7, 7)])
+def test_maxpool(ops, shape):
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(4)
+    x = F.relu(torch.randn(shape, generator=g)).requires_grad_(True)   # many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    OH, OW = y.shape[-2:]
+    yt = empty_ts(N, OH, OW, Cc)
+    idx = torch.empty(N * OH * OW * Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool(to_ts(x.detach()), yt, idx)
+    dxt = empty_ts(N, H, W, Cc)
+    ops.maxpool_bwd(to_ts(dy), idx, dxt)
+    torch.cuda.synchronize()
+    assert torch.equal(from_ts(yt), y.detach())
+    assert_close(from_ts(dxt), x.grad, rtol=1e-6, atol=1e-6, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 128, 25, 13)])
+def test_avgpool_ceil(ops, shape):
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(shape, generator=g).requires_grad_(True)
+    y = F.avg_pool2d(x, 2, ceil_mode=True)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    OH, OW = y.shape[-2:]
+    yt = empty_ts(N, OH, OW, Cc)
+    ops.avgpool(to_ts(x.detach()), yt)
+    dxt = empty_ts(N, H, W, Cc)
+    ops.avgpool_bwd(to_ts(dy), dxt)
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), y.detach(), rtol=1e-6, atol=1e-6, what="avgpool")
+    assert_close(from_ts(dxt), x.grad, rtol=1e-6, atol=1e-6, what="avgpool bwd")
+
+
+@pytest.mark.parametrize("blur", [True, False])
+@pytest.mark.parametrize("shape", [(2, 24, 8, 8), (1, 96, 5, 7)])
+def test_shuffle_blur(ops, shape, blur):
+    N, Cu, h, w = shape
+    g = torch.Generator().manual_seed(8)
+    pre = torch.randn(N, 4 * Cu, h, w, generator=g).requires_grad_(True)
+    yc = F.relu(pre)
+    up = F.pixel_shuffle(yc, 2)
+    if blur:
+        up = F.avg_pool2d(F.pad(up, (1, 0, 1, 0), mode="replicate"), 2, stride=1)
+    dX = torch.randn(up.shape, generator=g)
+    up.backward(dX)
+    yct = to_ts(yc.detach())
+    Xt = empty_ts(N, 2 * h, 2 * w, Cu, cs=Cu + 12, co=4)
+    ops.shuffle_blur(yct, Xt, blur)
+    dyct = empty_ts(N, h, w, 4 * Cu)
+    ops.shuffle_blur_bwd(to_ts(dX, cs=Cu + 8, co=8), yct, dyct, blur)
+    torch.cuda.synchronize()
+    assert_close(from_ts(Xt), up.detach(), rtol=1e-6, atol=1e-6, what="shuffle_blur")
+    assert outside_untouched(Xt)
+    assert_close(from_ts(dyct), pre.grad, rtol=1e-5, atol=1e-6, what="shuffle_blur bwd")
+
+
+def test_resize_nearest(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 26, 26, generator=g).requires_grad_(True)
+    y = F.interpolate(x, (25, 25), mode="nearest")
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yt = empty_ts(2, 25, 25, 32)
+    ops.resize_nearest(to_ts(x.detach()), yt)
+    dxt = empty_ts(2, 26, 26, 32)
+    ops.resize_nearest_bwd(to_ts(dy), dxt)
+    torch.cuda.synchronize()
+    assert torch.equal(from_ts(yt), y.detach())
+    assert_close(from_ts(dxt), x.grad, rtol=1e-6, atol=1e-6, what="resize bwd")
+    x2 = torch.randn(1, 8, 50, 50, generator=g)
+    y2t = empty_ts(1, 52, 52, 8)
+    ops.resize_nearest(to_ts(x2), y2t)
+    torch.cuda.synchronize()
+    assert torch.equal(from_ts(y2t), F.interpolate(x2, (52, 52), mode="nearest"))
+
+
+def test_layout_and_slices(ops):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 3, 9, 11, generator=g)
+    yt = empty_ts(2, 9, 11, 3, cs=8, co=4, fill=0.0)
+    ops.nchw_to_nhwc(x.cuda(), yt)
+    back = torch.empty(2, 3, 9, 11, device="cuda")
+    ops.nhwc_to_nchw(yt, back)
+    torch.cuda.synchronize()
+    assert torch.equal(from_ts(yt), x) and torch.equal(back.cpu(), x)
+    a = torch.randn(2, 20, 5, 5, generator=g)
+    b = torch.randn(2, 20, 5, 5, generator=g)
+    at = to_ts(a, cs=32, co=4)
+    bt = to_ts(b)
+    ops.copy_slice(at, bt, accumulate=True)
+    mt = empty_ts(2, 5, 5, 20)
+    ops.relu_mask(at, bt, mt)
+    ws = torch.empty(ops.colsum_workspace(50, 20), device="cuda")
+    cs_ = torch.empty(20, device="cuda")
+    ops.colsum(at, cs_, ws)
+    torch.cuda.synchronize()
+    assert_close(from_ts(bt), a + b, rtol=1e-6, atol=1e-6, what="copy accumulate")
+    assert torch.equal(from_ts(mt), a * ((a + b) > 0))
+    assert_close(cs_.cpu(), a.sum((0, 2, 3)), rtol=1e-5, atol=1e-5, what="colsum")
+
+
+@pytest.mark.parametrize("n_cls,weighted", [(5, True), (5, False), (2, True), (10, False)])
+def test_cross_entropy(ops, n_cls, weighted):
+    g = torch.Generator().manual_seed(12)
+    N, H, W = 2, 19, 23
+    z = (torch.randn(N, n_cls, H, W, generator=g) * 3).requires_grad_(True)
+    y = torch.randint(0, n_cls, (N, H, W), generator=g)
+    wt = (torch.rand(n_cls, generator=g) + 0.2) if weighted else None
+    zl = z.permute(0, 2, 3, 1).reshape(-1, n_cls)
+    loss = F.cross_entropy(zl, y.reshape(-1), weight=wt)
+    loss.backward()
+    zt = to_ts(z.detach(), cs=ops.rup4(n_cls) + 4, co=4)
+    P = N * H * W
+    ws = torch.empty(ops.ce_workspace(P), device="cuda")
+    lo, den = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    wd = None if wt is None else wt.cuda()
+    ops.ce_fwd(zt, y.cuda(), wd, lo, den, ws)
+    dzt = empty_ts(N, H, W, n_cls, fill=0.0)
+    ops.ce_bwd(zt, y.cuda(), wd, den, 1.0, dzt)
+    probs = torch.empty(N, n_cls, H, W, device="cuda")
+    am = torch.empty(N, H, W, dtype=torch.int64, device="cuda")
+    ops.softmax_argmax(zt, probs, am)
+    torch.cuda.synchronize()
+    assert abs(lo.item() - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+    assert_close(from_ts(dzt), z.grad, rtol=1e-4, atol=1e-9, what="ce bwd")
+    ref_p = F.softmax(z.detach(), dim=1)
+    assert_close(probs.cpu(), ref_p, rtol=1e-5, atol=1e-6, what="softmax")
+    assert torch.equal(am.cpu(), ref_p.argmax(dim=1))
+
+
+def test_adam_step_matches_fastai_restatement(ops):
+    from oracle.unet_oracle import FastaiAdam
+    g = torch.Generator().manual_seed(13)
+    n = 10000
+    p0 = torch.randn(n, generator=g)
+    ps = [torch.nn.Parameter(p0[:3000].clone()), torch.nn.Parameter(p0[3000:7000].clone()), torch.nn.Parameter(p0[7000:].clone())]
+    lrs = [1e-3, 3e-3, 1e-2]
+    opt = FastaiAdam([[ps[0]], [ps[1]], [ps[2]]], lrs, no_wd=[ps[1]])
+    code = torch.empty(n, dtype=torch.uint8)
+    code[:3000] = 0 | 4
+    code[3000:7000] = 1
+    code[7000:] = 2 | 4
+    pd = p0.clone().cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    coded = code.cuda()
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        for q, sl in zip(ps, (slice(0, 3000), slice(3000, 7000), slice(7000, n))):
+            q.grad = gr[sl].clone()
+        opt.mom = 0.95 - 0.02 * step
+        opt.step()
+        ops.adam_step(pd, gr.cuda(), m, v, coded, lrs, opt.mom, 0.99, 1e-5, 0.01, step)
+    torch.cuda.synchronize()
+    ref = torch.cat([q.detach() for q in ps])
+    assert_close(pd.cpu(), ref, rtol=1e-6, atol=1e-6, what="adam")
+
+
+def test_mosaic(ops):
+    g = torch.Generator().manual_seed(14)
+    Cc, MH, MW = 3, 20, 24
+    mosaic = torch.zeros(Cc, MH, MW, device="cuda")
+    count = torch.zeros(MH, MW, dtype=torch.int32, device="cuda")
+    ref = torch.zeros(Cc, MH, MW)
+    cnt = torch.zeros(MH, MW)
+    for (y0, x0) in [(0, 0), (4, 8), (8, 12), (12, 12)]:
+        pr = torch.rand(Cc, 8, 12, generator=g)
+        ops.mosaic_accumulate(pr.cuda(), mosaic, count, y0, x0)
+        ref[:, y0:y0 + 8, x0:x0 + 12] += pr
+        cnt[y0:y0 + 8, x0:x0 + 12] += 1
+    am = torch.empty(MH, MW, dtype=torch.uint8, device="cuda")
+    ops.mosaic_finalize(mosaic, count, am)
+    torch.cuda.synchronize()
+    refm = torch.where(cnt > 0, ref / cnt.clamp(min=1), ref)
+    assert_close(mosaic.cpu(), refm, rtol=1e-6, atol=1e-6, what="mosaic")
+    assert torch.equal(am.cpu().long(), refm.argmax(0))
+
+
+def test_bad_arguments_fail_loudly(ops):
+    from unet_amd._lib import UnetHipError
+    x = empty_ts(1, 8, 8, 16)
+    y = empty_ts(1, 9, 9, 16)
+    wp = torch.zeros(9 * 128 * 16, device="cuda")
+    with pytest.raises(UnetHipError):
+        ops.conv2d(x, wp, y, 3, 1)          # inconsistent output dims
+    with pytest.raises(UnetHipError):
+        ops.conv2d(x, wp, empty_ts(1, 8, 8, 16), 5, 1)   # unsupported kernel size

@@ -1,0 +1,138 @@
+"""ctypes binding of libunet_hip.so (the C ABI declared in include/unet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or does not
+export a declared symbol, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libunet_hip.so"
+HEADER = _HERE.parent / "include" / "unet_hip.h"
+
+UNET_OK = 0
+CONV_RELU = 1
+CONV_MASK = 4
+CONV_FWD = 0
+CONV_DGRAD = 1
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_cs", C.c_int), ("x_co", C.c_int),
+        ("wp", vp),
+        ("bias", vp),
+        ("res", vp), ("res_cs", C.c_int), ("res_co", C.c_int),
+        ("mask", vp), ("mask_cs", C.c_int), ("mask_co", C.c_int),
+        ("y", vp), ("y_cs", C.c_int), ("y_co", C.c_int),
+        ("N", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int),
+        ("ks", C.c_int), ("stride", C.c_int),
+        ("kind", C.c_int), ("flags", C.c_int),
+        ("colsum", vp),
+        ("colsumsq", vp),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_cs", C.c_int), ("x_co", C.c_int),
+        ("dy", vp), ("dy_cs", C.c_int), ("dy_co", C.c_int),
+        ("dw", vp),
+        ("dbias", vp),
+        ("N", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("ks", C.c_int), ("stride", C.c_int),
+        ("workspace", vp), ("workspace_floats", C.c_size_t),
+        ("accumulate", C.c_int),
+    ]
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/unet_hip.h declares (used by the CPU-side ABI test)."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m unet_amd.build` (hipcc --offload-arch=gfx950). "
+            "The MI355X path has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"libunet_hip.so does not export: {missing}")
+    return lib
+
+
+lib = _load()
+
+i, ll, f, sz = C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_sig = {
+    "unet_abi_version": (i, []),
+    "unet_last_error": (C.c_char_p, []),
+    "unet_conv2d_colsum_rows": (i, [C.POINTER(ConvDesc)]),
+    "unet_conv2d": (i, [C.POINTER(ConvDesc), vp]),
+    "unet_pack_weights_size": (sz, [i, i, i, i]),
+    "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
+    "unet_conv2d_wgrad_workspace": (sz, [C.POINTER(WgradDesc)]),
+    "unet_conv2d_wgrad": (i, [C.POINTER(WgradDesc), vp]),
+    "unet_bn_stats_rows": (i, [ll]),
+    "unet_bn_stats": (i, [vp, i, i, ll, i, vp, vp]),
+    "unet_bn_finalize": (i, [vp, vp, i, ll, i, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp]),
+    "unet_bn_eval_coeffs": (i, [vp, vp, vp, vp, f, i, vp, vp, vp]),
+    "unet_affine_act": (i, [vp, i, i, vp, vp, vp, i, i, vp, vp, vp, i, i, ll, i, i, vp]),
+    "unet_bn_bwd_reduce": (i, [vp, i, i, vp, i, i, vp, i, i, vp, vp, ll, i, vp, vp]),
+    "unet_bn_bwd_finalize": (i, [vp, i, ll, i, vp, vp, vp, vp, vp]),
+    "unet_bn_bwd_apply": (i, [vp, i, i, vp, i, i, vp, i, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, i, i, ll, i, vp]),
+    "unet_maxpool3x3s2": (i, [vp, i, i, vp, i, i, vp, i, i, i, i, i, i, vp]),
+    "unet_maxpool3x3s2_bwd": (i, [vp, i, i, vp, vp, i, i, i, i, i, i, i, i, i, vp]),
+    "unet_avgpool2_ceil": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, vp]),
+    "unet_avgpool2_ceil_bwd": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, i, vp]),
+    "unet_shuffle_blur": (i, [vp, i, i, vp, i, i, i, i, i, i, i, vp]),
+    "unet_shuffle_blur_bwd": (i, [vp, i, i, vp, i, i, vp, i, i, i, i, i, i, i, vp]),
+    "unet_resize_nearest": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, vp]),
+    "unet_resize_nearest_bwd": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, vp]),
+    "unet_nchw_to_nhwc": (i, [vp, vp, i, i, i, i, i, i, vp]),
+    "unet_nhwc_to_nchw": (i, [vp, i, i, vp, i, i, i, i, vp]),
+    "unet_copy_slice": (i, [vp, i, i, vp, i, i, ll, i, i, vp]),
+    "unet_relu_mask": (i, [vp, i, i, vp, i, i, vp, i, i, ll, i, vp]),
+    "unet_colsum": (i, [vp, i, i, ll, i, vp, vp, vp]),
+    "unet_colsum_workspace": (sz, [ll, i]),
+    "unet_ce_workspace": (sz, [ll]),
+    "unet_ce_fwd": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp, vp]),
+    "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),
+    "unet_softmax_argmax": (i, [vp, i, i, i, i, i, i, vp, vp, vp]),
+    "unet_adam_step": (i, [vp, vp, vp, vp, vp, ll, c_float_p, f, f, f, f, i, f, vp]),
+    "unet_mosaic_accumulate": (i, [vp, i, i, i, vp, vp, i, i, i, i, vp]),
+    "unet_mosaic_finalize": (i, [vp, vp, i, i, i, vp, vp]),
+}
+for _name, (_res, _args) in _sig.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+_undeclared = [s for s in declared_symbols() if s not in _sig]
+if _undeclared:
+    raise ImportError(f"ctypes signatures missing for: {_undeclared}")
+
+if lib.unet_abi_version() != 1:
+    raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
+
+
+class UnetHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != UNET_OK:
+        msg = lib.unet_last_error().decode(errors="replace")
+        raise UnetHipError(f"{what}: rc={rc}: {msg}")

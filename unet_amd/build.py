@@ -1,0 +1,63 @@
+"""Build libunet_hip.so (gfx950) in-tree with hipcc.  `python -m unet_amd.build [--force] [--verbose]`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+REPO = ROOT.parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libunet_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", str(REPO / "include"), "-I", str(CSRC),
+         "-Wno-unused-value"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    LIBDIR.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [REPO / "include" / "unet_hip.h"]
+    srcs = _sources()
+    objs = [LIBDIR / (s.stem + ".o") for s in srcs]
+
+    def compile_one(so):
+        s, o = so
+        if not force and not _stale(o, [s, *headers]):
+            return None
+        cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s.name}:\n{r.stderr[-8000:]}")
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        logs = list(ex.map(compile_one, zip(srcs, objs)))
+    if verbose:
+        (LIBDIR / "resource_usage.log").write_text("\n".join(l for l in logs if l))
+    if force or _stale(LIB, objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build_lib(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(p)

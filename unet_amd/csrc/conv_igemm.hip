@@ -1,0 +1,496 @@
+// Implicit-GEMM convolution on fp32 MFMA for gfx950 (MI355X).
+//
+//   y[n, oy, ox, k] = epilogue( sum_{tap} sum_{c} x[n, oy*S + dy_tap, ox*S + dx_tap, c] * W[tap][c][k] )
+//
+// GEMM view: M = output pixels (32-row MFMA tiles of a TH x TW spatial tile),
+// N = produced channels, K = taps x reduction channels.  One workgroup owns a
+// BM(=128 pixel) x BN(32/64/128 channel) output tile:
+//   * the input HALO tile of the spatial tile is staged ONCE per 16-channel
+//     chunk into LDS and re-used by all 9 taps (no im2col, 9x less L2->LDS traffic);
+//   * the filter slab of one (tap, chunk) is staged per stage from a pre-packed
+//     [tap][chunk][cout][16] image (fully coalesced 16-B loads);
+//   * both are double buffered: global loads for stage s+1 are issued before the
+//     MFMAs of stage s and written to the other LDS buffer after them, one
+//     barrier per stage;
+//   * LDS rows are 20 floats (16 + 4 pad) so that the ds_read_b128 operand
+//     fetches (4 k-values per lane) are bank-conflict free;
+//   * v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+//     each lane half reads 4 consecutive channels -> 4 MFMA k-steps per b128 pair.
+//
+// The same kernel serves forward convs (3x3 s1/s2, 1x1) and input gradients
+// (dgrad: flipped taps with transposed packed weights; stride-2 dgrad as 4 output
+// parity classes with 1/2/2/4 taps each).
+//
+// Replaces the ATen conv kernels behind fastai ConvLayer (layers.py) as used by
+// XResNet / DynamicUnet built at reference train.py:128-144.
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;   // reduction channels per chunk
+constexpr int LDK = 20;  // LDS row length in floats (16 + 4 pad)
+
+struct TapSet {
+    int n;              // number of taps
+    int min_dy, min_dx; // halo origin offset (input coords relative to tile origin * S)
+    int ext_y, ext_x;   // halo extent beyond (T-1)*S
+    int py, px;         // output parity offsets (OS == 2)
+    signed char dy[9], dx[9], widx[9];
+};
+
+struct KArgs {
+    const float* x; const float* wp; const float* bias; const float* res; const float* mask;
+    float* y; float* colsum; float* colsumsq;
+    int x_cs, x_co, res_cs, res_co, mask_cs, mask_co, y_cs, y_co;
+    int N, IH, IW, Cin, Cin4;
+    int OH, OW, Cout;
+    int S, OS, TSH, TSW, tiles_y, tiles_x, ntn;
+    int nchunks, coutPad, flags, mtiles;
+    TapSet taps[4];
+};
+
+template <int HIT, int NTH>
+__device__ __forceinline__ void ld_halo(float4 (&hreg)[HIT], const int (&goff)[HIT], const float* xb, int c0, int Cin4, int tid) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int q = (tid + it * NTH) & 3;
+        const bool ok = goff[it] >= 0 && (c0 + 4 * q) < Cin4;
+        hreg[it] = ok ? *reinterpret_cast<const float4*>(xb + goff[it] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int HIT, int NTH>
+__device__ __forceinline__ void st_halo(const float4 (&hreg)[HIT], float* dst, int hpix4, int tid) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        if (e < hpix4) *reinterpret_cast<float4*>(dst + (e >> 2) * LDK + (e & 3) * 4) = hreg[it];
+    }
+}
+// filter slab staging: one or two float4 per thread, held in named registers (a 2-element
+// array here was demoted to scratch by the compiler)
+template <int WIT, int NTH, int BN>
+__device__ __forceinline__ void ld_w(float4& w0, float4& w1, const float* src, int tid) {
+    static_assert(WIT == 1 || WIT == 2, "WIT");
+    int e = tid;
+    if constexpr ((BN * 4) % NTH != 0) e = e < BN * 4 ? e : BN * 4 - 1;  // clamp: the load stays unconditional
+    w0 = *reinterpret_cast<const float4*>(src + e * 4);
+    if constexpr (WIT == 2) w1 = *reinterpret_cast<const float4*>(src + (tid + NTH) * 4);
+}
+template <int WIT, int NTH, int BN>
+__device__ __forceinline__ void st_w(const float4& w0, const float4& w1, float* dst, int tid) {
+    if ((BN * 4) % NTH == 0 || tid < BN * 4) *reinterpret_cast<float4*>(dst + (tid >> 2) * LDK + (tid & 3) * 4) = w0;
+    if constexpr (WIT == 2) {
+        const int e = tid + NTH;
+        *reinterpret_cast<float4*>(dst + (e >> 2) * LDK + (e & 3) * 4) = w1;
+    }
+}
+
+template <int TW, int MT, int NT, int WM, int WN, int HIT>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs a) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
+    constexpr int WIT = (BN * 4 + NTH - 1) / NTH;  // weight float4 items per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const TapSet& ts = a.taps[blockIdx.z];
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.ntn; bid /= a.ntn;
+    const int mtile = bid;
+    const int tx_t = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty_t = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int oy0 = ty_t * TH, ox0 = tx_t * TW;
+    const int n0 = nt * BN;
+
+    const int S = a.S;
+    const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
+    const int HPIX = HH * HW;
+    // LDS map: [0,32) ints tap tables | halo[2] | wts[2]   (buffers addressed arithmetically: no runtime-indexed arrays)
+    int* s_tapoff = reinterpret_cast<int*>(smem);       // [0..8]  LDS float offset of the tap's window inside the halo tile
+    int* s_widx = reinterpret_cast<int*>(smem) + 16;    // [0..8]  packed-weight tap index
+    float* lds0 = smem + 32;
+    auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDK); };
+    auto wts_buf = [&](int b) -> float* { return lds0 + 2 * HPIX * LDK + b * (BN * LDK); };
+    if (tid < 9) {
+        const int t = tid < ts.n ? tid : 0;
+        s_tapoff[tid] = ((ts.dy[t] - ts.min_dy) * HW + (ts.dx[t] - ts.min_dx)) * LDK;
+        s_widx[tid] = ts.widx[t];
+    }
+
+    // ---- per-thread halo item addressing (independent of the chunk) ----
+    const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
+    const int iy0 = oy0 * S + ts.min_dy, ix0 = ox0 * S + ts.min_dx;
+    int goff[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        const int p = e >> 2, q = e & 3;
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool inb = (e < HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        goff[it] = inb ? ((iy * a.IW + ix) * a.x_cs + a.x_co + 4 * q) : -1;
+    }
+
+    float4 hreg[HIT];
+    float4 wreg0, wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define LOAD_HALO(chunk_) ld_halo<HIT, NTH>(hreg, goff, xb, (chunk_) * KC, a.Cin4, tid)
+#define STORE_HALO(dst_) st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid)
+#define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
+#define STORE_W(dst_) st_w<WIT, NTH, BN>(wreg0, wreg1, (dst_), tid)
+
+    // ---- MFMA operand addressing ----
+    int abase[MT], bbase[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pix = (wm * MT + m) * 32 + l31;
+        const int ty = pix / TW, tx = pix % TW;
+        abase[m] = ((ty * S) * HW + tx * S) * LDK + 4 * h;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bbase[n] = ((wn * NT + n) * 32 + l31) * LDK + 4 * h;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- pipeline prologue ----
+    const int ntaps = ts.n;
+    LOAD_HALO(0);
+    LOAD_W(ts.widx[0], 0);
+    STORE_HALO(halo_buf(0));
+    STORE_W(wts_buf(0));
+    __syncthreads();
+
+    int s = 0;
+    const int total = a.nchunks * ntaps;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        int ng = (a.Cin - chunk * KC + 7) >> 3;
+        ng = ng > 2 ? 2 : ng;
+        const float* hb = halo_buf(chunk & 1);
+        for (int t = 0; t < ntaps; ++t, ++s) {
+            const bool has_next = (s + 1) < total;
+            if (has_next) {
+                const bool wrap = (t + 1 == ntaps);
+                LOAD_W(s_widx[wrap ? 0 : t + 1], wrap ? chunk + 1 : chunk);
+            }
+            const bool halo_next = (chunk + 1 < a.nchunks);
+            if (t == 0 && halo_next) LOAD_HALO(chunk + 1);
+
+            const float* wb = wts_buf(s & 1);
+            const int tapoff = s_tapoff[t];
+            for (int g = 0; g < ng; ++g) {
+                float av[MT][4], bv4[NT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 f = *reinterpret_cast<const float4*>(hb + abase[m] + tapoff + 8 * g);
+                    av[m][0] = f.x; av[m][1] = f.y; av[m][2] = f.z; av[m][3] = f.w;
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 f = *reinterpret_cast<const float4*>(wb + bbase[n] + 8 * g);
+                    bv4[n][0] = f.x; bv4[n][1] = f.y; bv4[n][2] = f.z; bv4[n][3] = f.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][kk], bv4[n][kk], acc[m][n], 0, 0, 0);
+            }
+            if (has_next) STORE_W(wts_buf((s + 1) & 1));
+            if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1));
+            __syncthreads();
+        }
+    }
+
+#undef LOAD_HALO
+#undef STORE_HALO
+#undef LOAD_W
+#undef STORE_W
+
+    // ---- epilogue ----
+    // Phased per 32x32 tile (offsets -> residual loads -> mask loads -> math -> stores) so that the
+    // optional loads are issued back to back instead of one dependent round trip per element.
+    const bool relu = a.flags & UNET_CONV_RELU;
+    const int OS = a.OS;
+    // per-image bases (64-bit, uniform) + 32-bit in-image pixel index
+    const size_t img_pix = (size_t)img * a.OH * a.OW;
+    float* yb = a.y + img_pix * a.y_cs + a.y_co;
+    const float* resb = a.res ? a.res + img_pix * a.res_cs + a.res_co : nullptr;
+    const float* maskb = a.mask ? a.mask + img_pix * a.mask_cs + a.mask_co : nullptr;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cout = n0 + (wn * NT + n) * 32 + l31;
+        const bool cvalid = cout < a.Cout;
+        const float bv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int pidx[16];
+            bool valid[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int pix = (wm * MT + m) * 32 + row;
+                const int ty = pix / TW, tx = pix % TW;
+                const int oyt = oy0 + ty, oxt = ox0 + tx;
+                const int oy = oyt * OS + ts.py, ox = oxt * OS + ts.px;
+                valid[r] = cvalid && oyt < a.TSH && oxt < a.TSW && oy < a.OH && ox < a.OW;
+                pidx[r] = valid[r] ? (oy * a.OW + ox) : 0;  // pixel 0 is always addressable
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bv;
+            if (a.res != nullptr) {
+                const int cc = cvalid ? cout : 0;
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = resb[pidx[r] * a.res_cs + cc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.mask != nullptr) {
+                const int cc = cvalid ? cout : 0;
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = maskb[pidx[r] * a.mask_cs + cc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (valid[r]) {
+                    yb[pidx[r] * a.y_cs + cout] = v[r];
+                    csum += v[r];
+                    csq += v[r] * v[r];
+                }
+            }
+        }
+        if (a.colsum != nullptr) {
+            csum += __shfl_xor(csum, 32);
+            csq += __shfl_xor(csq, 32);
+            if (h == 0 && cvalid) {
+                const size_t row = ((size_t)blockIdx.z * a.mtiles + mtile) * WM + wm;
+                a.colsum[row * a.Cout + cout] = csum;
+                if (a.colsumsq != nullptr) a.colsumsq[row * a.Cout + cout] = csq;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ packing
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int T,
+                                    int mode, int nchunks, int outPad, size_t total) {
+    // wp[tap][chunk][o][16]; mode 0: o = cout, reduction r = cin; mode 1: o = cin, reduction r = cout
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i & 15);
+        size_t j = i >> 4;
+        const int o = (int)(j % outPad); j /= outPad;
+        const int chunk = (int)(j % nchunks);
+        const int tap = (int)(j / nchunks);
+        const int r = chunk * 16 + rr;
+        float v = 0.f;
+        if (mode == 0) {
+            if (o < Cout && r < Cin) v = w[((size_t)o * Cin + r) * T + tap];
+        } else {
+            if (o < Cin && r < Cout) v = w[((size_t)r * Cin + o) * T + tap];
+        }
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+struct Plan {
+    KArgs k;
+    int tw, bn, hit, nparity;
+    size_t lds_bytes;
+    dim3 grid;
+};
+
+int make_plan(const unet_conv_desc* d, Plan* p) {
+    UNET_CHECK_ARG(d != nullptr, "conv: null desc");
+    UNET_CHECK_ARG(d->x && d->wp && d->y, "conv: null tensor pointer");
+    UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv: ks must be 1 or 3 (got %d)", d->ks);
+    UNET_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
+    UNET_CHECK_ARG(!(d->ks == 1 && d->stride != 1), "conv: 1x1 stride 2 unsupported");
+    UNET_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims");
+    UNET_CHECK_ARG(unet::slice_ok(d->x_cs, d->x_co, d->Cin), "conv: bad x slice cs=%d co=%d C=%d", d->x_cs, d->x_co, d->Cin);
+    UNET_CHECK_ARG(unet::slice_ok(d->y_cs, d->y_co, d->Cout), "conv: bad y slice cs=%d co=%d C=%d", d->y_cs, d->y_co, d->Cout);
+    UNET_CHECK_ARG(unet::aligned16(d->x) && unet::aligned16(d->wp), "conv: x/wp must be 16-byte aligned");
+    if (d->res) UNET_CHECK_ARG(unet::slice_ok(d->res_cs, d->res_co, d->Cout), "conv: bad res slice");
+    if (d->flags & UNET_CONV_MASK) UNET_CHECK_ARG(d->mask && unet::slice_ok(d->mask_cs, d->mask_co, d->Cout), "conv: bad mask slice");
+    const int pad = (d->ks - 1) / 2;
+    if (d->kind == UNET_CONV_FWD) {
+        UNET_CHECK_ARG(d->OH == (d->IH + 2 * pad - d->ks) / d->stride + 1 && d->OW == (d->IW + 2 * pad - d->ks) / d->stride + 1,
+                       "conv fwd: output dims %dx%d inconsistent with input %dx%d ks %d stride %d", d->OH, d->OW, d->IH, d->IW, d->ks, d->stride);
+    } else if (d->kind == UNET_CONV_DGRAD) {
+        // here I* = dims of the forward OUTPUT gradient, O* = dims of the forward INPUT
+        UNET_CHECK_ARG(d->IH == (d->OH + 2 * pad - d->ks) / d->stride + 1 && d->IW == (d->OW + 2 * pad - d->ks) / d->stride + 1,
+                       "conv dgrad: grad dims %dx%d inconsistent with input dims %dx%d", d->IH, d->IW, d->OH, d->OW);
+    } else {
+        UNET_CHECK_ARG(false, "conv: bad kind %d", d->kind);
+    }
+    // the image-local offsets are 32-bit
+    UNET_CHECK_ARG((long long)d->IH * d->IW * d->x_cs < (1ll << 31) && (long long)d->OH * d->OW * d->y_cs < (1ll << 31) &&
+                       (long long)d->OH * d->OW * (d->res ? d->res_cs : 1) < (1ll << 31) &&
+                       (long long)d->OH * d->OW * ((d->flags & UNET_CONV_MASK) ? d->mask_cs : 1) < (1ll << 31),
+                   "conv: image too large for 32-bit in-image offsets");
+
+    KArgs& k = p->k;
+    memset(&k, 0, sizeof(k));
+    k.x = d->x; k.wp = d->wp; k.bias = d->bias; k.res = d->res; k.mask = (d->flags & UNET_CONV_MASK) ? d->mask : nullptr;
+    k.y = d->y; k.colsum = d->colsum; k.colsumsq = d->colsumsq;
+    k.x_cs = d->x_cs; k.x_co = d->x_co; k.res_cs = d->res_cs; k.res_co = d->res_co;
+    k.mask_cs = d->mask_cs; k.mask_co = d->mask_co; k.y_cs = d->y_cs; k.y_co = d->y_co;
+    k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, 4);
+    k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
+    k.flags = d->flags;
+    k.nchunks = unet::cdiv(d->Cin, KC);
+    k.coutPad = unet::roundup(d->Cout, 128);
+    p->nparity = 1;
+    k.S = 1; k.OS = 1; k.TSH = d->OH; k.TSW = d->OW;
+
+    const int T = d->ks * d->ks;
+    if (d->kind == UNET_CONV_FWD) {
+        k.S = d->stride;
+        TapSet& t = k.taps[0];
+        t.n = T; t.min_dy = -pad; t.min_dx = -pad; t.ext_y = d->ks; t.ext_x = d->ks; t.py = t.px = 0;
+        for (int r = 0; r < d->ks; ++r)
+            for (int s = 0; s < d->ks; ++s) {
+                const int i = r * d->ks + s;
+                t.dy[i] = (signed char)(r - pad); t.dx[i] = (signed char)(s - pad); t.widx[i] = (signed char)i;
+            }
+    } else if (d->stride == 1) {
+        TapSet& t = k.taps[0];
+        t.n = T; t.min_dy = -pad; t.min_dx = -pad; t.ext_y = d->ks; t.ext_x = d->ks; t.py = t.px = 0;
+        for (int r = 0; r < d->ks; ++r)
+            for (int s = 0; s < d->ks; ++s) {
+                const int i = r * d->ks + s;
+                t.dy[i] = (signed char)(pad - r); t.dx[i] = (signed char)(pad - s); t.widx[i] = (signed char)i;
+            }
+    } else {
+        // stride-2 3x3 pad-1 dgrad: 4 output parity classes.  Output row 2*o+py receives
+        //   py = 0: r = 1 from grad row o        py = 1: r = 0 from grad row o+1, r = 2 from grad row o
+        k.OS = 2; k.TSH = (d->OH + 1) / 2; k.TSW = (d->OW + 1) / 2;
+        p->nparity = 4;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                TapSet& t = k.taps[py * 2 + px];
+                int rs[2], rdy[2], nr, ss[2], sdx[2], ns;
+                if (py == 0) { nr = 1; rs[0] = 1; rdy[0] = 0; } else { nr = 2; rs[0] = 0; rdy[0] = 1; rs[1] = 2; rdy[1] = 0; }
+                if (px == 0) { ns = 1; ss[0] = 1; sdx[0] = 0; } else { ns = 2; ss[0] = 0; sdx[0] = 1; ss[1] = 2; sdx[1] = 0; }
+                t.n = nr * ns; t.min_dy = 0; t.min_dx = 0; t.ext_y = (py == 0) ? 1 : 2; t.ext_x = (px == 0) ? 1 : 2;
+                t.py = py; t.px = px;
+                int i = 0;
+                for (int a = 0; a < nr; ++a)
+                    for (int b = 0; b < ns; ++b, ++i) {
+                        t.dy[i] = (signed char)rdy[a]; t.dx[i] = (signed char)sdx[b]; t.widx[i] = (signed char)(rs[a] * 3 + ss[b]);
+                    }
+            }
+    }
+
+    p->tw = k.TSW >= 32 ? 32 : (k.TSW >= 16 ? 16 : 8);
+    const int th = 128 / p->tw;
+    p->bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+    p->hit = (k.S == 2) ? 10 : 4;
+    k.tiles_y = unet::cdiv(k.TSH, th);
+    k.tiles_x = unet::cdiv(k.TSW, p->tw);
+    k.ntn = unet::cdiv(d->Cout, p->bn);
+    k.mtiles = d->N * k.tiles_y * k.tiles_x;
+    int max_hpix = 0;
+    for (int z = 0; z < p->nparity; ++z) {
+        const int hh = (th - 1) * k.S + k.taps[z].ext_y, hw = (p->tw - 1) * k.S + k.taps[z].ext_x;
+        if (hh * hw > max_hpix) max_hpix = hh * hw;
+    }
+    UNET_CHECK_ARG(max_hpix * 4 <= p->hit * 256, "conv: halo tile too large (%d pixels)", max_hpix);
+    p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + 2 * p->bn * LDK) * sizeof(float);
+    p->grid = dim3((unsigned)((long long)k.mtiles * k.ntn), 1, (unsigned)p->nparity);
+    UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");
+    return UNET_OK;
+}
+
+template <int TW, int MT, int NT, int WM, int WN, int HIT>
+int launch_cfg(const Plan& p, hipStream_t st) {
+    auto kern = conv_igemm_kernel<TW, MT, NT, WM, WN, HIT>;
+    static size_t configured = 0;  // per instantiation
+    if (p.lds_bytes > configured) {
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = 160 * 1024;
+    }
+    hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+template <int TW, int HIT>
+int launch_bn(const Plan& p, hipStream_t st) {
+    switch (p.bn) {
+        case 32: return launch_cfg<TW, 1, 1, 4, 1, HIT>(p, st);
+        case 64: return launch_cfg<TW, 2, 1, 2, 2, HIT>(p, st);
+        default: return launch_cfg<TW, 2, 2, 2, 2, HIT>(p, st);
+    }
+}
+
+template <int HIT>
+int launch_tw(const Plan& p, hipStream_t st) {
+    switch (p.tw) {
+        case 32: return launch_bn<32, HIT>(p, st);
+        case 16: return launch_bn<16, HIT>(p, st);
+        default: return launch_bn<8, HIT>(p, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
+    Plan p;
+    int rc = make_plan(d, &p);
+    if (rc != UNET_OK) return rc;
+    const int wm = (p.bn == 32) ? 4 : 2;
+    return p.nparity * p.k.mtiles * wm;
+}
+
+extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
+    Plan p;
+    int rc = make_plan(d, &p);
+    if (rc != UNET_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
+}
+
+extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {
+    const int T = ks * ks;
+    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    return (size_t)T * unet::cdiv(red, KC) * unet::roundup(out, 128) * KC;
+}
+
+extern "C" int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream) {
+    UNET_CHECK_ARG(w && wp, "pack_weights: null pointer");
+    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1) && Cout > 0 && Cin > 0, "pack_weights: bad args");
+    const int T = ks * ks;
+    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int nchunks = unet::cdiv(red, KC), outPad = unet::roundup(out, 128);
+    const size_t total = (size_t)T * nchunks * outPad * KC;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wp, Cout, Cin, T, mode, nchunks, outPad, total);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}

@@ -1,0 +1,264 @@
+// Weight gradient of the 3x3 / 1x1 convolutions on fp32 MFMA for gfx950.
+//
+//   dW[k][c][r][s] = sum_{n,oy,ox} dy[n,oy,ox,k] * x[n, oy*S + r - pad, ox*S + s - pad, c]
+//
+// GEMM view: M = 64 output channels (k), N = 64 input channels (c), reduction =
+// pixels; one accumulator tile per filter tap, all taps kept live (each wave owns
+// 32 k x 32 c x T taps = T*16 accumulator VGPRs).  A workgroup walks a contiguous
+// range of pixel tiles (split-K over pixels); per tile it stages the dy tile
+// [PT pixels][64 k] and the x HALO tile [halo pixels][64 c] into LDS once and all
+// taps read shifted windows of the same halo image.  Both MFMA operands are read
+// as 32 consecutive floats per half-wave (NHWC rows), i.e. conflict-free ds_read_b32:
+//   v_mfma_f32_32x32x2_f32: A[i=l&31][kk=l>>5] = dy[pixel 2*step+kk][k0+i]
+//                           B[kk=l>>5][j=l&31] = x[pixel 2*step+kk shifted by tap][c0+j]
+// Partials are written [split][tap][k][c] (coalesced) and reduced deterministically
+// by a second kernel into the torch layout [Cout][Cin][ks][ks].
+//
+// Replaces the autograd weight-gradient ATen kernels for fastai ConvLayer convs
+// (reference train.py:247-250 -> loss.backward()).
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 64;  // output channels per block
+constexpr int BC = 64;  // input channels per block
+
+struct WArgs {
+    const float* x; const float* dy; float* part;
+    int x_cs, x_co, dy_cs, dy_co;
+    int N, IH, IW, Cin, Cin4, OH, OW, Cout, Cout4;
+    int tiles_y, tiles_x, total_tiles, tiles_per_block;
+    int kt, ct;  // number of k / c block tiles
+};
+
+template <int PTW, int S, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
+    constexpr int PT = (S == 1) ? 64 : 32;      // pixels per tile
+    constexpr int PTH = PT / PTW;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int T = KS * KS;
+    constexpr int HH = (PTH - 1) * S + KS, HW = (PTW - 1) * S + KS, HPIX = HH * HW;
+    constexpr int DIT = (PT * 16 + 255) / 256;     // dy float4 items per thread
+    constexpr int XIT = (HPIX * 16 + 255) / 256;   // x  float4 items per thread
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dyT = smem;                 // [PT][64]
+    float* xh = smem + PT * BK;        // [HPIX][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
+    const int k0 = kblk * BK, c0 = cblk * BC;
+    const int split = blockIdx.y;
+    const int tile_begin = split * a.tiles_per_block;
+    int tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Stage one pixel tile: global -> registers -> LDS in batches of 4 float4 per thread (the
+    // accumulators own most of the register file; the co-resident workgroup hides this phase).
+    auto stage_tile = [&](int tile) {
+        int b = tile;
+        const int tx = b % a.tiles_x; b /= a.tiles_x;
+        const int ty = b % a.tiles_y;
+        const int img = b / a.tiles_y;
+        const int oy0 = ty * PTH, ox0 = tx * PTW;
+        const float* dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
+        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
+        {
+            float4 r[DIT];
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                const int p = e >> 4, q = e & 15;
+                const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
+                const bool ok = (e < PT * 16) && oy < a.OH && ox < a.OW && (k0 + 4 * q) < a.Cout4;
+                r[it] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                if (e < PT * 16) *reinterpret_cast<float4*>(dyT + e * 4) = r[it];
+            }
+        }
+        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+        constexpr int XB = 4;
+#pragma unroll
+        for (int base = 0; base < XIT; base += XB) {
+            float4 r[XB];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int e = tid + (base + j) * 256;
+                const int p = e >> 4, q = e & 15;
+                const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+                const bool ok = (e < HPIX * 16) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
+                r[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int e = tid + (base + j) * 256;
+                if (e < HPIX * 16) *reinterpret_cast<float4*>(xh + e * 4) = r[j];
+            }
+        }
+    };
+
+    // per-lane operand bases (floats)
+    const float* abase = dyT + h * BK + wk * 32 + l31;                  // + (2*step) * BK
+    const float* bbase = xh + (h * S) * BC + wc * 32 + l31;             // + window offset
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        stage_tile(tile);
+        __syncthreads();
+#pragma unroll
+        for (int step = 0; step < PT / 2; ++step) {
+            // pixel 2*step + h ; 2*step is even and PTW is even, so px = (2*step % PTW) + h, py = 2*step / PTW
+            const int py = (2 * step) / PTW, px = (2 * step) % PTW;
+            const float av = abase[(2 * step) * BK];
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const float bv = bbase[((py * S + r) * HW + px * S + s) * BC];
+                    acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KS + s], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- write partials: part[split][tap][k][c] ----
+    const size_t KC_ = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)split * T * KC_;
+    const int c = c0 + wc * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (k < a.Cout && c < a.Cin) pb[(size_t)t * KC_ + (size_t)k * a.Cin + c] = acc[t][r];
+        }
+}
+
+// dw[(k*Cin + c)*T + t] (=|+=) sum_split part[split][t][k][c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, size_t KC_,
+                                    int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < KC_; i += (size_t)gridDim.x * blockDim.x) {
+        for (int t = 0; t < T; ++t) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += part[((size_t)sp * T + t) * KC_ + i];
+            if (accumulate) dw[i * T + t] += s; else dw[i * T + t] = s;
+        }
+    }
+}
+
+struct WPlan {
+    WArgs k;
+    int ptw, splits, T;
+    size_t lds_bytes;
+};
+
+int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
+    UNET_CHECK_ARG(d != nullptr, "wgrad: null desc");
+    UNET_CHECK_ARG(d->x && d->dy && d->dw, "wgrad: null tensor pointer");
+    UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "wgrad: ks must be 1 or 3");
+    UNET_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride must be 1 or 2");
+    UNET_CHECK_ARG(!(d->ks == 1 && d->stride != 1), "wgrad: 1x1 stride 2 unsupported");
+    UNET_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0, "wgrad: bad dims");
+    const int pad = (d->ks - 1) / 2;
+    UNET_CHECK_ARG(d->OH == (d->IH + 2 * pad - d->ks) / d->stride + 1 && d->OW == (d->IW + 2 * pad - d->ks) / d->stride + 1,
+                   "wgrad: output dims inconsistent");
+    UNET_CHECK_ARG(unet::slice_ok(d->x_cs, d->x_co, d->Cin), "wgrad: bad x slice");
+    UNET_CHECK_ARG(unet::slice_ok(d->dy_cs, d->dy_co, d->Cout), "wgrad: bad dy slice");
+    UNET_CHECK_ARG(unet::aligned16(d->x) && unet::aligned16(d->dy), "wgrad: x/dy must be 16-byte aligned");
+    WArgs& k = p->k;
+    memset(&k, 0, sizeof(k));
+    k.x = d->x; k.dy = d->dy; k.part = d->workspace;
+    k.x_cs = d->x_cs; k.x_co = d->x_co; k.dy_cs = d->dy_cs; k.dy_co = d->dy_co;
+    k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, 4);
+    k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cout4 = unet::roundup(d->Cout, 4);
+    p->T = d->ks * d->ks;
+    p->ptw = d->OW >= 32 ? 32 : (d->OW >= 16 ? 16 : 8);
+    const int pt = d->stride == 1 ? 64 : 32;
+    const int pth = pt / p->ptw;
+    k.tiles_y = unet::cdiv(d->OH, pth);
+    k.tiles_x = unet::cdiv(d->OW, p->ptw);
+    k.total_tiles = d->N * k.tiles_y * k.tiles_x;
+    k.kt = unet::cdiv(d->Cout, BK);
+    k.ct = unet::cdiv(d->Cin, BC);
+    // aim for ~1024 workgroups (256 CUs x 2 resident x 2 waves of blocks); at least 4 tiles per block
+    int want = 1024 / (k.kt * k.ct);
+    if (want < 1) want = 1;
+    int tpb = unet::cdiv(k.total_tiles, want);
+    if (tpb < 4) tpb = 4;
+    if (tpb > k.total_tiles) tpb = k.total_tiles;
+    k.tiles_per_block = tpb;
+    p->splits = unet::cdiv(k.total_tiles, tpb);
+    const int hh = (pth - 1) * d->stride + d->ks, hw = (p->ptw - 1) * d->stride + d->ks;
+    p->lds_bytes = (size_t)(pt * BK + hh * hw * BC) * sizeof(float);
+    return UNET_OK;
+}
+
+template <int PTW, int S, int KS>
+int launch_w(const WPlan& p, hipStream_t st) {
+    auto kern = wgrad_kernel<PTW, S, KS>;
+    static bool configured = false;
+    if (!configured) {
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes, st, p.k);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+template <int PTW>
+int launch_w_ptw(const WPlan& p, int ks, int stride, hipStream_t st) {
+    if (ks == 1) return launch_w<PTW, 1, 1>(p, st);
+    if (stride == 1) return launch_w<PTW, 1, 3>(p, st);
+    return launch_w<PTW, 2, 3>(p, st);
+}
+
+}  // namespace
+
+extern "C" size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d) {
+    WPlan p;
+    if (make_wplan(d, &p) != UNET_OK) return 0;
+    return (size_t)p.splits * p.T * d->Cout * d->Cin;
+}
+
+extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
+    WPlan p;
+    int rc = make_wplan(d, &p);
+    if (rc != UNET_OK) return rc;
+    const size_t need = (size_t)p.splits * p.T * d->Cout * d->Cin;
+    UNET_CHECK_ARG(d->workspace != nullptr && d->workspace_floats >= need, "wgrad: workspace too small (%zu < %zu floats)",
+                   d->workspace_floats, need);
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.ptw) {
+        case 32: rc = launch_w_ptw<32>(p, d->ks, d->stride, st); break;
+        case 16: rc = launch_w_ptw<16>(p, d->ks, d->stride, st); break;
+        default: rc = launch_w_ptw<8>(p, d->ks, d->stride, st); break;
+    }
+    if (rc != UNET_OK) return rc;
+    const size_t KC_ = (size_t)d->Cout * d->Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_, 256)), dim3(256), 0, st, d->workspace, d->dw,
+                       p.splits, p.T, KC_, d->accumulate);
+    UNET_CHECK_LAUNCH();
+    if (d->dbias != nullptr) {
+        // bias gradient = column sums of dy; workspace is free again after the reduce (stream ordered)
+        const long long P = (long long)d->N * d->OH * d->OW;
+        UNET_CHECK_ARG(d->workspace_floats >= unet_colsum_workspace(P, d->Cout), "wgrad: workspace too small for dbias");
+        return unet_colsum(d->dy, d->dy_cs, d->dy_co, P, d->Cout, d->dbias, d->workspace, stream);
+    }
+    return UNET_OK;
+}

@@ -1,0 +1,971 @@
+// HBM-bound kernels of the U-Net step for gfx950: BatchNorm statistics / apply /
+// backward, pooling, pixel-shuffle + blur data movement, layout conversion,
+// per-pixel weighted cross-entropy, softmax/argmax, fused Adam.
+// All tensors fp32 NHWC slices (ptr, channel stride cs, channel offset co);
+// every access is a 16-byte float4 with consecutive lanes on consecutive channels
+// (coalesced), grid-stride loops capped at 2048 workgroups.
+//
+// Reference call sites these replace: fastai layers.py (BatchNorm, ResBlock.forward,
+// PixelShuffle_ICNR), vision/models/unet.py (UnetBlock.forward), losses.py
+// (CrossEntropyLossFlat), optimizer.py (Adam) as driven by reference train.py:128-250
+// and predict.py:193-232.
+
+#include <math.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace unet {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace unet
+
+extern "C" int unet_abi_version(void) { return UNET_ABI_VERSION; }
+extern "C" const char* unet_last_error(void) { return unet::g_err; }
+
+namespace {
+
+using unet::cdiv;
+using unet::ew_grid;
+using unet::roundup;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 gate4(float4 g, float4 ref) {
+    return make_float4(ref.x > 0.f ? g.x : 0.f, ref.y > 0.f ? g.y : 0.f, ref.z > 0.f ? g.z : 0.f, ref.w > 0.f ? g.w : 0.f);
+}
+
+// --------------------------------------------------------------------------
+// Per-channel reduction over pixels.  F(p, c4) -> two float4 values; result
+// planes out0[rows][Cp], out1[rows][Cp] (one row per workgroup).
+// Thread layout: tx = channel quad (TC lanes), ty = pixel sub-index (256/TC).
+// --------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void channel_reduce(F f, long long P, int C4, int TC, float* out0, float* out1, int Cp) {
+    __shared__ float4 sm0[256];
+    __shared__ float4 sm1[256];
+    const int tx = threadIdx.x % TC, ty = threadIdx.x / TC, PY = 256 / TC;
+    for (int cbase = 0; cbase < C4; cbase += TC) {
+        const int c4 = cbase + tx;
+        float4 s0 = f4(0.f), s1 = f4(0.f);
+        if (c4 < C4) {
+            for (long long p = (long long)blockIdx.x * PY + ty; p < P; p += (long long)gridDim.x * PY) {
+                float4 v0, v1;
+                f(p, c4, v0, v1);
+                s0 = s0 + v0;
+                s1 = s1 + v1;
+            }
+        }
+        sm0[threadIdx.x] = s0;
+        sm1[threadIdx.x] = s1;
+        __syncthreads();
+        if (ty == 0 && c4 < C4) {
+            for (int j = 1; j < PY; ++j) {
+                s0 = s0 + sm0[j * TC + tx];
+                s1 = s1 + sm1[j * TC + tx];
+            }
+            st4(out0 + (size_t)blockIdx.x * Cp + 4 * c4, s0);
+            if (out1 != nullptr) st4(out1 + (size_t)blockIdx.x * Cp + 4 * c4, s1);
+        }
+        __syncthreads();
+    }
+}
+
+static int pick_tc(int C4) {
+    int tc = 1;
+    while (tc < C4 && tc < 64) tc <<= 1;
+    return tc;
+}
+
+static int stats_rows(long long P) {
+    long long r = (P + 127) / 128;
+    if (r < 1) r = 1;
+    if (r > 1024) r = 1024;
+    return (int)r;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int cs, int co, long long P, int C4, int TC,
+                                                       float* out0, float* out1, int Cp) {
+    channel_reduce(
+        [&](long long p, int c4, float4& v0, float4& v1) {
+            const float4 v = ld4(x + (size_t)p * cs + co + 4 * c4);
+            v0 = v;
+            v1 = v * v;
+        },
+        P, C4, TC, out0, out1, Cp);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int cs, int co, long long P, int C4, int TC,
+                                                     float* out0, int Cp) {
+    channel_reduce(
+        [&](long long p, int c4, float4& v0, float4& v1) {
+            v0 = ld4(x + (size_t)p * cs + co + 4 * c4);
+            v1 = f4(0.f);
+        },
+        P, C4, TC, out0, nullptr, Cp);
+}
+
+__global__ void rows_sum_kernel(const float* __restrict__ part, int rows, int Cp, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * Cp + c];
+    out[c] = (float)s;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumsq, int rows, int rstride,
+                                   double count, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                   float* shift, float* save_mean, float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += (double)psum[(size_t)r * rstride + c];
+        q += (double)psumsq[(size_t)r * rstride + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                      float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ x2, int x2_cs,
+                                                         int x2_co, const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                         float* __restrict__ y, int y_cs, int y_co, long long P, int C4, int relu) {
+    const long long total = P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C4;
+        const int c = 4 * (int)(i - p * C4);
+        float4 v = ld4(x + (size_t)p * x_cs + x_co + c);
+        if (scale != nullptr) v = v * ld4(scale + c) + ld4(shift + c);
+        if (x2 != nullptr) {
+            float4 w = ld4(x2 + (size_t)p * x2_cs + x2_co + c);
+            if (scale2 != nullptr) w = w * ld4(scale2 + c) + ld4(shift2 + c);
+            v = v + w;
+        }
+        if (relu) v = relu4(v);
+        st4(y + (size_t)p * y_cs + y_co + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, int d_cs, int d_co,
+                                                            const float* __restrict__ out, int o_cs, int o_co,
+                                                            const float* __restrict__ x, int x_cs, int x_co,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            long long P, int C4, int TC, float* out0, float* out1, int Cp) {
+    channel_reduce(
+        [&](long long p, int c4, float4& v0, float4& v1) {
+            float4 g = ld4(dout + (size_t)p * d_cs + d_co + 4 * c4);
+            if (out != nullptr) g = gate4(g, ld4(out + (size_t)p * o_cs + o_co + 4 * c4));
+            const float4 xh = (ld4(x + (size_t)p * x_cs + x_co + 4 * c4) - ld4(mean + 4 * c4)) * ld4(invstd + 4 * c4);
+            v0 = g;
+            v1 = g * xh;
+        },
+        P, C4, TC, out0, out1, Cp);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int Cp, double count, int C, float* dgamma,
+                                       float* dbeta, float* c1, float* c2, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    const float* p1 = part + (size_t)rows * Cp;
+    for (int r = 0; r < rows; ++r) {
+        s += (double)part[(size_t)r * Cp + c];
+        q += (double)p1[(size_t)r * Cp + c];
+    }
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+    c1[c] = (float)(s / count);
+    c2[c] = (float)(q / count);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int d_cs, int d_co,
+                                                           const float* __restrict__ out, int o_cs, int o_co,
+                                                           const float* __restrict__ x, int x_cs, int x_co,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, float* __restrict__ dx, int dx_cs, int dx_co,
+                                                           float* gout, int g_cs, int g_co, int g_acc, long long P, int C4) {
+    const long long total = P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C4;
+        const int c = 4 * (int)(i - p * C4);
+        float4 g = ld4(dout + (size_t)p * d_cs + d_co + c);
+        if (out != nullptr) g = gate4(g, ld4(out + (size_t)p * o_cs + o_co + c));
+        const float4 is = ld4(invstd + c);
+        const float4 xh = (ld4(x + (size_t)p * x_cs + x_co + c) - ld4(mean + c)) * is;
+        const float4 gm = gamma ? ld4(gamma + c) : f4(1.f);
+        const float4 r = gm * is * (g - ld4(c1 + c) - xh * ld4(c2 + c));
+        st4(dx + (size_t)p * dx_cs + dx_co + c, r);
+        if (gout != nullptr) {
+            float* gp = gout + (size_t)p * g_cs + g_co + c;
+            st4(gp, g_acc ? (ld4(gp) + g) : g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pooling
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+                                                      int y_co, uint8_t* __restrict__ idx, int N, int IH, int IW, int C4, int OH, int OW) {
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int mi[4] = {-1, -1, -1, -1};
+        for (int r = 0; r < 3; ++r) {
+            const int iy = 2 * oy - 1 + r;
+            if (iy < 0 || iy >= IH) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int ix = 2 * ox - 1 + s;
+                if (ix < 0 || ix >= IW) continue;
+                const float4 v = ld4(x + ((size_t)(n * IH + iy) * IW + ix) * x_cs + x_co + c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (mi[j] < 0 || vv[j] > m[j] || vv[j] != vv[j]) { m[j] = vv[j]; mi[j] = r * 3 + s; }
+            }
+        }
+        const size_t po = (size_t)(n * OH + oy) * OW + ox;
+        st4(y + po * y_cs + y_co + c, make_float4(m[0], m[1], m[2], m[3]));
+        if (idx != nullptr) {
+            uint8_t* ip = idx + po * (4 * C4) + c;
+            *reinterpret_cast<uchar4*>(ip) = make_uchar4((uint8_t)mi[0], (uint8_t)mi[1], (uint8_t)mi[2], (uint8_t)mi[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int dx_cs, int dx_co, int N, int IH, int IW, int C4,
+                                                          int OH, int OW, int accumulate) {
+    const long long total = (long long)N * IH * IW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ix = (int)(t % IW); t /= IW;
+        const int iy = (int)(t % IH);
+        const int n = (int)(t / IH);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;  // windows with 2*oy-1 <= iy <= 2*oy+1
+        const int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= OH) continue;
+            const int r = iy - (2 * oy - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= OW) continue;
+                const int s = ix - (2 * ox - 1);
+                const size_t po = (size_t)(n * OH + oy) * OW + ox;
+                const uchar4 k = *reinterpret_cast<const uchar4*>(idx + po * (4 * C4) + c);
+                const float4 g = ld4(dy + po * dy_cs + dy_co + c);
+                const int code = r * 3 + s;
+                if (k.x == code) acc[0] += g.x;
+                if (k.y == code) acc[1] += g.y;
+                if (k.z == code) acc[2] += g.z;
+                if (k.w == code) acc[3] += g.w;
+            }
+        }
+        float* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
+        float4 r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        st4(dp, accumulate ? (ld4(dp) + r4) : r4);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+                                                      int y_co, int N, int IH, int IW, int C4, int OH, int OW) {
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        float4 s = f4(0.f);
+        int cnt = 0;
+        for (int r = 0; r < 2; ++r) {
+            const int iy = 2 * oy + r;
+            if (iy >= IH) continue;
+            for (int q = 0; q < 2; ++q) {
+                const int ix = 2 * ox + q;
+                if (ix >= IW) continue;
+                s = s + ld4(x + ((size_t)(n * IH + iy) * IW + ix) * x_cs + x_co + c);
+                ++cnt;
+            }
+        }
+        const float inv = 1.f / (float)cnt;
+        st4(y + ((size_t)(n * OH + oy) * OW + ox) * y_cs + y_co + c, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
+                                                          int dx_cs, int dx_co, int N, int IH, int IW, int C4, int OH, int OW,
+                                                          int accumulate) {
+    const long long total = (long long)N * IH * IW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ix = (int)(t % IW); t /= IW;
+        const int iy = (int)(t % IH);
+        const int n = (int)(t / IH);
+        const int oy = iy / 2, ox = ix / 2;
+        const int ch = (2 * oy + 1 < IH) ? 2 : 1, cw = (2 * ox + 1 < IW) ? 2 : 1;
+        const float inv = 1.f / (float)(ch * cw);
+        const float4 g = ld4(dy + ((size_t)(n * OH + oy) * OW + ox) * dy_cs + dy_co + c);
+        float* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
+        float4 r4 = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+        st4(dp, accumulate ? (ld4(dp) + r4) : r4);
+    }
+}
+
+// ------------------------------------------------- pixel shuffle (+ blur)
+// yc: conv output [N,h,w,4*Cu] (post-ReLU).  P[2h+i][2w+j][c] = yc[h][w][4c+2i+j].
+// blur: out[y][x] = mean P[max(y-a,0)][max(x-b,0)], a,b in {0,1}.
+// One thread owns the 2x2 output block of one channel of one low-res pixel: it needs
+// P at rows 2h-1..2h+1, cols 2w-1..2w+1 = yc of 4 low-res neighbours (float4 each).
+__global__ __launch_bounds__(256) void shuffle_blur_kernel(const float* __restrict__ yc, int yc_cs, int yc_co, float* __restrict__ X,
+                                                           int X_cs, int X_co, int N, int h, int w, int Cu, int do_blur) {
+    const long long total = (long long)N * h * w * Cu;
+    const int H = 2 * h, W = 2 * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = (int)(t % Cu); t /= Cu;
+        const int ww = (int)(t % w); t /= w;
+        const int hh = (int)(t % h);
+        const int n = (int)(t / h);
+        auto Y = [&](int a, int b) { return ld4(yc + ((size_t)(n * h + a) * w + b) * yc_cs + yc_co + 4 * c); };
+        const float4 q11 = Y(hh, ww);  // .x=(0,0) .y=(0,1) .z=(1,0) .w=(1,1) sub-pixels
+        float o00, o01, o10, o11;
+        if (!do_blur) {
+            o00 = q11.x; o01 = q11.y; o10 = q11.z; o11 = q11.w;
+        } else {
+            // P rows: 2hh-1 (clamped), 2hh, 2hh+1 ; cols likewise.  p[r][s], r,s in {0,1,2} for rows/cols -1,0,+1
+            const int hm = hh > 0 ? hh - 1 : hh, wm = ww > 0 ? ww - 1 : ww;
+            const float4 q01 = Y(hm, ww), q10 = Y(hh, wm), q00 = Y(hm, wm);
+            float p[3][3];
+            // row -1: sub-row 1 of the low-res row above (or clamp to row 0 = sub-row 0 of this one when hh == 0)
+            const bool top = hh == 0, left = ww == 0;
+            p[1][1] = q11.x; p[1][2] = q11.y; p[2][1] = q11.z; p[2][2] = q11.w;
+            p[1][0] = left ? q11.x : q10.y;  p[2][0] = left ? q11.z : q10.w;
+            p[0][1] = top ? q11.x : q01.z;   p[0][2] = top ? q11.y : q01.w;
+            p[0][0] = top ? (left ? q11.x : q10.y) : (left ? q01.z : q00.w);
+            o00 = 0.25f * (p[0][0] + p[0][1] + p[1][0] + p[1][1]);
+            o01 = 0.25f * (p[0][1] + p[0][2] + p[1][1] + p[1][2]);
+            o10 = 0.25f * (p[1][0] + p[1][1] + p[2][0] + p[2][1]);
+            o11 = 0.25f * (p[1][1] + p[1][2] + p[2][1] + p[2][2]);
+        }
+        float* o = X + ((size_t)(n * H + 2 * hh) * W + 2 * ww) * X_cs + X_co + c;
+        o[0] = o00;
+        o[X_cs] = o01;
+        o[(size_t)W * X_cs] = o10;
+        o[(size_t)W * X_cs + X_cs] = o11;
+    }
+}
+
+// adjoint: dyc[h][w][4c+2i+j] = (yc > 0) * dP[2h+i][2w+j][c], dP = blur^T(dX)
+__global__ __launch_bounds__(256) void shuffle_blur_bwd_kernel(const float* __restrict__ dX, int dX_cs, int dX_co,
+                                                               const float* __restrict__ yc, int yc_cs, int yc_co,
+                                                               float* __restrict__ dyc, int dyc_cs, int dyc_co, int N, int h, int w,
+                                                               int Cu, int do_blur) {
+    const long long total = (long long)N * h * w * Cu;
+    const int H = 2 * h, W = 2 * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = (int)(t % Cu); t /= Cu;
+        const int ww = (int)(t % w); t /= w;
+        const int hh = (int)(t % h);
+        const int n = (int)(t / h);
+        auto D = [&](int y, int x) -> float {
+            return (y < H && x < W) ? dX[((size_t)(n * H + y) * W + x) * dX_cs + dX_co + c] : 0.f;
+        };
+        float g[2][2];
+        if (!do_blur) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) g[a][b] = D(2 * hh + a, 2 * ww + b);
+        } else {
+            // dP[y][x] = 1/4 sum_{i in {y, y+1}} sum_{j in {x, x+1}} wy(y,i) wx(x,j) dOut[i][j]; the clamp doubles the
+            // weight of output row/col 0 on P row/col 0.
+            float d[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) d[a][b] = D(2 * hh + a, 2 * ww + b);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float wy0 = (2 * hh + a == 0) ? 2.f : 1.f, wx0 = (2 * ww + b == 0) ? 2.f : 1.f;
+                    g[a][b] = 0.25f * (wy0 * wx0 * d[a][b] + wy0 * d[a][b + 1] + wx0 * d[a + 1][b] + d[a + 1][b + 1]);
+                }
+        }
+        const size_t po = ((size_t)(n * h + hh) * w + ww);
+        const float4 ref = ld4(yc + po * yc_cs + yc_co + 4 * c);
+        st4(dyc + po * dyc_cs + dyc_co + 4 * c, gate4(make_float4(g[0][0], g[0][1], g[1][0], g[1][1]), ref));
+    }
+}
+
+// ------------------------------------------------------- nearest resize
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+    int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y,
+                                                             int y_cs, int y_co, int N, int IH, int IW, int OH, int OW, int C4) {
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const int iy = nearest_src(oy, sh, IH), ix = nearest_src(ox, sw, IW);
+        st4(y + ((size_t)(n * OH + oy) * OW + ox) * y_cs + y_co + c, ld4(x + ((size_t)(n * IH + iy) * IW + ix) * x_cs + x_co + c));
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
+                                                                 int dx_cs, int dx_co, int N, int IH, int IW, int OH, int OW, int C4) {
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    const long long total = (long long)N * IH * IW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c = 4 * (int)(t % C4); t /= C4;
+        const int ix = (int)(t % IW); t /= IW;
+        const int iy = (int)(t % IH);
+        const int n = (int)(t / IH);
+        // candidate destination range: conservative window around iy / scale
+        int oy_lo = (int)floorf((float)iy / sh) - 2, oy_hi = (int)ceilf((float)(iy + 1) / sh) + 2;
+        int ox_lo = (int)floorf((float)ix / sw) - 2, ox_hi = (int)ceilf((float)(ix + 1) / sw) + 2;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+        float4 s = f4(0.f);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (nearest_src(oy, sh, IH) != iy) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (nearest_src(ox, sw, IW) != ix) continue;
+                s = s + ld4(dy + ((size_t)(n * OH + oy) * OW + ox) * dy_cs + dy_co + c);
+            }
+        }
+        st4(dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c, s);
+    }
+}
+
+// ------------------------------------------------------ layout conversion
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int y_cs, int y_co, int N,
+                                                           int C, int H, int W) {
+    const long long HW = (long long)H * W, total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, p = i - n * HW;
+        float* o = y + (size_t)i * y_cs + y_co;
+        for (int c = 0; c < C; ++c) o[c] = x[((size_t)n * C + c) * HW + p];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int N,
+                                                           int C, int H, int W) {
+    const long long HW = (long long)H * W, total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, p = i - n * HW;
+        const float* s = x + (size_t)i * x_cs + x_co;
+        for (int c = 0; c < C; ++c) y[((size_t)n * C + c) * HW + p] = s[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+                                                         int y_co, long long P, int C4, int accumulate) {
+    const long long total = P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C4;
+        const int c = 4 * (int)(i - p * C4);
+        const float4 v = ld4(x + (size_t)p * x_cs + x_co + c);
+        float* o = y + (size_t)p * y_cs + y_co + c;
+        st4(o, accumulate ? (ld4(o) + v) : v);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ g, int g_cs, int g_co, const float* __restrict__ ref,
+                                                        int r_cs, int r_co, float* __restrict__ y, int y_cs, int y_co, long long P, int C4) {
+    const long long total = P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C4;
+        const int c = 4 * (int)(i - p * C4);
+        st4(y + (size_t)p * y_cs + y_co + c, gate4(ld4(g + (size_t)p * g_cs + g_co + c), ld4(ref + (size_t)p * r_cs + r_co + c)));
+    }
+}
+
+// ---------------------------------------------------------------- loss
+constexpr int CE_MAXC = 64;
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ weight, long long P, int C, float* __restrict__ part) {
+    float num = 0.f, den = 0.f;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const long long y = target[p];
+        if (y < 0 || y >= C) continue;  // ignore_index semantics
+        const float* zp = z + (size_t)p * z_cs + z_co;
+        float m = zp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zp[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
+        const float nll = (m + logf(s)) - zp[y];
+        const float w = weight ? weight[y] : 1.f;
+        num += w * nll;
+        den += w;
+    }
+    // wavefront (64-lane) reduction, then one LDS hop
+    __shared__ float sn[4], sd[4];
+    for (int o = 32; o > 0; o >>= 1) {
+        num += __shfl_down(num, o);
+        den += __shfl_down(den, o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sn[wv] = num; sd[wv] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = sn[0] + sn[1] + sn[2] + sn[3];
+        part[2 * blockIdx.x + 1] = sd[0] + sd[1] + sd[2] + sd[3];
+    }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ part, int rows, float* loss, float* denom) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double n = 0.0, d = 0.0;
+    for (int r = 0; r < rows; ++r) { n += (double)part[2 * r]; d += (double)part[2 * r + 1]; }
+    *loss = (float)(n / d);
+    *denom = (float)d;
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ weight, long long P, int C, const float* __restrict__ denom,
+                                                     float gscale, float* __restrict__ dz, int dz_cs, int dz_co) {
+    const float inv = gscale / *denom;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const long long y = target[p];
+        float* dp = dz + (size_t)p * dz_cs + dz_co;
+        if (y < 0 || y >= C) {
+            for (int c = 0; c < C; ++c) dp[c] = 0.f;
+            continue;
+        }
+        const float* zp = z + (size_t)p * z_cs + z_co;
+        float m = zp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zp[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
+        const float w = (weight ? weight[y] : 1.f) * inv;
+        const float is = 1.f / s;
+        for (int c = 0; c < C; ++c) dp[c] = w * (expf(zp[c] - m) * is - (c == y ? 1.f : 0.f));
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __restrict__ z, int z_cs, int z_co, int N, long long HW, int C,
+                                                             float* __restrict__ probs, int64_t* __restrict__ amax) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, p = i - n * HW;
+        const float* zp = z + (size_t)i * z_cs + z_co;
+        float m = zp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zp[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
+        float best = -1.f;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            const float pr = expf(zp[c] - m) / s;
+            if (probs) probs[((size_t)n * C + c) * HW + p] = pr;
+            if (pr > best) { best = pr; bi = c; }
+        }
+        if (amax) amax[i] = bi;
+    }
+}
+
+// ----------------------------------------------------------------- Adam
+struct AdamArgs {
+    float decay[4];     // 1 - lr*wd per group
+    float step_size[4]; // -lr / debias1 per group
+    float mom, one_minus_mom, sqr_mom, one_minus_sqr, debias2, eps, grad_scale;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const uint8_t* __restrict__ code, long long n, AdamArgs a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int cd = code[i];
+        const int grp = cd & 3;
+        float pv = p[i];
+        const float gv = g[i] * a.grad_scale;
+        if (cd & 4) pv *= a.decay[grp];
+        const float mv = m[i] * a.mom + a.one_minus_mom * gv;
+        const float vv = v[i] * a.sqr_mom + a.one_minus_sqr * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float den = sqrtf(vv / a.debias2) + a.eps;
+        p[i] = pv + a.step_size[grp] * (mv / den);
+    }
+}
+
+// -------------------------------------------------------------- mosaic
+__global__ __launch_bounds__(256) void mosaic_acc_kernel(const float* __restrict__ probs, int C, int th, int tw, float* __restrict__ mosaic,
+                                                         int32_t* __restrict__ count, int MH, int MW, int y0, int x0) {
+    const long long total = (long long)th * tw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ty = (int)(i / tw), tx = (int)(i % tw);
+        const int my = y0 + ty, mx = x0 + tx;
+        if (my < 0 || my >= MH || mx < 0 || mx >= MW) continue;
+        for (int c = 0; c < C; ++c) mosaic[((size_t)c * MH + my) * MW + mx] += probs[((size_t)c * th + ty) * tw + tx];
+        count[(size_t)my * MW + mx] += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void mosaic_fin_kernel(float* __restrict__ mosaic, const int32_t* __restrict__ count, int C, int MH, int MW,
+                                                         uint8_t* __restrict__ amax) {
+    const long long total = (long long)MH * MW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cnt = count[i];
+        float best = -INFINITY;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            float v = mosaic[(size_t)c * total + i];
+            if (cnt > 0) { v = v / (float)cnt; mosaic[(size_t)c * total + i] = v; }
+            if (v > best) { best = v; bi = c; }
+        }
+        if (amax) amax[i] = (uint8_t)bi;
+    }
+}
+
+inline int c4of(int C) { return roundup(C, 4) / 4; }
+inline bool pslice_ok(int cs, int co, int C) { return unet::slice_ok(cs, co, roundup(C, 4)); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int unet_bn_stats_rows(long long P) { return stats_rows(P); }
+
+extern "C" int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream) {
+    UNET_CHECK_ARG(x && partial && P > 0 && C > 0 && (C & 3) == 0, "bn_stats: bad args (C must be a multiple of 4)");
+    UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C), "bn_stats: bad slice");
+    const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, partial, partial + (size_t)rows * C, C);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_bn_finalize(const float* psum, const float* psumsq, int rows, long long count, int C, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                float* shift, float* save_mean, float* save_invstd, void* stream) {
+    UNET_CHECK_ARG(psum && psumsq && scale && shift && rows > 0 && count > 0 && C > 0, "bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, psum, psumsq, rows, C, (double)count, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                   int C, float* scale, float* shift, void* stream) {
+    UNET_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, gamma, beta, running_mean, running_var, eps, C, scale,
+                       shift);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_affine_act(const float* x, int x_cs, int x_co, const float* scale, const float* shift, const float* x2, int x2_cs,
+                               int x2_co, const float* scale2, const float* shift2, float* y, int y_cs, int y_co, long long P, int C,
+                               int relu, void* stream) {
+    UNET_CHECK_ARG(x && y && P > 0 && C > 0, "affine_act: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "affine_act: bad slice");
+    UNET_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (scale2 == nullptr) == (shift2 == nullptr), "affine_act: scale/shift mismatch");
+    UNET_CHECK_ARG((scale == nullptr && scale2 == nullptr) || (C & 3) == 0, "affine_act: per-channel vectors need C % 4 == 0");
+    if (x2) UNET_CHECK_ARG(pslice_ok(x2_cs, x2_co, C), "affine_act: bad x2 slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2,
+                       shift2, y, y_cs, y_co, P, C4, relu);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_bn_bwd_reduce(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+                                  int x_co, const float* mean, const float* invstd, long long P, int C, float* partial, void* stream) {
+    UNET_CHECK_ARG(dout && x && mean && invstd && partial && P > 0 && C > 0 && (C & 3) == 0, "bn_bwd_reduce: bad args");
+    UNET_CHECK_ARG(unet::slice_ok(d_cs, d_co, C) && unet::slice_ok(x_cs, x_co, C), "bn_bwd_reduce: bad slice");
+    if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_reduce: bad out slice");
+    const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P,
+                       C4, TC, partial, partial + (size_t)rows * C, C);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_bn_bwd_finalize(const float* partial, int rows, long long count, int C, float* dgamma, float* dbeta, float* c1,
+                                    float* c2, void* stream) {
+    UNET_CHECK_ARG(partial && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, partial, rows, C, (double)count, C, dgamma, dbeta, c1, c2,
+                       0);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_bn_bwd_apply(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+                                 int x_co, const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
+                                 float* dx, int dx_cs, int dx_co, float* gout, int g_cs, int g_co, int g_accumulate, long long P, int C,
+                                 void* stream) {
+    UNET_CHECK_ARG(dout && x && mean && invstd && c1 && c2 && dx && P > 0 && C > 0 && (C & 3) == 0, "bn_bwd_apply: bad args");
+    UNET_CHECK_ARG(unet::slice_ok(d_cs, d_co, C) && unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(dx_cs, dx_co, C), "bn_bwd_apply: bad slice");
+    if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_apply: bad out slice");
+    if (gout) UNET_CHECK_ARG(unet::slice_ok(g_cs, g_co, C), "bn_bwd_apply: bad gout slice");
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co,
+                       mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C4);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_maxpool3x3s2(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW,
+                                 int C, int OH, int OW, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0 && (C & 3) == 0, "maxpool: bad args");
+    UNET_CHECK_ARG(OH == (IH + 2 - 3) / 2 + 1 && OW == (IW + 2 - 3) / 2 + 1, "maxpool: bad output dims");
+    UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(y_cs, y_co, C), "maxpool: bad slice");
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, idx, N,
+                       IH, IW, C4, OH, OW);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_maxpool3x3s2_bwd(const float* dy, int dy_cs, int dy_co, const uint8_t* idx, float* dx, int dx_cs, int dx_co, int N,
+                                     int IH, int IW, int C, int OH, int OW, int accumulate, void* stream) {
+    UNET_CHECK_ARG(dy && idx && dx && N > 0 && C > 0 && (C & 3) == 0, "maxpool_bwd: bad args");
+    UNET_CHECK_ARG(unet::slice_ok(dy_cs, dy_co, C) && unet::slice_ok(dx_cs, dx_co, C), "maxpool_bwd: bad slice");
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, idx, dx, dx_cs,
+                       dx_co, N, IH, IW, C4, OH, OW, accumulate);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_avgpool2_ceil(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH,
+                                  int OW, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0 && (C & 3) == 0, "avgpool: bad args");
+    UNET_CHECK_ARG(OH == (IH + 1) / 2 && OW == (IW + 1) / 2, "avgpool: bad output dims");
+    UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(y_cs, y_co, C), "avgpool: bad slice");
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, N, IH,
+                       IW, C4, OH, OW);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_avgpool2_ceil_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C,
+                                      int OH, int OW, int accumulate, void* stream) {
+    UNET_CHECK_ARG(dy && dx && N > 0 && C > 0 && (C & 3) == 0, "avgpool_bwd: bad args");
+    UNET_CHECK_ARG(OH == (IH + 1) / 2 && OW == (IW + 1) / 2, "avgpool_bwd: bad output dims");
+    UNET_CHECK_ARG(unet::slice_ok(dy_cs, dy_co, C) && unet::slice_ok(dx_cs, dx_co, C), "avgpool_bwd: bad slice");
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx, dx_cs,
+                       dx_co, N, IH, IW, C4, OH, OW, accumulate);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X, int X_cs, int X_co, int N, int h, int w, int Cu,
+                                 int do_blur, void* stream) {
+    UNET_CHECK_ARG(yc && X && N > 0 && h > 0 && w > 0 && Cu > 0, "shuffle_blur: bad args");
+    UNET_CHECK_ARG(unet::slice_ok(yc_cs, yc_co, 4 * Cu) && X_cs > 0 && X_co >= 0 && X_co + Cu <= X_cs, "shuffle_blur: bad slice");
+    hipLaunchKernelGGL(shuffle_blur_kernel, dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, yc, yc_cs, yc_co, X, X_cs, X_co, N,
+                       h, w, Cu, do_blur);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, const float* yc, int yc_cs, int yc_co, float* dyc, int dyc_cs,
+                                     int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream) {
+    UNET_CHECK_ARG(dX && yc && dyc && N > 0 && h > 0 && w > 0 && Cu > 0, "shuffle_blur_bwd: bad args");
+    UNET_CHECK_ARG(unet::slice_ok(yc_cs, yc_co, 4 * Cu) && unet::slice_ok(dyc_cs, dyc_co, 4 * Cu) && dX_cs > 0 && dX_co + Cu <= dX_cs,
+                   "shuffle_blur_bwd: bad slice");
+    hipLaunchKernelGGL(shuffle_blur_bwd_kernel, dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, dX, dX_cs, dX_co, yc, yc_cs,
+                       yc_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, do_blur);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW,
+                                   int C, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0, "resize_nearest: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "resize_nearest: bad slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co,
+                       N, IH, IW, OH, OW, C4);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_resize_nearest_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW,
+                                       int OH, int OW, int C, void* stream) {
+    UNET_CHECK_ARG(dy && dx && N > 0 && C > 0, "resize_nearest_bwd: bad args");
+    UNET_CHECK_ARG(pslice_ok(dy_cs, dy_co, C) && pslice_ok(dx_cs, dx_co, C), "resize_nearest_bwd: bad slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx,
+                       dx_cs, dx_co, N, IH, IW, OH, OW, C4);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && y_co >= 0 && y_co + C <= y_cs, "nchw_to_nhwc: bad args");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, x, y, y_cs, y_co, N, C, H, W);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_nhwc_to_nchw(const float* x, int x_cs, int x_co, float* y, int N, int C, int H, int W, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && x_co >= 0 && x_co + C <= x_cs, "nhwc_to_nchw: bad args");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, N, C, H, W);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_copy_slice(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, int accumulate,
+                               void* stream) {
+    UNET_CHECK_ARG(x && y && P > 0 && C > 0, "copy_slice: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "copy_slice: bad slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(copy_slice_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, accumulate);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_cs, int r_co, float* y, int y_cs, int y_co,
+                              long long P, int C, void* stream) {
+    UNET_CHECK_ARG(g && ref && y && P > 0 && C > 0, "relu_mask: bad args");
+    UNET_CHECK_ARG(pslice_ok(g_cs, g_co, C) && pslice_ok(r_cs, r_co, C) && pslice_ok(y_cs, y_co, C), "relu_mask: bad slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, g, g_cs, g_co, ref, r_cs, r_co, y, y_cs, y_co, P, C4);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" size_t unet_colsum_workspace(long long P, int C) { return (size_t)stats_rows(P) * roundup(C, 4); }
+
+extern "C" int unet_colsum(const float* x, int x_cs, int x_co, long long P, int C, float* out, float* workspace, void* stream) {
+    UNET_CHECK_ARG(x && out && workspace && P > 0 && C > 0, "colsum: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C), "colsum: bad slice");
+    const int rows = stats_rows(P), C4 = c4of(C), Cp = 4 * C4, TC = pick_tc(C4);
+    hipLaunchKernelGGL(colsum_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, workspace, Cp);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, workspace, rows, Cp, C, out);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+static int ce_rows(long long P) {
+    long long r = (P + 255) / 256;
+    if (r > 1024) r = 1024;
+    if (r < 1) r = 1;
+    return (int)r;
+}
+
+extern "C" size_t unet_ce_workspace(long long P) { return (size_t)2 * ce_rows(P); }
+
+extern "C" int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float* loss,
+                           float* denom, float* workspace, void* stream) {
+    UNET_CHECK_ARG(z && target && loss && denom && workspace && P > 0 && C > 0 && C <= CE_MAXC, "ce_fwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs, "ce_fwd: bad slice");
+    const int rows = ce_rows(P);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, workspace);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, loss, denom);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                           const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream) {
+    UNET_CHECK_ARG(z && target && denom && dz && P > 0 && C > 0 && C <= CE_MAXC, "ce_bwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs && dz_co >= 0 && dz_co + C <= dz_cs, "ce_bwd: bad slice");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs,
+                       dz_co);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, int H, int W, int C, float* probs_nchw, int64_t* argmax,
+                                   void* stream) {
+    UNET_CHECK_ARG(z && N > 0 && H > 0 && W > 0 && C > 0 && C <= CE_MAXC && z_co + C <= z_cs, "softmax_argmax: bad args");
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, z, z_cs, z_co, N, (long long)H * W, C,
+                       probs_nchw, argmax);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n, const float* lr, float mom,
+                              float sqr_mom, float eps, float wd, int step, float grad_scale, void* stream) {
+    UNET_CHECK_ARG(p && g && m && v && code && lr && n > 0 && step >= 1, "adam_step: bad args");
+    AdamArgs a;
+    const double debias1 = 1.0 - pow((double)mom, (double)step);
+    const double debias2 = 1.0 - pow((double)sqr_mom, (double)step);
+    for (int i = 0; i < 4; ++i) {
+        a.decay[i] = (float)(1.0 - (double)lr[i] * (double)wd);
+        a.step_size[i] = (float)(-(double)lr[i] / debias1);
+    }
+    a.mom = mom; a.one_minus_mom = (float)(1.0 - (double)mom);
+    a.sqr_mom = sqr_mom; a.one_minus_sqr = (float)(1.0 - (double)sqr_mom);
+    a.debias2 = (float)debias2; a.eps = eps; a.grad_scale = grad_scale;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST, p, g, m, v, code, n, a);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_mosaic_accumulate(const float* probs_nchw, int C, int th, int tw, float* mosaic, int32_t* count, int MH, int MW, int y0,
+                                      int x0, void* stream) {
+    UNET_CHECK_ARG(probs_nchw && mosaic && count && C > 0 && th > 0 && tw > 0 && MH > 0 && MW > 0, "mosaic_accumulate: bad args");
+    hipLaunchKernelGGL(mosaic_acc_kernel, dim3(ew_grid((long long)th * tw, 256)), dim3(256), 0, ST, probs_nchw, C, th, tw, mosaic, count, MH, MW,
+                       y0, x0);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_mosaic_finalize(float* mosaic, const int32_t* count, int C, int MH, int MW, uint8_t* argmax, void* stream) {
+    UNET_CHECK_ARG(mosaic && count && C > 0 && MH > 0 && MW > 0, "mosaic_finalize: bad args");
+    hipLaunchKernelGGL(mosaic_fin_kernel, dim3(ew_grid((long long)MH * MW, 256)), dim3(256), 0, ST, mosaic, count, C, MH, MW, argmax);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}

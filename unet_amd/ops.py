@@ -1,0 +1,312 @@
+"""Thin Python wrappers over the C ABI: torch tensors in, HIP launches out.
+
+PyTorch is used for device memory and streams only.  Activations are fp32 NHWC
+buffers; ``TS`` names a channel slice ``buf[..., co:co+C]`` of a buffer with
+physical channel stride ``cs`` (this is how ``torch.cat`` disappears).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, WgradDesc, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def rup4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+@dataclass
+class TS:
+    """Channel slice of an NHWC fp32 buffer."""
+    buf: torch.Tensor   # [N, H, W, cs] contiguous fp32
+    co: int
+    C: int
+
+    def __post_init__(self):
+        assert self.buf.dtype == torch.float32 and self.buf.is_contiguous() and self.buf.dim() == 4
+        assert self.co % 4 == 0 and self.co + self.C <= self.cs, (self.co, self.C, self.cs)
+
+    @property
+    def cs(self) -> int: return self.buf.shape[3]
+    @property
+    def N(self) -> int: return self.buf.shape[0]
+    @property
+    def H(self) -> int: return self.buf.shape[1]
+    @property
+    def W(self) -> int: return self.buf.shape[2]
+    @property
+    def P(self) -> int: return self.buf.shape[0] * self.buf.shape[1] * self.buf.shape[2]
+    @property
+    def ptr(self) -> int: return self.buf.data_ptr()
+
+    def view(self) -> torch.Tensor:
+        return self.buf[..., self.co:self.co + self.C]
+
+    def sub(self, off: int, C: int) -> "TS":
+        return TS(self.buf, self.co + off, C)
+
+
+def new_act(N, H, W, C, device, zero=False) -> TS:
+    cs = rup4(C)
+    need_zero = zero or cs != C
+    buf = (torch.zeros if need_zero else torch.empty)((N, H, W, cs), dtype=torch.float32, device=device)
+    return TS(buf, 0, C)
+
+
+def full(buf: torch.Tensor, C: Optional[int] = None) -> TS:
+    return TS(buf, 0, buf.shape[3] if C is None else C)
+
+
+# ------------------------------------------------------------------ conv
+
+def conv_out_hw(H, W, ks, stride):
+    pad = (ks - 1) // 2
+    return (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+
+
+def pack_weights(w: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w: [Cout, Cin, ks, ks] contiguous.  mode 0 = forward image, 1 = dgrad image."""
+    Cout, Cin, ks, _ = w.shape
+    assert w.is_contiguous() and w.dtype == torch.float32
+    n = lib.unet_pack_weights_size(Cout, Cin, ks, mode)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+    assert out.numel() >= n
+    check(lib.unet_pack_weights(w.data_ptr(), out.data_ptr(), Cout, Cin, ks, mode, _stream()), "pack_weights")
+    return out
+
+
+def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, bias=None, res: Optional[TS] = None,
+               mask: Optional[TS] = None, relu=False, colsum=None, colsumsq=None) -> ConvDesc:
+    d = ConvDesc()
+    d.x, d.x_cs, d.x_co = x.ptr, x.cs, x.co
+    d.wp = wp.data_ptr()
+    d.bias = _p(bias)
+    if res is not None:
+        d.res, d.res_cs, d.res_co = res.ptr, res.cs, res.co
+    flags = L.CONV_RELU if relu else 0
+    if mask is not None:
+        d.mask, d.mask_cs, d.mask_co = mask.ptr, mask.cs, mask.co
+        flags |= L.CONV_MASK
+    d.y, d.y_cs, d.y_co = y.ptr, y.cs, y.co
+    d.N, d.IH, d.IW, d.Cin = x.N, x.H, x.W, x.C
+    d.OH, d.OW, d.Cout = y.H, y.W, y.C
+    d.ks, d.stride, d.kind, d.flags = ks, stride, kind, flags
+    d.colsum, d.colsumsq = _p(colsum), _p(colsumsq)
+    return d
+
+
+def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, res=None, mask=None, relu=False,
+           colsum=None, colsumsq=None):
+    d = _conv_desc(x, wp, y, ks, stride, L.CONV_FWD, bias, res, mask, relu, colsum, colsumsq)
+    check(lib.unet_conv2d(C.byref(d), _stream()), "conv2d")
+
+
+def conv2d_dgrad(dy: TS, wp_dgrad: torch.Tensor, dx: TS, ks: int, stride: int = 1, res=None, mask=None, colsum=None):
+    """dx = conv^T(dy); optional residual add, ReLU-backward mask, column sums of the result."""
+    d = _conv_desc(dy, wp_dgrad, dx, ks, stride, L.CONV_DGRAD, None, res, mask, False, colsum, None)
+    check(lib.unet_conv2d(C.byref(d), _stream()), "conv2d_dgrad")
+
+
+def conv_colsum_rows(x: TS, wp, y: TS, ks, stride, kind) -> int:
+    d = _conv_desc(x, wp, y, ks, stride, kind)
+    r = lib.unet_conv2d_colsum_rows(C.byref(d))
+    if r < 0:
+        check(r, "conv2d_colsum_rows")
+    return r
+
+
+def _wgrad_desc(x: TS, dy: TS, dw, dbias, ks, stride, ws, accumulate) -> WgradDesc:
+    d = WgradDesc()
+    d.x, d.x_cs, d.x_co = x.ptr, x.cs, x.co
+    d.dy, d.dy_cs, d.dy_co = dy.ptr, dy.cs, dy.co
+    d.dw, d.dbias = _p(dw), _p(dbias)
+    d.N, d.IH, d.IW, d.Cin = x.N, x.H, x.W, x.C
+    d.OH, d.OW, d.Cout = dy.H, dy.W, dy.C
+    d.ks, d.stride = ks, stride
+    d.workspace = _p(ws)
+    d.workspace_floats = 0 if ws is None else ws.numel()
+    d.accumulate = int(accumulate)
+    return d
+
+
+def wgrad_workspace(x: TS, dy: TS, ks, stride, with_bias=False) -> int:
+    d = _wgrad_desc(x, dy, torch.empty(0), None, ks, stride, None, 0)
+    d.dw = 1  # non-null placeholder for validation
+    n = lib.unet_conv2d_wgrad_workspace(C.byref(d))
+    if with_bias:
+        n = max(n, lib.unet_colsum_workspace(dy.P, dy.C))
+    return int(n)
+
+
+def conv2d_wgrad(x: TS, dy: TS, dw: torch.Tensor, ks: int, stride: int, ws: torch.Tensor, dbias=None, accumulate=False):
+    d = _wgrad_desc(x, dy, dw, dbias, ks, stride, ws, accumulate)
+    check(lib.unet_conv2d_wgrad(C.byref(d), _stream()), "conv2d_wgrad")
+
+
+# ------------------------------------------------------------------ batch norm
+
+def bn_stats_rows(P: int) -> int:
+    return lib.unet_bn_stats_rows(P)
+
+
+def bn_stats(x: TS, partial: torch.Tensor):
+    check(lib.unet_bn_stats(x.ptr, x.cs, x.co, x.P, x.C, partial.data_ptr(), _stream()), "bn_stats")
+
+
+def bn_finalize(psum, psumsq, rows, count, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinvstd):
+    check(lib.unet_bn_finalize(_p(psum), _p(psumsq), rows, count, C_, _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                               _p(scale), _p(shift), _p(smean), _p(sinvstd), _stream()), "bn_finalize")
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
+    check(lib.unet_bn_eval_coeffs(_p(gamma), _p(beta), _p(rmean), _p(rvar), eps, rmean.numel(), _p(scale), _p(shift), _stream()),
+          "bn_eval_coeffs")
+
+
+def affine_act(x: TS, y: TS, scale=None, shift=None, x2: Optional[TS] = None, scale2=None, shift2=None, relu=False):
+    check(lib.unet_affine_act(x.ptr, x.cs, x.co, _p(scale), _p(shift),
+                              None if x2 is None else x2.ptr, 0 if x2 is None else x2.cs, 0 if x2 is None else x2.co,
+                              _p(scale2), _p(shift2), y.ptr, y.cs, y.co, x.P, x.C, int(relu), _stream()), "affine_act")
+
+
+def bn_bwd_reduce(dout: TS, out: Optional[TS], x: TS, mean, invstd, partial):
+    check(lib.unet_bn_bwd_reduce(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
+                                 0 if out is None else out.co, x.ptr, x.cs, x.co, _p(mean), _p(invstd), x.P, x.C,
+                                 partial.data_ptr(), _stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_finalize(partial, rows, count, C_, dgamma, dbeta, c1, c2):
+    check(lib.unet_bn_bwd_finalize(_p(partial), rows, count, C_, _p(dgamma), _p(dbeta), _p(c1), _p(c2), _stream()), "bn_bwd_finalize")
+
+
+def bn_bwd_apply(dout: TS, out: Optional[TS], x: TS, mean, invstd, gamma, c1, c2, dx: TS, gout: Optional[TS] = None,
+                 g_accumulate=False):
+    check(lib.unet_bn_bwd_apply(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
+                                0 if out is None else out.co, x.ptr, x.cs, x.co, _p(mean), _p(invstd), _p(gamma), _p(c1), _p(c2),
+                                dx.ptr, dx.cs, dx.co, None if gout is None else gout.ptr, 0 if gout is None else gout.cs,
+                                0 if gout is None else gout.co, int(g_accumulate), x.P, x.C, _stream()), "bn_bwd_apply")
+
+
+# ------------------------------------------------------------------ pooling
+
+def maxpool(x: TS, y: TS, idx: Optional[torch.Tensor]):
+    check(lib.unet_maxpool3x3s2(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, _p(idx), x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "maxpool")
+
+
+def maxpool_bwd(dy: TS, idx: torch.Tensor, dx: TS, accumulate=False):
+    check(lib.unet_maxpool3x3s2_bwd(dy.ptr, dy.cs, dy.co, idx.data_ptr(), dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W,
+                                    int(accumulate), _stream()), "maxpool_bwd")
+
+
+def avgpool(x: TS, y: TS):
+    check(lib.unet_avgpool2_ceil(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "avgpool")
+
+
+def avgpool_bwd(dy: TS, dx: TS, accumulate=False):
+    check(lib.unet_avgpool2_ceil_bwd(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W, int(accumulate),
+                                     _stream()), "avgpool_bwd")
+
+
+# ------------------------------------------------------------------ decoder data movement
+
+def shuffle_blur(yc: TS, X: TS, blur: bool):
+    assert yc.C == 4 * X.C and X.H == 2 * yc.H and X.W == 2 * yc.W
+    check(lib.unet_shuffle_blur(yc.ptr, yc.cs, yc.co, X.ptr, X.cs, X.co, yc.N, yc.H, yc.W, X.C, int(blur), _stream()), "shuffle_blur")
+
+
+def shuffle_blur_bwd(dX: TS, yc: TS, dyc: TS, blur: bool):
+    assert yc.C == 4 * dX.C and dX.H == 2 * yc.H and dX.W == 2 * yc.W
+    check(lib.unet_shuffle_blur_bwd(dX.ptr, dX.cs, dX.co, yc.ptr, yc.cs, yc.co, dyc.ptr, dyc.cs, dyc.co, yc.N, yc.H, yc.W, dX.C,
+                                    int(blur), _stream()), "shuffle_blur_bwd")
+
+
+def resize_nearest(x: TS, y: TS):
+    check(lib.unet_resize_nearest(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, y.H, y.W, x.C, _stream()), "resize_nearest")
+
+
+def resize_nearest_bwd(dy: TS, dx: TS):
+    check(lib.unet_resize_nearest_bwd(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dy.H, dy.W, dx.C, _stream()),
+          "resize_nearest_bwd")
+
+
+def nchw_to_nhwc(x: torch.Tensor, y: TS):
+    N, C_, H, W = x.shape
+    assert x.is_contiguous() and y.C == C_
+    check(lib.unet_nchw_to_nhwc(x.data_ptr(), y.ptr, y.cs, y.co, N, C_, H, W, _stream()), "nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x: TS, y: torch.Tensor):
+    assert y.is_contiguous()
+    check(lib.unet_nhwc_to_nchw(x.ptr, x.cs, x.co, y.data_ptr(), x.N, x.C, x.H, x.W, _stream()), "nhwc_to_nchw")
+
+
+def copy_slice(x: TS, y: TS, accumulate=False):
+    check(lib.unet_copy_slice(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, int(accumulate), _stream()), "copy_slice")
+
+
+def relu_mask(g: TS, ref: TS, y: TS):
+    check(lib.unet_relu_mask(g.ptr, g.cs, g.co, ref.ptr, ref.cs, ref.co, y.ptr, y.cs, y.co, g.P, g.C, _stream()), "relu_mask")
+
+
+def colsum_workspace(P, C_) -> int:
+    return int(lib.unet_colsum_workspace(P, C_))
+
+
+def colsum(x: TS, out: torch.Tensor, ws: torch.Tensor):
+    assert ws.numel() >= colsum_workspace(x.P, x.C)
+    check(lib.unet_colsum(x.ptr, x.cs, x.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "colsum")
+
+
+# ------------------------------------------------------------------ loss
+
+def ce_workspace(P) -> int:
+    return int(lib.unet_ce_workspace(P))
+
+
+def ce_fwd(z: TS, target: torch.Tensor, weight, loss, denom, ws):
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == z.P
+    check(lib.unet_ce_fwd(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, loss.data_ptr(), denom.data_ptr(),
+                          ws.data_ptr(), _stream()), "ce_fwd")
+
+
+def ce_bwd(z: TS, target, weight, denom, gscale: float, dz: TS):
+    check(lib.unet_ce_bwd(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, denom.data_ptr(), gscale, dz.ptr, dz.cs,
+                          dz.co, _stream()), "ce_bwd")
+
+
+def softmax_argmax(z: TS, probs: Optional[torch.Tensor], amax: Optional[torch.Tensor]):
+    check(lib.unet_softmax_argmax(z.ptr, z.cs, z.co, z.N, z.H, z.W, z.C, _p(probs), _p(amax), _stream()), "softmax_argmax")
+
+
+# ------------------------------------------------------------------ optimiser
+
+def adam_step(p, g, m, v, code, lrs, mom, sqr_mom, eps, wd, step, grad_scale=1.0):
+    arr = (C.c_float * 4)(*([float(l) for l in lrs] + [0.0] * (4 - len(lrs))))
+    check(lib.unet_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), code.data_ptr(), p.numel(), arr,
+                             float(mom), float(sqr_mom), float(eps), float(wd), int(step), float(grad_scale), _stream()), "adam_step")
+
+
+def mosaic_accumulate(probs: torch.Tensor, mosaic: torch.Tensor, count: torch.Tensor, y0: int, x0: int):
+    Cc, th, tw = probs.shape
+    _, MH, MW = mosaic.shape
+    check(lib.unet_mosaic_accumulate(probs.data_ptr(), Cc, th, tw, mosaic.data_ptr(), count.data_ptr(), MH, MW, y0, x0, _stream()),
+          "mosaic_accumulate")
+
+
+def mosaic_finalize(mosaic: torch.Tensor, count: torch.Tensor, amax: Optional[torch.Tensor]):
+    Cc, MH, MW = mosaic.shape
+    check(lib.unet_mosaic_finalize(mosaic.data_ptr(), count.data_ptr(), Cc, MH, MW, _p(amax), _stream()), "mosaic_finalize")
