@@ -1,0 +1,314 @@
+"""HipDynamicUnet: the MI355X-native drop-in for the model object the reference builds
+with ``models.unet.DynamicUnet(body, n_out, img_size, blur=True, blur_final=True,
+self_attention, y_range=None, norm_type=NormType, last_cross=True, bottle=False)``
+(``train.py:141-144``) on a ``create_body(xresnetNN)`` encoder whose first conv was
+replaced for N input channels (``train.py:128-135``).
+
+Surface kept: ``nn.Module``; ``model(x: f32[B,C,H,W]) -> f32[B,n_out,H,W]``
+raw logits; ``train()/eval()``; ``parameters()``; ``state_dict()/load_state_dict()`` with
+fastai's key scheme; indexing ``m[0]`` / ``m[0][:3]`` / ``m[0][3:]`` / ``m[1:]``.
+
+Execution: all parameters live in ONE flat fp32 device buffer (grads in a second one),
+activations in persistent NHWC buffers; forward and backward are explicit programs of
+C-ABI launches (``unet_amd/modules.py``), so a whole step can be captured in a hipGraph.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import (BN_EPS, BN_MOM, ConvLayer, Ctx, Encoder, PixelShuffle_ICNR, ResBlock, UnetBlock, _BNExec, _ConvExec,
+                      _kaiming_init)
+from .ops import TS
+
+
+class _Marker(nn.Module):
+    """parameter-free stand-ins that keep fastai's child numbering (ResizeToOrig, MergeLayer)."""
+    def __init__(self, name):
+        super().__init__()
+        self._name = name
+
+    def extra_repr(self):
+        return self._name
+
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{self._name} runs only inside HipDynamicUnet")
+
+
+class HipDynamicUnet(nn.Module):
+    def __init__(self, arch: str, n_in: int, n_out: int, img_size: Sequence[int] = (512, 512), self_attention: bool = False,
+                 device="cuda"):
+        super().__init__()
+        self.arch, self.n_in, self.n_out = arch, n_in, n_out
+        self.img_size = tuple(img_size)
+        enc = Encoder(arch, n_in)
+        # DynamicUnet.__init__: encoder children whose output size differs from the next child's are the skips
+        self.sz_chg_idxs = [6, 5, 4, 2]
+        ni = enc.out_channels
+        post_bn = nn.BatchNorm2d(ni, eps=BN_EPS, momentum=BN_MOM)
+        with torch.no_grad():
+            post_bn.bias.fill_(1e-3)
+        middle = nn.Sequential(ConvLayer(ni, ni * 2, norm=None), ConvLayer(ni * 2, ni, norm=None))
+        layers: List[nn.Module] = [enc, post_bn, nn.ReLU(), middle]
+        xc = ni
+        for i, idx in enumerate(self.sz_chg_idxs):
+            not_final = i != len(self.sz_chg_idxs) - 1
+            sa = self_attention and (i == len(self.sz_chg_idxs) - 3)
+            blk = UnetBlock(xc, enc.skip_channels[idx], final_div=not_final, blur=True, self_attention=sa)
+            layers.append(blk)
+            xc = blk.out_channels
+        layers.append(PixelShuffle_ICNR(xc))
+        layers.append(_Marker("ResizeToOrig"))
+        layers.append(_Marker("MergeLayer(dense=True)"))
+        self.up_c = xc
+        xc += n_in
+        layers.append(ResBlock(1, xc, xc, norm=None))
+        layers.append(ConvLayer(xc, n_out, ks=1, norm=None, act=False))
+        _kaiming_init(layers[3], layers[-2])
+        self.layers = nn.ModuleList(layers)
+        self.cat_c = xc
+        self._post_bx = _BNExec(post_bn)
+        self._device = torch.device(device)
+        self.ctx: Optional[Ctx] = None
+        self.flat_param: Optional[torch.Tensor] = None
+        self.flat_grad: Optional[torch.Tensor] = None
+        self._last: Dict[str, object] = {}
+        if self._device.type == "cuda":
+            self._materialize()
+
+    # ------------------------------------------------------------------ fastai indexing contract
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return nn.Sequential(*list(self.layers)[i])
+        return self.layers[i]
+
+    def __len__(self):
+        return len(self.layers)
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _materialize(self):
+        dev = self._device
+        for b_name, b in list(self.named_buffers()):
+            b.data = b.data.to(dev)
+        params = list(self.parameters())
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._param_offsets = {}
+        for p, o in zip(params, offs):
+            view = self.flat_param[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+            self._param_offsets[id(p)] = (o, p.numel())
+        self.ctx = Ctx(dev)
+        for m in self.modules():
+            cx = getattr(m, "cx", None)
+            if isinstance(cx, _ConvExec):
+                cx.ctx = self.ctx
+
+    def param_span(self, p: nn.Parameter) -> Tuple[int, int]:
+        return self._param_offsets[id(p)]
+
+    def mark_weights_dirty(self):
+        """call after parameter memory was rewritten by a HIP kernel (Adam step, all-reduce broadcast)"""
+        self.ctx.weights_epoch += 1
+
+    def zero_grad(self, set_to_none: bool = False):  # grads are views of the flat buffer: keep them
+        self.flat_grad.zero_()
+
+    def _apply(self, fn, recurse=True):
+        # .cuda()/.to(device) after construction would break the flat views; the model is born on its device
+        probe = fn(torch.zeros(1, device=self._device))
+        if probe.device != self._device or probe.dtype != torch.float32:
+            raise RuntimeError("HipDynamicUnet is bound to its device/dtype at construction (fp32 on cuda)")
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.mark_weights_dirty()
+        return r
+
+    # ------------------------------------------------------------------ programs
+    def _hip_forward(self, x: torch.Tensor, training: bool) -> TS:
+        """x: [B, n_in, H, W] fp32 (device).  Returns the logits slice (NHWC)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.n_in, x.shape
+        x = x.contiguous()
+        ctx = self.ctx
+        ctx.training = training
+        N, _, H, W = x.shape
+        L = self.layers
+        enc: Encoder = L[0]
+        x0 = ctx.act(self, "x0", N, H, W, self.n_in, zero=True)
+        ops.nchw_to_nhwc(x, x0)
+        skips: Dict[int, TS] = {}
+        h = x0
+        for i, child in enumerate(enc):
+            if i == 3:
+                OH, OW = (h.H + 2 - 3) // 2 + 1, (h.W + 2 - 3) // 2 + 1
+                y = ctx.act(child, "y", N, OH, OW, h.C)
+                idx = ctx.vec(child, f"idx{N}x{OH}x{OW}", N * OH * OW * h.C, dtype=torch.uint8)
+                ops.maxpool(h, y, idx)
+                ctx.saved[(id(child), "x")] = h
+                h = y
+            elif i < 3:
+                h = child.hip_fwd(ctx, h)
+            else:
+                for blk in child:
+                    h = blk.hip_fwd(ctx, h)
+            if i in self.sz_chg_idxs:
+                skips[i] = h
+        # BatchNorm(ni) -> ReLU -> middle_conv
+        e = h
+        scale, shift = self._post_bx.coeffs(ctx, e)
+        m0 = ctx.act(self, "m0", e.N, e.H, e.W, e.C)
+        ops.affine_act(e, m0, scale, shift, relu=True)
+        ctx.saved[(id(self), "e")] = e
+        h = m0
+        for cl in L[3]:
+            a = ctx.act(cl, "a", h.N, h.H, h.W, cl.nf)
+            cl.cx.fwd(h, a, relu=True)
+            ctx.saved[(id(cl), "x")] = h
+            h = a
+        for k, idx in enumerate(self.sz_chg_idxs):
+            h = L[4 + k].hip_fwd(ctx, h, skips[idx])
+        nb = 4 + len(self.sz_chg_idxs)
+        X = ctx.act(self, "xcat", N, H, W, self.cat_c, zero=True)
+        L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
+        ops.nchw_to_nhwc(x, X.sub(self.up_c, self.n_in))
+        o = L[nb + 3].hip_fwd(ctx, X)
+        z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True)
+        head: ConvLayer = L[nb + 4]
+        head.cx.fwd(o, z)
+        ctx.saved[(id(head), "x")] = o
+        self._last = {"skips": skips, "N": N, "H": H, "W": W, "z": z, "training": training}
+        return z
+
+    def _hip_backward(self, dz: TS):
+        """dz: dL/dlogits (NHWC slice, same geometry as the logits).  Fills every .grad view."""
+        ctx = self.ctx
+        L = self.layers
+        enc: Encoder = L[0]
+        last = self._last
+        assert last.get("training", False), "backward needs a preceding training-mode forward"
+        skips: Dict[int, TS] = last["skips"]
+        nb = 4 + len(self.sz_chg_idxs)
+        head: ConvLayer = L[nb + 4]
+        o: TS = ctx.saved[(id(head), "x")]
+        do = head.bwd_from_dy(ctx, dz, mask=o)                  # masked by relu of the final ResBlock
+        dX = L[nb + 3].bwd_nonorm(ctx, do)
+        d = L[nb].hip_bwd(ctx, dX.sub(0, self.up_c))            # -> masked grad wrt UnetBlock 3 conv2 pre-activation
+        dskips: Dict[int, TS] = {}
+        for k in range(len(self.sz_chg_idxs) - 1, -1, -1):
+            idx = self.sz_chg_idxs[k]
+            s = skips[idx]
+            ds = ctx.act(self, f"dskip{idx}", s.N, s.H, s.W, s.C)
+            d = L[4 + k].hip_bwd(ctx, d, ds, False)
+            dskips[idx] = ds
+        # middle_conv (d is masked wrt middle_conv[1] pre-activation)
+        mids = list(L[3])
+        for j in range(len(mids) - 1, -1, -1):
+            xin: TS = ctx.saved[(id(mids[j]), "x")]
+            d = mids[j].bwd_from_dy(ctx, d, mask=xin)           # xin is a ReLU output in both cases (m0, mid0 out)
+        # post-encoder BN (ReLU already applied through the mask above)
+        e: TS = ctx.saved[(id(self), "e")]
+        de = ctx.act(self, "de", e.N, e.H, e.W, e.C)
+        self._post_bx.bwd(ctx, d, None, e, de)
+        # encoder, last child to first
+        d = de
+        children = list(enc)
+        for i in range(len(children) - 1, -1, -1):
+            child = children[i]
+            if i in dskips and i != len(children) - 1:
+                ops.copy_slice(dskips[i], d, accumulate=True)   # skip gradient joins the encoder gradient
+            if i > 3:
+                for blk in reversed(list(child)):
+                    d = blk.hip_bwd(ctx, d)
+            elif i == 3:
+                xin: TS = ctx.saved[(id(child), "x")]
+                idxb = ctx.vec(child, f"idx{d.N}x{d.H}x{d.W}", d.N * d.H * d.W * d.C, dtype=torch.uint8)
+                dx = ctx.act(child, "dx", xin.N, xin.H, xin.W, xin.C)
+                ops.maxpool_bwd(d, idxb, dx)
+                d = dx
+            else:
+                d = child.hip_bwd(ctx, d, need_dx=(i != 0))
+
+    # ------------------------------------------------------------------ torch-facing surface
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Raw logits [B, n_out, H, W] (a channels-last view of the NHWC logits buffer, no copy).
+        With grad enabled in training mode the result carries an autograd node that runs the HIP backward."""
+        if self.flat_param is None:
+            raise RuntimeError("HipDynamicUnet needs a GPU: it has no CPU fallback")
+        x = x.to(self._device, torch.float32)
+        if self.training and torch.is_grad_enabled():
+            return _UnetFunction.apply(self, x, self.flat_param.requires_grad_(True))
+        z = self._hip_forward(x, self.training)
+        return z.view().permute(0, 3, 1, 2)
+
+    def logits_ts(self) -> TS:
+        return self._last["z"]
+
+    def _ensure_grad_views(self):
+        """torch.optim's zero_grad(set_to_none=True) drops .grad: re-attach the flat-buffer views."""
+        for p in self.parameters():
+            o, n = self._param_offsets[id(p)]
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    def forward_loss_backward(self, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                              grad_scale: float = 1.0) -> torch.Tensor:
+        """One fused training pass: logits -> weighted per-pixel cross-entropy (CrossEntropyLossFlat(axis=1, weight),
+        train.py:195,211) -> backward into the flat gradient buffer.  Returns the loss as a 1-element device tensor
+        (no host sync).  grad_scale multiplies the gradient (1/world for tile-DDP averaging)."""
+        x = x.to(self._device, torch.float32)
+        z = self._hip_forward(x, True)
+        ctx = self.ctx
+        y = y.to(self._device, torch.int64).contiguous()
+        P = z.P
+        loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
+        ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
+        dz = ctx.act(self, "dlogits", z.N, z.H, z.W, z.C, zero=True)
+        ops.ce_bwd(z, y, weight, denom, grad_scale, dz)
+        self._ensure_grad_views()
+        self._hip_backward(dz)
+        return loss
+
+    @torch.no_grad()
+    def predict_probs(self, x: torch.Tensor, want_probs=True, want_argmax=True):
+        """eval-mode forward + softmax(dim=1) + argmax: what Learner.predict returns per tile (predict.py:193-203,232)."""
+        x = x.to(self._device, torch.float32)
+        z = self._hip_forward(x, False)
+        probs = torch.empty((z.N, z.C, z.H, z.W), dtype=torch.float32, device=self._device) if want_probs else None
+        amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=self._device) if want_argmax else None
+        ops.softmax_argmax(z, probs, amax)
+        return probs, amax
+
+    def memory_bytes(self) -> int:
+        return self.ctx.bytes_allocated() + 2 * self.flat_param.numel() * 4
+
+
+class _UnetFunction(torch.autograd.Function):
+    """Bridges torch autograd (loss.backward() in a fastai-style loop) to the HIP backward program.
+    Parameter gradients are written straight into the flat gradient buffer (the .grad views)."""
+
+    @staticmethod
+    def forward(ctx, model: HipDynamicUnet, x: torch.Tensor, flat_param: torch.Tensor):
+        z = model._hip_forward(x, True)
+        ctx.model = model
+        return z.view().permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dlogits: torch.Tensor):
+        model: HipDynamicUnet = ctx.model
+        z: TS = model._last["z"]
+        dz = model.ctx.act(model, "dlogits", z.N, z.H, z.W, z.C, zero=True)
+        dz.view().copy_(dlogits.permute(0, 2, 3, 1))
+        model._ensure_grad_views()
+        model._hip_backward(dz)
+        return None, None, None

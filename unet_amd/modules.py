@@ -1,0 +1,497 @@
+"""Module tree of the MI355X DynamicUnet and its hand-written forward / backward programs.
+
+The tree mirrors the object the reference builds at ``train.py:128-144``
+(``create_body(xresnetNN)`` + stem swap + fastai ``DynamicUnet(blur=True,
+blur_final=True, self_attention, norm_type=NormType, last_cross=True, bottle=False)``)
+child for child, so that ``state_dict()`` keys (``layers.0.0.0.weight`` ...), the
+splitter indexing ``m[0][:3] / m[0][3:] / m[1:]`` (``train.py:78-80``) and
+``print(model)`` look like fastai's.  ``nn.Conv2d`` / ``nn.BatchNorm2d`` instances are
+parameter holders only: the arithmetic runs in libunet_hip.so through
+``hip_fwd`` / ``hip_bwd`` of the container blocks.  There is no autograd inside the
+network and no CPU / eager fallback: calling ``forward`` of an inner block raises.
+
+Gradient convention of the programs
+    encoder blocks (conv -> BN -> ReLU):  ``hip_bwd`` receives dL/d(block output);
+    decoder conv layers (conv + bias + ReLU, no norm): ``hip_bwd`` receives the gradient
+    w.r.t. the PRE-activation, i.e. already multiplied by (output > 0): the ReLU backward
+    of a layer is fused into the dgrad epilogue of its consumer (UNET_CONV_MASK).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import TS
+
+BN_EPS = 1e-5
+BN_MOM = 0.1
+
+
+# --------------------------------------------------------------------------
+# execution context: persistent device buffers (static addresses => graph-capturable)
+# --------------------------------------------------------------------------
+
+class Ctx:
+    def __init__(self, device):
+        self.device = device
+        self.training = True
+        self.need_grad = True
+        self._acts: Dict[tuple, TS] = {}
+        self._vecs: Dict[tuple, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        self.saved: Dict[tuple, object] = {}
+        # bumped whenever parameter memory is rewritten behind torch's back (HIP Adam step, all-reduce ...):
+        # packed filter images older than this epoch are rebuilt
+        self.weights_epoch = 0
+
+    # activations are keyed by (owner id, tag, shape): allocated once per input geometry
+    def act(self, owner, tag, N, H, W, C, zero=False) -> TS:
+        key = (id(owner), tag, N, H, W, C)
+        t = self._acts.get(key)
+        if t is None:
+            t = ops.new_act(N, H, W, C, self.device, zero=zero)
+            self._acts[key] = t
+        return t
+
+    def vec(self, owner, tag, n, dtype=torch.float32) -> torch.Tensor:
+        key = (id(owner), tag, n, dtype)
+        t = self._vecs.get(key)
+        if t is None:
+            t = torch.zeros(n, dtype=dtype, device=self.device)
+            self._vecs[key] = t
+        return t
+
+    def workspace(self, nfloats: int) -> torch.Tensor:
+        """One shared scratch buffer: every launch is stream ordered, so reuse is safe."""
+        if self._ws is None or self._ws.numel() < nfloats:
+            self._ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def bytes_allocated(self) -> int:
+        n = sum(t.buf.numel() * 4 for t in self._acts.values()) + sum(v.numel() * v.element_size() for v in self._vecs.values())
+        return n + (0 if self._ws is None else self._ws.numel() * 4)
+
+
+def _no_forward(self, *a, **k):
+    raise RuntimeError(f"{type(self).__name__} runs only inside HipDynamicUnet (HIP path); it has no eager forward")
+
+
+# --------------------------------------------------------------------------
+# leaf helpers: one convolution / one batch norm on the device
+# --------------------------------------------------------------------------
+
+class _ConvExec:
+    """Packed-weight cache + launches for one nn.Conv2d parameter holder."""
+
+    def __init__(self, conv: nn.Conv2d):
+        self.conv = conv
+        self.ks = conv.kernel_size[0]
+        self.stride = conv.stride[0]
+        self.wp_f: Optional[torch.Tensor] = None
+        self.wp_d: Optional[torch.Tensor] = None
+        self._ver_f = None
+        self._ver_d = None
+        self.ctx: Optional["Ctx"] = None   # set by HipDynamicUnet once the tree is built
+
+    def packed(self, mode: int) -> torch.Tensor:
+        w = self.conv.weight
+        ver = (w._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
+        if mode == 0:
+            if self.wp_f is None or self._ver_f != ver:
+                self.wp_f = ops.pack_weights(w.data, 0, self.wp_f)
+                self._ver_f = ver
+            return self.wp_f
+        if self.wp_d is None or self._ver_d != ver:
+            self.wp_d = ops.pack_weights(w.data, 1, self.wp_d)
+            self._ver_d = ver
+        return self.wp_d
+
+    def out_hw(self, H, W):
+        return ops.conv_out_hw(H, W, self.ks, self.stride)
+
+    def fwd(self, x: TS, y: TS, relu=False, res: Optional[TS] = None):
+        b = self.conv.bias
+        ops.conv2d(x, self.packed(0), y, self.ks, self.stride, bias=None if b is None else b.data, res=res, relu=relu)
+
+    def bwd_w(self, ctx: Ctx, x: TS, dy: TS):
+        """weight (+bias) gradient into the .grad views of the flat gradient buffer"""
+        w, b = self.conv.weight, self.conv.bias
+        n = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)
+        ops.conv2d_wgrad(x, dy, w.grad, self.ks, self.stride, ctx.workspace(n), dbias=None if b is None else b.grad)
+
+    def bwd_x(self, dy: TS, dx: TS, res: Optional[TS] = None, mask: Optional[TS] = None):
+        ops.conv2d_dgrad(dy, self.packed(1), dx, self.ks, self.stride, res=res, mask=mask)
+
+
+class _BNExec:
+    """Train-mode statistics / eval-mode coefficients / backward of one nn.BatchNorm2d holder."""
+
+    def __init__(self, bn: nn.BatchNorm2d):
+        self.bn = bn
+        self.C = bn.num_features
+
+    def coeffs(self, ctx: Ctx, x: TS) -> Tuple[torch.Tensor, torch.Tensor]:
+        bn, C_ = self.bn, self.C
+        scale, shift = ctx.vec(self, "scale", C_), ctx.vec(self, "shift", C_)
+        if ctx.training:
+            P = x.P
+            rows = ops.bn_stats_rows(P)
+            part = ctx.workspace(2 * rows * C_)
+            ops.bn_stats(x, part)
+            mean, invstd = ctx.vec(self, "mean", C_), ctx.vec(self, "invstd", C_)
+            ops.bn_finalize(part, part[rows * C_:], rows, P, C_, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                            BN_MOM, BN_EPS, scale, shift, mean, invstd)
+            bn.num_batches_tracked += 1
+        else:
+            ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, BN_EPS, scale, shift)
+        return scale, shift
+
+    def bwd(self, ctx: Ctx, dout: TS, out: Optional[TS], x: TS, dx: TS, gout: Optional[TS] = None, g_accumulate=False):
+        """dx = dL/dx of y = bn(x) given dL/d(act(y + ..)) = dout; `out` (post-ReLU) supplies the ReLU mask."""
+        bn, C_ = self.bn, self.C
+        P = x.P
+        mean, invstd = ctx.vec(self, "mean", C_), ctx.vec(self, "invstd", C_)
+        rows = ops.bn_stats_rows(P)
+        part = ctx.workspace(2 * rows * C_)
+        ops.bn_bwd_reduce(dout, out, x, mean, invstd, part)
+        c1, c2 = ctx.vec(self, "c1", C_), ctx.vec(self, "c2", C_)
+        ops.bn_bwd_finalize(part, rows, P, C_, bn.weight.grad, bn.bias.grad, c1, c2)
+        ops.bn_bwd_apply(dout, out, x, mean, invstd, bn.weight.data, c1, c2, dx, gout=gout, g_accumulate=g_accumulate)
+
+
+# --------------------------------------------------------------------------
+# fastai layers.py: ConvLayer / ResBlock / PixelShuffle_ICNR
+# --------------------------------------------------------------------------
+
+class ConvLayer(nn.Sequential):
+    """conv [-> BN] [-> ReLU]; norm 'batch' | 'batchzero' (encoder) or None (decoder: bias, no norm)."""
+    forward = _no_forward
+
+    def __init__(self, ni, nf, ks=3, stride=1, norm: Optional[str] = "batch", act=True, bias_std=0.01):
+        bn = norm in ("batch", "batchzero")
+        conv = nn.Conv2d(ni, nf, ks, stride=stride, padding=(ks - 1) // 2, bias=not bn)
+        with torch.no_grad():
+            if conv.bias is not None:
+                conv.bias.normal_(0, bias_std) if bias_std != 0 else conv.bias.zero_()
+            if act:
+                nn.init.kaiming_uniform_(conv.weight)
+        layers: List[nn.Module] = [conv]
+        if bn:
+            b = nn.BatchNorm2d(nf, eps=BN_EPS, momentum=BN_MOM)
+            with torch.no_grad():
+                b.bias.fill_(1e-3)
+                b.weight.fill_(0.0 if norm == "batchzero" else 1.0)
+            layers.append(b)
+        if act:
+            layers.append(nn.ReLU())
+        super().__init__(*layers)
+        self.has_bn, self.has_act = bn, act
+        self.cx = _ConvExec(conv)
+        self.bx = _BNExec(self[1]) if bn else None
+        self.nf = nf
+
+    # ---- encoder flavour: conv -> BN -> [ReLU]; returns the materialised activation
+    def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
+        OH, OW = self.cx.out_hw(x.H, x.W)
+        if self.has_bn:
+            y = ctx.act(self, "y", x.N, OH, OW, self.nf)
+            self.cx.fwd(x, y)
+            scale, shift = self.bx.coeffs(ctx, y)
+            a = ctx.act(self, "a", x.N, OH, OW, self.nf)
+            ops.affine_act(y, a, scale, shift, relu=self.has_act)
+        else:
+            a = ctx.act(self, "a", x.N, OH, OW, self.nf)
+            self.cx.fwd(x, a, relu=self.has_act)
+        ctx.saved[(id(self), "x")] = x
+        return a
+
+    def raw_fwd(self, ctx: Ctx, x: TS) -> Tuple[TS, torch.Tensor, torch.Tensor]:
+        """conv + BN statistics only (the affine is applied by the caller, fused with the residual add)."""
+        OH, OW = self.cx.out_hw(x.H, x.W)
+        y = ctx.act(self, "y", x.N, OH, OW, self.nf)
+        self.cx.fwd(x, y)
+        scale, shift = self.bx.coeffs(ctx, y)
+        ctx.saved[(id(self), "x")] = x
+        return y, scale, shift
+
+    def hip_bwd(self, ctx: Ctx, da: TS, need_dx=True, dx_res: Optional[TS] = None) -> Optional[TS]:
+        """BN flavour: da = dL/d(output).  Returns dL/dx (+ dx_res fused) or None."""
+        assert self.has_bn
+        x: TS = ctx.saved[(id(self), "x")]
+        y = ctx.act(self, "y", da.N, da.H, da.W, self.nf)
+        a = ctx.act(self, "a", da.N, da.H, da.W, self.nf)
+        dy = ctx.act(self, "dy", da.N, da.H, da.W, self.nf)
+        self.bx.bwd(ctx, da, a if self.has_act else None, y, dy)
+        return self.bwd_from_dy(ctx, dy, need_dx, dx_res)
+
+    def bwd_from_dy(self, ctx: Ctx, dy: TS, need_dx=True, dx_res: Optional[TS] = None, mask: Optional[TS] = None) -> Optional[TS]:
+        """dy = dL/d(conv output).  wgrad (+bias) then dgrad; `mask` fuses the ReLU backward of the producer of x."""
+        x: TS = ctx.saved[(id(self), "x")]
+        self.cx.bwd_w(ctx, x, dy)
+        if not need_dx:
+            return None
+        dx = ctx.act(self, "dx", x.N, x.H, x.W, x.C)
+        self.cx.bwd_x(dy, dx, res=dx_res, mask=mask)
+        return dx
+
+
+class ResBlock(nn.Module):
+    """fastai ResBlock.  Encoder flavour (norm='batch'): out = relu(bn(convpath(x)) + idpath(x));
+    decoder flavour (norm=None, the final block): out = relu(conv2(relu(conv1(x)+b1)) + b2 + x)."""
+    forward = _no_forward
+
+    def __init__(self, expansion, ni, nf, stride=1, norm: Optional[str] = "batch"):
+        super().__init__()
+        norm2 = "batchzero" if norm == "batch" else norm
+        nh = nf
+        nf, ni = nf * expansion, ni * expansion
+        if expansion == 1:
+            convpath = [ConvLayer(ni, nh, 3, stride=stride, norm=norm), ConvLayer(nh, nf, 3, norm=norm2, act=False)]
+        else:
+            convpath = [ConvLayer(ni, nh, 1, norm=norm), ConvLayer(nh, nh, 3, stride=stride, norm=norm),
+                        ConvLayer(nh, nf, 1, norm=norm2, act=False)]
+        self.convpath = nn.Sequential(*convpath)
+        idpath: List[nn.Module] = []
+        if ni != nf:
+            idpath.append(ConvLayer(ni, nf, 1, norm="batch", act=False))
+        if stride != 1:
+            idpath.insert(0, nn.AvgPool2d(stride, ceil_mode=True))
+        self.idpath = nn.Sequential(*idpath)
+        self.act = nn.ReLU(inplace=True)
+        self.has_norm = norm is not None
+        self.pool = stride != 1
+        # plain attribute (not a registered child: it already lives in self.idpath)
+        self.__dict__["idconv"] = next((m for m in self.idpath if isinstance(m, ConvLayer)), None)
+        self.nf = nf
+
+    # ------------------------------------------------------------ encoder flavour
+    def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
+        if not self.has_norm:
+            return self._fwd_nonorm(ctx, x)
+        h = x
+        for cl in list(self.convpath)[:-1]:
+            h = cl.hip_fwd(ctx, h)
+        y2, s2, b2 = self.convpath[-1].raw_fwd(ctx, h)
+        p = x
+        if self.pool:
+            p = ctx.act(self, "pool", x.N, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
+            ops.avgpool(x, p)
+        out = ctx.act(self, "out", y2.N, y2.H, y2.W, self.nf)
+        if self.idconv is not None:
+            yi, si, bi = self.idconv.raw_fwd(ctx, p)
+            ops.affine_act(y2, out, s2, b2, x2=yi, scale2=si, shift2=bi, relu=True)
+        else:
+            ops.affine_act(y2, out, s2, b2, x2=p, relu=True)
+        ctx.saved[(id(self), "x")] = x
+        return out
+
+    def hip_bwd(self, ctx: Ctx, dout: TS, need_dx=True) -> Optional[TS]:
+        if not self.has_norm:
+            raise RuntimeError("use bwd_nonorm for the decoder ResBlock")
+        x: TS = ctx.saved[(id(self), "x")]
+        last: ConvLayer = self.convpath[-1]
+        out = ctx.act(self, "out", dout.N, dout.H, dout.W, self.nf)
+        y2 = ctx.act(last, "y", dout.N, dout.H, dout.W, self.nf)
+        dy2 = ctx.act(last, "dy", dout.N, dout.H, dout.W, self.nf)
+        # identity branch first so that its gradient can be fused into the conv path's last dgrad
+        if self.idconv is not None:
+            last.bx.bwd(ctx, dout, out, y2, dy2)
+            yi = ctx.act(self.idconv, "y", dout.N, dout.H, dout.W, self.nf)
+            dyi = ctx.act(self.idconv, "dy", dout.N, dout.H, dout.W, self.nf)
+            self.idconv.bx.bwd(ctx, dout, out, yi, dyi)
+            dp = self.idconv.bwd_from_dy(ctx, dyi, need_dx=need_dx)
+        else:
+            dp = ctx.act(self, "g", dout.N, dout.H, dout.W, self.nf)
+            last.bx.bwd(ctx, dout, out, y2, dy2, gout=dp)
+        dxb = dp
+        if need_dx and self.pool:
+            dxb = ctx.act(self, "dpool", x.N, x.H, x.W, x.C)
+            ops.avgpool_bwd(dp, dxb)
+        # conv path, last to first
+        d = last.bwd_from_dy(ctx, dy2)
+        cls = list(self.convpath)[:-1]
+        for i in range(len(cls) - 1, -1, -1):
+            first = i == 0
+            d = cls[i].hip_bwd(ctx, d, need_dx=(need_dx or not first), dx_res=dxb if first else None)
+        return d
+
+    # ------------------------------------------------------------ decoder flavour (no norm)
+    def _fwd_nonorm(self, ctx: Ctx, x: TS) -> TS:
+        c1, c2 = self.convpath[0], self.convpath[1]
+        t1 = ctx.act(c1, "a", x.N, x.H, x.W, c1.nf)
+        c1.cx.fwd(x, t1, relu=True)
+        out = ctx.act(self, "out", x.N, x.H, x.W, self.nf)
+        c2.cx.fwd(t1, out, relu=True, res=x)
+        ctx.saved[(id(c1), "x")] = x
+        ctx.saved[(id(c2), "x")] = t1
+        return out
+
+    def bwd_nonorm(self, ctx: Ctx, dout_pre: TS) -> TS:
+        """dout_pre = dL/d(pre-activation of the block output), i.e. already masked by (out > 0).
+        Returns dL/dx (x is not a ReLU output here: it is the dense concat)."""
+        c1, c2 = self.convpath[0], self.convpath[1]
+        t1: TS = ctx.saved[(id(c2), "x")]
+        dt1 = c2.bwd_from_dy(ctx, dout_pre, mask=t1)
+        return c1.bwd_from_dy(ctx, dt1, dx_res=dout_pre)
+
+
+class PixelShuffle_ICNR(nn.Sequential):
+    """1x1 ConvLayer(ni -> 4 nf, bias, ReLU) -> PixelShuffle(2) [-> ReplicationPad2d((1,0,1,0)) -> AvgPool2d(2,1)]."""
+    forward = _no_forward
+
+    def __init__(self, ni, nf=None, blur=False):
+        nf = ni if nf is None else nf
+        layers: List[nn.Module] = [ConvLayer(ni, nf * 4, ks=1, norm=None, bias_std=0), nn.PixelShuffle(2)]
+        with torch.no_grad():
+            layers[0][0].weight.copy_(icnr_init(layers[0][0].weight.data))
+        if blur:
+            layers += [nn.ReplicationPad2d((1, 0, 1, 0)), nn.AvgPool2d(2, stride=1)]
+        super().__init__(*layers)
+        self.blur, self.nf = blur, nf
+
+    def hip_fwd(self, ctx: Ctx, up_in: TS, dst: TS, out_hw: Tuple[int, int]):
+        """writes [blur](shuffle(relu(conv1x1(up_in)))) into `dst` (a channel slice of the concat buffer),
+        nearest-resized to out_hw when the skip / input size differs (non-/32 tiles)."""
+        cl: ConvLayer = self[0]
+        yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
+        cl.cx.fwd(up_in, yc, relu=True)
+        ctx.saved[(id(cl), "x")] = up_in
+        if (2 * up_in.H, 2 * up_in.W) == tuple(out_hw):
+            ops.shuffle_blur(yc, dst, self.blur)
+        else:
+            tmp = ctx.act(self, "up", up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
+            ops.shuffle_blur(yc, tmp, self.blur)
+            ops.resize_nearest(tmp, dst)
+
+    def hip_bwd(self, ctx: Ctx, d_dst: TS) -> TS:
+        """d_dst = dL/d(dst slice).  Returns dL/d(pre-activation of the producer of up_in) (masked)."""
+        cl: ConvLayer = self[0]
+        up_in: TS = ctx.saved[(id(cl), "x")]
+        yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
+        dyc = ctx.act(cl, "dy", up_in.N, up_in.H, up_in.W, 4 * self.nf)
+        if (2 * up_in.H, 2 * up_in.W) == (d_dst.H, d_dst.W):
+            ops.shuffle_blur_bwd(d_dst, yc, dyc, self.blur)
+        else:
+            tmp = ctx.act(self, "dup", up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
+            ops.resize_nearest_bwd(d_dst, tmp)
+            ops.shuffle_blur_bwd(tmp, yc, dyc, self.blur)
+        return cl.bwd_from_dy(ctx, dyc, mask=up_in)
+
+
+def icnr_init(x: torch.Tensor, scale=2, init=nn.init.kaiming_normal_) -> torch.Tensor:
+    ni, nf, h, w = x.shape
+    ni2 = int(ni / (scale ** 2))
+    k = init(x.new_zeros([ni2, nf, h, w])).transpose(0, 1)
+    k = k.contiguous().view(ni2, nf, -1).repeat(1, 1, scale ** 2)
+    return k.contiguous().view([nf, ni, h, w]).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------
+# decoder blocks (vision/models/unet.py)
+# --------------------------------------------------------------------------
+
+def _bias_relu_layer_fwd(ctx: Ctx, cl: ConvLayer, x: TS) -> TS:
+    a = ctx.act(cl, "a", x.N, x.H, x.W, cl.nf)
+    cl.cx.fwd(x, a, relu=True)
+    ctx.saved[(id(cl), "x")] = x
+    return a
+
+
+class UnetBlock(nn.Module):
+    forward = _no_forward
+
+    def __init__(self, up_in_c, x_in_c, final_div=True, blur=True, self_attention=False):
+        super().__init__()
+        if self_attention:
+            raise NotImplementedError("self_attention=True is not built yet on the HIP path (SURVEY.md A12)")
+        self.shuf = PixelShuffle_ICNR(up_in_c, up_in_c // 2, blur=blur)
+        self.bn = nn.BatchNorm2d(x_in_c, eps=BN_EPS, momentum=BN_MOM)
+        with torch.no_grad():
+            self.bn.bias.fill_(1e-3)
+        ni = up_in_c // 2 + x_in_c
+        nf = ni if final_div else ni // 2
+        self.conv1 = ConvLayer(ni, nf, norm=None)
+        self.conv2 = ConvLayer(nf, nf, norm=None)
+        self.relu = nn.ReLU()
+        _kaiming_init(self.conv1, self.conv2)
+        self.cu, self.cs, self.ni, self.out_channels = up_in_c // 2, x_in_c, ni, nf
+        self.bx = _BNExec(self.bn)
+
+    def hip_fwd(self, ctx: Ctx, up_in: TS, s: TS) -> TS:
+        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
+        self.shuf.hip_fwd(ctx, up_in, X.sub(0, self.cu), (s.H, s.W))
+        scale, shift = self.bx.coeffs(ctx, s)
+        ops.affine_act(s, X.sub(self.cu, self.cs), scale, shift, relu=True)
+        ctx.saved[(id(self), "s")] = s
+        t1 = _bias_relu_layer_fwd(ctx, self.conv1, X)
+        return _bias_relu_layer_fwd(ctx, self.conv2, t1)
+
+    def hip_bwd(self, ctx: Ctx, dt2_pre: TS, dskip: TS, dskip_accumulate: bool) -> TS:
+        """dt2_pre = masked gradient w.r.t. conv2's pre-activation.  Writes dL/d(skip) into dskip and returns the
+        masked gradient w.r.t. the pre-activation of the producer of up_in."""
+        s: TS = ctx.saved[(id(self), "s")]
+        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
+        t1: TS = ctx.saved[(id(self.conv2), "x")]
+        dt1 = self.conv2.bwd_from_dy(ctx, dt2_pre, mask=t1)
+        dX = self.conv1.bwd_from_dy(ctx, dt1, mask=X)          # relu(cat) backward fused
+        assert not dskip_accumulate
+        self.bx.bwd(ctx, dX.sub(self.cu, self.cs), None, s, dskip)
+        return self.shuf.hip_bwd(ctx, dX.sub(0, self.cu))
+
+
+def _kaiming_init(*mods):
+    for m in mods:
+        for l in m.modules():
+            if isinstance(l, nn.Conv2d):
+                nn.init.kaiming_normal_(l.weight)
+                if l.bias is not None:
+                    with torch.no_grad():
+                        l.bias.fill_(0.0)
+
+
+XRESNET_LAYERS = {"xresnet18": (1, [2, 2, 2, 2]), "xresnet34": (1, [3, 4, 6, 3]), "xresnet50": (4, [3, 4, 6, 3])}
+
+
+def _init_cnn(m: nn.Module):
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, 0)
+    if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+        nn.init.kaiming_normal_(m.weight)
+    for l in m.children():
+        _init_cnn(l)
+
+
+class MaxPool(nn.MaxPool2d):
+    forward = _no_forward
+
+
+class Stage(nn.Sequential):
+    forward = _no_forward
+
+
+class Encoder(nn.Sequential):
+    """children 0..7 of fastai XResNet (create_body cut at the pooling layer) with the reference's stem swap."""
+    forward = _no_forward
+
+    def __init__(self, arch: str, c_in: int):
+        expansion, layers = XRESNET_LAYERS[arch]
+        stem_szs = [3, 32, 32, 64]
+        stem = [ConvLayer(stem_szs[i], stem_szs[i + 1], 3, stride=2 if i == 0 else 1) for i in range(3)]
+        block_szs = [64 // expansion, 64, 128, 256, 512]
+        stages = []
+        for i, nb in enumerate(layers):
+            ni, nf = block_szs[i], block_szs[i + 1]
+            stages.append(Stage(*[ResBlock(expansion, ni if j == 0 else nf, nf, stride=(1 if i == 0 else 2) if j == 0 else 1)
+                                  for j in range(nb)]))
+        super().__init__(*stem, MaxPool(3, stride=2, padding=1), *stages)
+        _init_cnn(self)
+        # train.py:130-135: fresh nn.Conv2d(c_in, 32, 3, 2, 1, bias=False) with PyTorch's default init
+        new_conv = nn.Conv2d(c_in, 32, kernel_size=3, stride=2, padding=1, bias=False)
+        self[0][0] = new_conv
+        self[0].cx = _ConvExec(new_conv)
+        self.out_channels = block_szs[-1] * expansion
+        self.skip_channels = {2: 64, 4: 64 * expansion, 5: 128 * expansion, 6: 256 * expansion}

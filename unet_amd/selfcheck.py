@@ -1,0 +1,48 @@
+"""smoke(): one tiny train step + one eval forward on cuda:0, checked against the CPU oracle."""
+from __future__ import annotations
+
+import torch
+
+
+def smoke_check(verbose: bool = True) -> dict:
+    from oracle import unet_oracle as O       # checker only (allowed in smoke())
+    from unet_amd.model import HipDynamicUnet
+
+    torch.manual_seed(0)
+    ref = O.DynamicUnet("xresnet18", 4, 5, (64, 64))
+    O.randomize_bn_and_zero_gammas(ref)
+    model = HipDynamicUnet("xresnet18", 4, 5, (64, 64), device="cuda:0")
+    model.load_state_dict(ref.state_dict())
+    x, y = O.synthetic_batch(2, 4, 64, 64, 5)
+    w = torch.full((5,), 0.2)
+
+    ref.train()
+    logits_ref = ref(x)
+    loss_ref = O.CrossEntropyLossFlat(weight=w)(logits_ref, y)
+    loss_ref.backward()
+
+    model.train()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    logits = model.logits_ts().view().permute(0, 3, 1, 2).cpu()
+    err = (logits - logits_ref.detach()).abs().max().item()
+    gerr = 0.0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        scale = q.grad.abs().max().item() + 1e-12
+        gerr = max(gerr, (p.grad.cpu() - q.grad).abs().max().item() / scale)
+    out = {"logit_err": err, "loss": float(loss.item()), "loss_ref": float(loss_ref.item()), "grad_rel_err": gerr}
+    if verbose:
+        print("smoke:", out)
+    assert err < 1e-3, out
+    assert abs(out["loss"] - out["loss_ref"]) < 1e-4, out
+    assert gerr < 5e-3, out
+
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        pr_ref = torch.softmax(ref(x), dim=1)
+    probs, amax = model.predict_probs(x.cuda())
+    torch.cuda.synchronize()
+    assert (probs.cpu() - pr_ref).abs().max().item() < 1e-3
+    agree = (amax.cpu() == pr_ref.argmax(1)).float().mean().item()
+    assert agree == 1.0, f"argmax agreement {agree}"
+    return out
