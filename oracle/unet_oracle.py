@@ -350,8 +350,11 @@ class CrossEntropyLossFlat:
         self.axis = axis
 
     def __call__(self, inp: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        # fastai BaseLoss.__call__: `inp, targ = map(self._contiguous, (inp, targ))` -- BOTH are
+        # transposed (axis <-> last) before flattening, so pixel i of inp meets pixel i of targ.
         inp = inp.transpose(self.axis, -1).contiguous()
-        return self.func(inp.view(-1, inp.shape[-1]), targ.contiguous().view(-1))
+        targ = targ.transpose(self.axis, -1).contiguous()
+        return self.func(inp.view(-1, inp.shape[-1]), targ.view(-1))
 
     def activation(self, x):
         return F.softmax(x, dim=self.axis)

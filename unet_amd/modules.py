@@ -477,6 +477,11 @@ class Encoder(nn.Sequential):
     """children 0..7 of fastai XResNet (create_body cut at the pooling layer) with the reference's stem swap."""
     forward = _no_forward
 
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):   # m[0][:3] / m[0][3:] of the fastai splitter (train.py:78-80)
+            return nn.Sequential(*list(self._modules.values())[idx])
+        return super().__getitem__(idx)
+
     def __init__(self, arch: str, c_in: int):
         expansion, layers = XRESNET_LAYERS[arch]
         stem_szs = [3, 32, 32, 64]
