@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Headline benchmark: 512x512 tiles/s, forward + backward + optimizer step, 4-channel -> 5-class xresnet34
+DynamicUnet (BASELINE.json configs[1]: batch 16 per MI355X; configs[2]: the same per GPU, tile-DDP over N GPUs).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0.  `value` = tiles processed by all ranks / wall time of the K timed steps (max over
+ranks), inputs resident in HBM.  `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM 3x3 conv, the
+100->100 @512x512 layer of the final ResBlock): algorithmic FLOPs of that launch / its mean duration measured
+with events on the launch stream inside the timed region.  `cpu_baseline` = the torch-CPU oracle of the same step
+on this host's cores, on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+GFLOP_PER_TILE_FWD_BWD = 767.388      # BASELINE.md section 2 (conv MACs x 2, cfg2)
+PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 matrix == vector peak
+ARCH, N_IN, N_CLS, SIZE = "xresnet34", 4, 5, 512
+
+
+def synth(batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 256, (batch, N_IN, SIZE, SIZE), generator=g).float() / 255
+    y = torch.randint(0, N_CLS, (batch, SIZE, SIZE), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(sample_tiles: int = 1, iters: int = 2):
+    """The reference's path restated on PyTorch-CPU (oracle/unet_oracle.py), same step, bounded sample."""
+    from oracle import unet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = O.DynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE))
+    m.train()
+    opt = O.FastaiAdam(O.xresnet_split(m), list(O.even_mults(1e-5, 1e-4, 3)), no_wd=O.bn_bias_params(m))
+    loss_fn = O.CrossEntropyLossFlat(weight=torch.full((N_CLS,), 1.0 / N_CLS))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randint(0, 256, (sample_tiles, N_IN, SIZE, SIZE), generator=g).float() / 255
+    y = torch.randint(0, N_CLS, (sample_tiles, SIZE, SIZE), generator=g)
+
+    def step():
+        opt.zero_grad()
+        loss_fn(m(x), y).backward()
+        opt.step()
+
+    step()  # warm-up
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": round(sample_tiles / t, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_tiles} tile(s) of the same 4x512x512 xresnet34 step, fp32, 1 warm-up + {iters} timed, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from unet_amd.distributed import broadcast_parameters, init_from_env
+    rank, local_rank, world = init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    import torch.distributed as dist
+
+    torch.manual_seed(0)
+    model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev)
+    broadcast_parameters(model.flat_param, list(model.buffers()))
+    model.mark_weights_dirty()
+    model.train()
+    lr, enc_factor = 1e-4, 10.0        # params_and_main.py:53,84 defaults
+    lrs = [lr / enc_factor, lr / enc_factor ** 0.5, lr]
+    opt = FlatAdam(model, lrs)
+    weights = torch.full((N_CLS,), 1.0 / N_CLS, device=dev)   # CLASS_WEIGHTS "even" (train.py:338-339)
+    step = TrainStep(model, opt, weights, world)
+    x, y = synth(args.batch, 1234 + rank, dev)
+
+    probe_layer = model.layers[11].convpath[0]      # final ResBlock conv1: 100 -> 100 @ 512x512
+    for _ in range(args.warmup):
+        step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    probe_layer.cx.probe = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    probes = probe_layer.cx.probe
+    probe_layer.cx.probe = None
+    kern_ms = sum(a.elapsed_time(b) for a, b in probes) / max(1, len(probes))
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        value = tiles / dt
+        c = model.cat_c
+        kflop = 2.0 * args.batch * SIZE * SIZE * c * c * 9            # algorithmic FLOPs of the probed launch
+        achieved = kflop / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "512x512 tiles/sec fwd+bwd (4-ch->5-class U-Net)", "value": round(value, 3), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: 4x512x512 tiles, xresnet34 DynamicUnet, 5 classes, fwd+bwd+fastai-Adam step, "
+                                   "BN train mode, CE weights even", "tiles_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"tile-dp{world}", "self_attention": False},
+            "loss": round(float(loss.item()), 5),
+            "step_tflops": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
+            "step_frac_of_f32_peak": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3 / (PEAK_F32_TFLOPS * world), 4),
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<32,2,2,2,2,4> (3x3 100->100 @512^2, fwd)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(kern_ms, 4), "launch_gflop": round(kflop / 1e9, 2)},
+            "hbm_bytes_allocated": model.memory_bytes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

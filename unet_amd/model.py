@@ -76,6 +76,10 @@ class HipDynamicUnet(nn.Module):
         self.flat_param: Optional[torch.Tensor] = None
         self.flat_grad: Optional[torch.Tensor] = None
         self._last: Dict[str, object] = {}
+        # called as hook(offset) during backward once every gradient element at flat index >= offset is final
+        # (tile-DDP launches its bucketed all-reduce from here, overlapping the rest of the backward)
+        self.grad_ready_hook = None
+        # optional (start_event, end_event) recorded around one conv launch: {id(conv_layer): (e0, e1)}
         if self._device.type == "cuda":
             self._materialize()
 
@@ -108,6 +112,13 @@ class HipDynamicUnet(nn.Module):
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
             self._param_offsets[id(p)] = (o, p.numel())
         self.ctx = Ctx(dev)
+        enc = self.layers[0]
+        self._enc_child_offset = {}
+        for i, child in enumerate(enc):
+            ps = list(child.parameters())
+            if ps:
+                self._enc_child_offset[i] = min(self._param_offsets[id(p)][0] for p in ps)
+        self._decoder_offset = min(self._param_offsets[id(p)][0] for l in list(self.layers)[1:] for p in l.parameters())
         for m in self.modules():
             cx = getattr(m, "cx", None)
             if isinstance(cx, _ConvExec):
@@ -220,6 +231,9 @@ class HipDynamicUnet(nn.Module):
         e: TS = ctx.saved[(id(self), "e")]
         de = ctx.act(self, "de", e.N, e.H, e.W, e.C)
         self._post_bx.bwd(ctx, d, None, e, de)
+        hook = self.grad_ready_hook
+        if hook is not None:
+            hook(self._decoder_offset)
         # encoder, last child to first
         d = de
         children = list(enc)
@@ -238,6 +252,8 @@ class HipDynamicUnet(nn.Module):
                 d = dx
             else:
                 d = child.hip_bwd(ctx, d, need_dx=(i != 0))
+            if hook is not None and i in self._enc_child_offset:
+                hook(self._enc_child_offset[i])
 
     # ------------------------------------------------------------------ torch-facing surface
     def forward(self, x: torch.Tensor) -> torch.Tensor:
