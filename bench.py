@@ -39,7 +39,13 @@ def synth(batch, seed, device):
 def cpu_baseline(sample_tiles: int = 1, iters: int = 2):
     """The reference's path restated on PyTorch-CPU (oracle/unet_oracle.py), same step, bounded sample."""
     from oracle import unet_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share; os.cpu_count() reports the whole host and would
+    # oversubscribe oneDNN by an order of magnitude
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("UNET_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = O.DynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE))
@@ -55,10 +61,12 @@ def cpu_baseline(sample_tiles: int = 1, iters: int = 2):
         loss_fn(m(x), y).backward()
         opt.step()
 
-    step()  # warm-up
+    t0 = time.perf_counter(); step()  # warm-up
+    print(f"[bench] cpu_baseline warm-up {time.perf_counter() - t0:.1f}s on {cores} threads", file=sys.stderr, flush=True)
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline iter {ts[-1]:.1f}s", file=sys.stderr, flush=True)
     t = sorted(ts)[len(ts) // 2]
     return {"value": round(sample_tiles / t, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{sample_tiles} tile(s) of the same 4x512x512 xresnet34 step, fp32, 1 warm-up + {iters} timed, median"}
@@ -96,9 +104,16 @@ def main():
     step = TrainStep(model, opt, weights, world)
     x, y = synth(args.batch, 1234 + rank, dev)
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     probe_layer = model.layers[11].convpath[0]      # final ResBlock conv1: 100 -> 100 @ 512x512
-    for _ in range(args.warmup):
+    log(f"model ready: {sum(p.numel() for p in model.parameters())} params, batch {args.batch}/gpu, world {world}")
+    for i in range(args.warmup):
         step(x, y)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -150,14 +150,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
 }
 
 // dw[(k*Cin + c)*T + t] (=|+=) sum_split part[split][t][k][c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, size_t KC_,
-                                    int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < KC_; i += (size_t)gridDim.x * blockDim.x) {
-        for (int t = 0; t < T; ++t) {
-            float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += part[((size_t)sp * T + t) * KC_ + i];
-            if (accumulate) dw[i * T + t] += s; else dw[i * T + t] = s;
+// one thread per (t, k*Cin+c): reads are coalesced along c for every split, 8 independent loads in flight
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T,
+                                                           size_t KC_, int accumulate) {
+    const size_t total = (size_t)T * KC_;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = e / KC_, i = e - t * KC_;
+        const float* p = part + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= splits; sp += 4) {
+            s0 += p[(size_t)(sp + 0) * total];
+            s1 += p[(size_t)(sp + 1) * total];
+            s2 += p[(size_t)(sp + 2) * total];
+            s3 += p[(size_t)(sp + 3) * total];
         }
+        for (; sp < splits; ++sp) s0 += p[(size_t)sp * total];
+        const float s = (s0 + s1) + (s2 + s3);
+        float* o = dw + i * T + t;
+        *o = accumulate ? (*o + s) : s;
     }
 }
 
@@ -195,8 +206,8 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.total_tiles = d->N * k.tiles_y * k.tiles_x;
     k.kt = unet::cdiv(d->Cout, BK);
     k.ct = unet::cdiv(d->Cin, BC);
-    // aim for ~1024 workgroups (256 CUs x 2 resident x 2 waves of blocks); at least 4 tiles per block
-    int want = 1024 / (k.kt * k.ct);
+    // aim for ~512 workgroups (256 CUs x 2 resident); at least 4 tiles per block
+    int want = 512 / (k.kt * k.ct);
     if (want < 1) want = 1;
     int tpb = unet::cdiv(k.total_tiles, want);
     if (tpb < 4) tpb = 4;
@@ -251,7 +262,7 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     }
     if (rc != UNET_OK) return rc;
     const size_t KC_ = (size_t)d->Cout * d->Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_, 256)), dim3(256), 0, st, d->workspace, d->dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_ * p.T, 256)), dim3(256), 0, st, d->workspace, d->dw,
                        p.splits, p.T, KC_, d->accumulate);
     UNET_CHECK_LAUNCH();
     if (d->dbias != nullptr) {

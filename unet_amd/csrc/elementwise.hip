@@ -90,7 +90,7 @@ static int pick_tc(int C4) {
 static int stats_rows(long long P) {
     long long r = (P + 127) / 128;
     if (r < 1) r = 1;
-    if (r > 1024) r = 1024;
+    if (r > 512) r = 512;
     return (int)r;
 }
 
@@ -115,25 +115,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         P, C4, TC, out0, nullptr, Cp);
 }
 
-__global__ void rows_sum_kernel(const float* __restrict__ part, int rows, int Cp, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * Cp + c];
-    out[c] = (float)s;
+// Sum rows of one or two [rows][stride] planes for 32 consecutive channels per workgroup:
+// 256 threads = 32 channels (tx, coalesced 128-B row segments) x 8 row lanes (ty), fp64 accumulation,
+// one LDS hop.  Result for channel c lands in thread (tx = c % 32, ty = 0).
+__device__ __forceinline__ void rows_reduce2(const float* __restrict__ p0, const float* __restrict__ p1, int rows, int stride, int C,
+                                             double& s, double& q, int& c_out) {
+    __shared__ double sh0[256];
+    __shared__ double sh1[256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int r = ty; r < rows; r += 8) {
+            a += (double)p0[(size_t)r * stride + c];
+            if (p1 != nullptr) b += (double)p1[(size_t)r * stride + c];
+        }
+    }
+    sh0[threadIdx.x] = a;
+    sh1[threadIdx.x] = b;
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { a += sh0[j * 32 + tx]; b += sh1[j * 32 + tx]; }
+    }
+    s = a; q = b; c_out = (ty == 0 && c < C) ? c : -1;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumsq, int rows, int rstride,
-                                   double count, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                                   float* shift, float* save_mean, float* save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s += (double)psum[(size_t)r * rstride + c];
-        q += (double)psumsq[(size_t)r * rstride + c];
-    }
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int rows, int Cp, int C, float* __restrict__ out) {
+    double s, q; int c;
+    rows_reduce2(part, nullptr, rows, Cp, C, s, q, c);
+    if (c >= 0) out[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumsq, int rows,
+                                                          int rstride, double count, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                          float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                                          float* save_invstd) {
+    double s, q; int c;
+    rows_reduce2(psum, psumsq, rows, rstride, C, s, q, c);
+    if (c < 0) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -197,16 +218,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         P, C4, TC, out0, out1, Cp);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int Cp, double count, int C, float* dgamma,
-                                       float* dbeta, float* c1, float* c2, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    const float* p1 = part + (size_t)rows * Cp;
-    for (int r = 0; r < rows; ++r) {
-        s += (double)part[(size_t)r * Cp + c];
-        q += (double)p1[(size_t)r * Cp + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int Cp, double count, int C,
+                                                              float* dgamma, float* dbeta, float* c1, float* c2, int accumulate) {
+    double s, q; int c;
+    rows_reduce2(part, part + (size_t)rows * Cp, rows, Cp, C, s, q, c);
+    if (c < 0) return;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
     c1[c] = (float)(s / count);
@@ -693,7 +709,7 @@ extern "C" int unet_bn_finalize(const float* psum, const float* psumsq, int rows
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
                                 float* shift, float* save_mean, float* save_invstd, void* stream) {
     UNET_CHECK_ARG(psum && psumsq && scale && shift && rows > 0 && count > 0 && C > 0, "bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, psum, psumsq, rows, C, (double)count, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, ST, psum, psumsq, rows, C, (double)count, C, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
@@ -738,7 +754,7 @@ extern "C" int unet_bn_bwd_reduce(const float* dout, int d_cs, int d_co, const f
 extern "C" int unet_bn_bwd_finalize(const float* partial, int rows, long long count, int C, float* dgamma, float* dbeta, float* c1,
                                     float* c2, void* stream) {
     UNET_CHECK_ARG(partial && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, partial, rows, C, (double)count, C, dgamma, dbeta, c1, c2,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, ST, partial, rows, C, (double)count, C, dgamma, dbeta, c1, c2,
                        0);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
@@ -891,7 +907,7 @@ extern "C" int unet_colsum(const float* x, int x_cs, int x_co, long long P, int 
     const int rows = stats_rows(P), C4 = c4of(C), Cp = 4 * C4, TC = pick_tc(C4);
     hipLaunchKernelGGL(colsum_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, workspace, Cp);
     UNET_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, ST, workspace, rows, Cp, C, out);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, ST, workspace, rows, Cp, C, out);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
