@@ -108,7 +108,8 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    probe_layer = model.layers[11].convpath[0]      # final ResBlock conv1: 100 -> 100 @ 512x512
+    from unet_amd import ops as _ops
+    DOMINANT = 32 * 10000 + 128 * 10 + 0    # conv_igemm_kernel<32,2,2,2,2,4>: all wide 3x3 / 1x1 convs, fwd and dgrad
     log(f"model ready: {sum(p.numel() for p in model.parameters())} params, batch {args.batch}/gpu, world {world}")
     for i in range(args.warmup):
         step(x, y)
@@ -118,7 +119,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    probe_layer.cx.probe = []
+    _ops.CONV_PROBE = probe = _ops.ConvProbe(DOMINANT)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(x, y)
@@ -131,16 +132,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    probes = probe_layer.cx.probe
-    probe_layer.cx.probe = None
-    kern_ms = sum(a.elapsed_time(b) for a, b in probes) / max(1, len(probes))
+    _ops.CONV_PROBE = None
+    ps = probe.summary()
 
     if rank == 0:
         tiles = args.batch * world * args.steps
         value = tiles / dt
-        c = model.cat_c
-        kflop = 2.0 * args.batch * SIZE * SIZE * c * c * 9            # algorithmic FLOPs of the probed launch
-        achieved = kflop / (kern_ms * 1e-3) / 1e12
+        # dominant kernel over ALL its launches in the timed region: algorithmic FLOPs / summed launch durations
+        achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"      # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get("conv_igemm_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "512x512 tiles/sec fwd+bwd (4-ch->5-class U-Net)", "value": round(value, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -151,10 +154,13 @@ def main():
             "loss": round(float(loss.item()), 5),
             "step_tflops": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
             "step_frac_of_f32_peak": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3 / (PEAK_F32_TFLOPS * world), 4),
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<32,2,2,2,2,4> (3x3 100->100 @512^2, fwd)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<32,2,2,2,2,4> (fp32-MFMA implicit GEMM: every wide 3x3/1x1 "
+                                                     "conv, forward and input-gradient)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
-                         "launch_ms": round(kern_ms, 4), "launch_gflop": round(kflop / 1e9, 2)},
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                         "launches_per_step": ps["launches"] // max(1, args.steps), "avg_launch_ms": round(ps["avg_ms"], 4),
+                         "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
+                         "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)},
             "hbm_bytes_allocated": model.memory_bytes(),
         }
         if world == 1 and not args.no_cpu_baseline:

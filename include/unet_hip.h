@@ -75,6 +75,8 @@ typedef struct {
 /* number of partial rows the colsum buffers must hold for this desc */
 int unet_conv2d_colsum_rows(const unet_conv_desc* d);
 int unet_conv2d(const unet_conv_desc* d, void* stream);
+/* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) -- for profilers / bench.py */
+int unet_conv2d_variant(const unet_conv_desc* d);
 
 /* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].
  * mode 0 (FWD):   wp[tap][chunk][coutPad][16]  reduction over Cin

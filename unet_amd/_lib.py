@@ -81,6 +81,7 @@ _sig = {
     "unet_last_error": (C.c_char_p, []),
     "unet_conv2d_colsum_rows": (i, [C.POINTER(ConvDesc)]),
     "unet_conv2d": (i, [C.POINTER(ConvDesc), vp]),
+    "unet_conv2d_variant": (i, [C.POINTER(ConvDesc)]),
     "unet_pack_weights_size": (sz, [i, i, i, i]),
     "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
     "unet_conv2d_wgrad_workspace": (sz, [C.POINTER(WgradDesc)]),

@@ -468,6 +468,13 @@ extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
     return p.nparity * p.k.mtiles * wm;
 }
 
+extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
+    Plan p;
+    int rc = make_plan(d, &p);
+    if (rc != UNET_OK) return rc;
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0);
+}
+
 extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     Plan p;
     int rc = make_plan(d, &p);

@@ -96,8 +96,6 @@ class _ConvExec:
         self._ver_f = None
         self._ver_d = None
         self.ctx: Optional["Ctx"] = None   # set by HipDynamicUnet once the tree is built
-        # bench.py: when a list, every forward launch is bracketed by two events on the launch stream
-        self.probe: Optional[list] = None
 
     def packed(self, mode: int) -> torch.Tensor:
         w = self.conv.weight
@@ -117,14 +115,7 @@ class _ConvExec:
 
     def fwd(self, x: TS, y: TS, relu=False, res: Optional[TS] = None):
         b = self.conv.bias
-        wp = self.packed(0)
-        if self.probe is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        ops.conv2d(x, wp, y, self.ks, self.stride, bias=None if b is None else b.data, res=res, relu=relu)
-        if self.probe is not None:
-            e1.record()
-            self.probe.append((e0, e1))
+        ops.conv2d(x, self.packed(0), y, self.ks, self.stride, bias=None if b is None else b.data, res=res, relu=relu)
 
     def bwd_w(self, ctx: Ctx, x: TS, dy: TS):
         """weight (+bias) gradient into the .grad views of the flat gradient buffer"""

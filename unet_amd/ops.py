@@ -109,16 +109,46 @@ def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, 
     return d
 
 
+class ConvProbe:
+    """bench.py: brackets every conv launch of one kernel instantiation with events on the launch stream and
+    sums the ALGORITHMIC FLOPs (2 * pixels * Cin * Cout * k*k, no padding) of those launches."""
+
+    def __init__(self, variant: int):
+        self.variant = variant
+        self.events = []
+        self.flops = 0.0
+
+    def summary(self):
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        return {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms)), "flops": self.flops}
+
+
+CONV_PROBE: Optional[ConvProbe] = None
+
+
+def _launch_conv(d: ConvDesc, what: str, alg_flops: float):
+    pr = CONV_PROBE
+    if pr is not None and lib.unet_conv2d_variant(C.byref(d)) == pr.variant:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.unet_conv2d(C.byref(d), _stream()), what)
+        e1.record()
+        pr.events.append((e0, e1))
+        pr.flops += alg_flops
+        return
+    check(lib.unet_conv2d(C.byref(d), _stream()), what)
+
+
 def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, res=None, mask=None, relu=False,
            colsum=None, colsumsq=None):
     d = _conv_desc(x, wp, y, ks, stride, L.CONV_FWD, bias, res, mask, relu, colsum, colsumsq)
-    check(lib.unet_conv2d(C.byref(d), _stream()), "conv2d")
+    _launch_conv(d, "conv2d", 2.0 * y.P * x.C * y.C * ks * ks)
 
 
 def conv2d_dgrad(dy: TS, wp_dgrad: torch.Tensor, dx: TS, ks: int, stride: int = 1, res=None, mask=None, colsum=None):
     """dx = conv^T(dy); optional residual add, ReLU-backward mask, column sums of the result."""
     d = _conv_desc(dy, wp_dgrad, dx, ks, stride, L.CONV_DGRAD, None, res, mask, False, colsum, None)
-    check(lib.unet_conv2d(C.byref(d), _stream()), "conv2d_dgrad")
+    _launch_conv(d, "conv2d_dgrad", 2.0 * dy.P * dy.C * dx.C * ks * ks)
 
 
 def conv_colsum_rows(x: TS, wp, y: TS, ks, stride, kind) -> int:
