@@ -1,0 +1,64 @@
+"""End-to-end tile workflow on the GPU: train_func (25 positional arguments) -> export -> save_predictions with and
+without overlap merge, on synthetic GeoTIFF tiles written by unet_amd.tiffio."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(root, n_train=6, n_val=2, size=64, n_cls=3, seed=0):
+    from unet_amd.tiffio import write_tiff
+    g = np.random.default_rng(seed)
+    for split, n in (("trai", n_train), ("vali", n_val)):
+        (root / split / "img_tiles").mkdir(parents=True)
+        (root / split / "mask_tiles").mkdir(parents=True)
+        for i in range(n):
+            mask = np.zeros((size, size), dtype=np.uint8)
+            mask[:, size // 3:] = 1
+            mask[size // 2:, 2 * size // 3:] = 2
+            img = (mask[None].astype(np.float32) * 80 + g.normal(40, 10, (4, size, size))).clip(0, 255).astype(np.uint8)
+            gt = (500000.0 + i * size * 0.2, 0.2, 0.0, 5800000.0, 0.0, -0.2)
+            write_tiff(root / split / "img_tiles" / f"t{i}.tif", img, geotransform=gt)
+            write_tiff(root / split / "mask_tiles" / f"t{i}.tif", mask, geotransform=gt)
+
+
+def test_train_export_predict_merge(tmp_path):
+    import train as T
+    import predict as P
+    from unet_amd import xresnet18
+    from unet_amd.tiffio import read_tiff, write_tiff
+    data = tmp_path / "data"
+    _make_dataset(data)
+    codes = ["a", "b", "c"]
+    learn = T.train_func(data, None, tmp_path / "models", "run1", 2, False, False, "weighted", xresnet18, 3, 2e-3, 10, None, None,
+                         "dice_multi", False, ["vali"], codes, False, None, True, None, 1, "", False)
+    hist = (tmp_path / "models" / "run1" / "run1_history.csv").read_text().strip().splitlines()
+    assert hist[0] == "epoch,train_loss,valid_loss,dice_multi,time" and len(hist) == 4
+    first, last = float(hist[1].split(",")[2]), float(hist[-1].split(",")[2])
+    assert np.isfinite(last) and last < first * 1.5
+    pkl = tmp_path / "models" / "run1" / "run1.pkl"
+    assert pkl.exists() and (tmp_path / "models" / "run1" / "run1_model_summary.txt").exists()
+
+    # prediction tiles with 50 % horizontal overlap
+    pred = tmp_path / "pred" / "tiles"
+    pred.mkdir(parents=True)
+    g = np.random.default_rng(1)
+    for i in range(3):
+        img = g.integers(0, 255, (4, 64, 64)).astype(np.uint8)
+        write_tiff(pred / f"p{i}.tif", img, geotransform=(1000.0 + i * 32 * 0.5, 0.5, 0.0, 2000.0, 0.0, -0.5))
+    out_dir = P.save_predictions(pkl, pred, False, merge=False, validation_vision=False)
+    m0, meta = read_tiff(out_dir / "p0.tif")
+    assert m0.shape == (64, 64) and m0.dtype == np.uint8 and meta["geotransform"][0] == 1000.0
+    merged_file = P.save_predictions(pkl, pred, False, merge=True, AOI="aoi", year="2024", validation_vision=False)
+    mm, meta = read_tiff(merged_file)
+    assert mm.shape == (64, 128) and meta["geotransform"][:2] == (1000.0, 0.5)
+    # the merged mask equals sum-probs / count / argmax computed on the host from per-tile probabilities
+    lr = T.load_learner(pkl)
+    acc = np.zeros((3, 64, 128)); cnt = np.zeros((64, 128))
+    for i in range(3):
+        _, _, pr = lr.predict(pred / f"p{i}.tif")
+        acc[:, :, i * 32:i * 32 + 64] += pr.numpy(); cnt[:, i * 32:i * 32 + 64] += 1
+    assert np.array_equal((acc / cnt).argmax(0).astype(np.uint8), mm)
+    # non-overlapped columns of the merge equal the per-tile masks
+    assert np.array_equal(mm[:, :32], m0[:, :32])

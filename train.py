@@ -1,0 +1,133 @@
+"""Training entry points of the tile workflow on the MI355X hot path.
+
+Mirrors the reference's ``train.py`` surface: ``unet_learner_MS`` (``train.py:98-160``), ``train_unet`` (``:163-283``) and
+``train_func`` with its 25 positional arguments (``:287-292``).  Data layout: ``<data_path>/{trai,vali}/{img_tiles,mask_tiles}``
+with ``.tif`` (uncompressed GeoTIFF) or ``.npy`` tiles.  Out of scope here: plots, LR finder,
+regression mode, albumentations pipelines (only the built-in flips), run-parameter JSON beyond a compact dump.
+"""
+from __future__ import annotations
+
+import json
+import shutil
+import warnings
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from unet_amd import xresnet34  # noqa: F401  (architecture tokens, like `from fastai.vision.all import xresnet34`)
+from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, Learner, SaveModelCallback,
+                              TileDataset, load_learner, open_tile)
+from unet_amd.model import HipDynamicUnet
+
+
+def _arch_name(arch) -> str:
+    return arch if isinstance(arch, str) else arch.__name__
+
+
+def _tiles(folder: Path):
+    return sorted([p for p in folder.iterdir() if p.suffix.lower() in (".tif", ".tiff", ".npy")])
+
+
+def get_datatype(data_path: Path) -> str:
+    """utils.py:72-89: max < 257 in the first training tile -> 'int8' else 'int16'."""
+    first = _tiles(Path(data_path) / "trai" / "img_tiles")[0]
+    return "int8" if open_tile(first).max() < 257 else "int16"
+
+
+def get_class_weights(ds: TileDataset, n_cls: int, max_tiles: int = 1200) -> np.ndarray:
+    """utils.py:106-117: total / count per class over (up to 1200) training masks."""
+    cnt = np.zeros(n_cls, dtype=np.float64)
+    for i in range(min(len(ds), max_tiles)):
+        cnt += np.bincount(ds[i][1].numpy().ravel(), minlength=n_cls)[:n_cls]
+    return cnt.sum() / np.maximum(cnt, 1)
+
+
+def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda") -> DataLoaders:
+    data_path = Path(data_path)
+    dtype = dtype or get_datatype(data_path)
+    sets = {}
+    for split in ("trai", "vali"):
+        imgs = _tiles(data_path / split / "img_tiles")
+        masks = [data_path / split / "mask_tiles" / p.name for p in imgs]
+        sets[split] = TileDataset(imgs, masks, dtype)
+    return DataLoaders(sets["trai"], sets["vali"], bs, device=device, vocab=list(codes))
+
+
+def unet_learner_MS(dls, arch, pretrained=True, loss_func=None, norm_type=None, opt_func=Adam, lr=1e-3, splitter=None, cbs=None,
+                    metrics=None, path=None, model_dir="models", wd=None, wd_bn_bias=False, train_bn=True,
+                    moms=(0.95, 0.85, 0.95), regression=False, self_attention=False) -> Learner:
+    if regression:
+        raise NotImplementedError("regression mode is out of scope of the MI355X hot path (SURVEY.md section 2)")
+    x0, _ = dls.train_ds[0]
+    n_in, size = x0.shape[0], tuple(x0.shape[-2:])
+    n_out = len(dls.vocab)
+    model = HipDynamicUnet(_arch_name(arch), n_in, n_out, size, self_attention=self_attention, device=dls.device)
+    return Learner(dls=dls, model=model, loss_func=loss_func, opt_func=opt_func, lr=lr, splitter=splitter, cbs=cbs, metrics=metrics,
+                   path=path, model_dir=model_dir, wd=wd, wd_bn_bias=wd_bn_bias, train_bn=train_bn, moms=moms)
+
+
+def train_unet(class_weights, dls, architecture, epochs, path, lr, encoder_factor, lr_finder=None, regression=False,
+               loss_func=None, monitor=None, existing_model=None, self_attention=False, export_model_summary=False) -> Learner:
+    weights = torch.tensor(np.asarray(class_weights, dtype=np.float32), device=dls.device)
+    if loss_func is None:
+        loss_func = CrossEntropyLossFlat(axis=1, weight=weights)
+    metrics = [DiceMulti()]
+    monitor = monitor or "dice_multi"
+    comp = np.less if monitor in ("train_loss", "valid_loss") else np.greater
+    if monitor not in ("train_loss", "valid_loss", "dice_multi"):
+        warnings.warn("Monitor not recognised. Assuming maximization.")
+    path = Path(path)
+    cbs = [SaveModelCallback(monitor=monitor, comp=comp, fname="best-model"), CSVLogger()]
+    loss_func.func.weight = weights                     # train.py:211 (also overrides a user loss: quirk Q5)
+    if existing_model is None:
+        learn = unet_learner_MS(dls, architecture, loss_func=loss_func, opt_func=Adam, metrics=metrics, cbs=cbs,
+                                regression=regression, self_attention=self_attention, path=path.parent)
+    else:
+        learn = load_learner(existing_model, device=dls.device)
+        learn.dls, learn.loss_func, learn.opt_func, learn.path = dls, loss_func, Adam, path.parent
+        learn.cbs = cbs
+    if export_model_summary:
+        Path(str(path).rsplit(".", 1)[0] + "_model_summary.txt").write_text(
+            f"Class_weights: {class_weights}\n{learn.summary()}\n{learn.model}\n")
+    if lr_finder is not None:
+        warnings.warn("lr_finder is not available on this path; using LEARNING_RATE as given")
+    learn.unfreeze()
+    learn.fit_one_cycle(epochs, lr_max=slice(lr / encoder_factor, lr))
+    hist = Path(str(path).rsplit(".", 1)[0] + "_history.csv")
+    shutil.move(str(learn.path / learn.csv_logger.fname), str(hist))
+    learn.remove_cb(CSVLogger)
+    return learn
+
+
+def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, visualize_data_example, enable_regression,
+               CLASS_WEIGHTS, ARCHITECTURE, EPOCHS, LEARNING_RATE, ENCODER_FACTOR, LR_FINDER, loss_func, monitor, self_attention,
+               VALID_SCENES, CODES, transforms, split_idx, export_model_summary, aug_pipe, n_transform_imgs, info, class_zero):
+    data_path = Path(data_path)
+    dtype = get_datatype(data_path)
+    new_path = Path(model_Path) / description
+    new_path.mkdir(parents=True, exist_ok=True)
+    model_path = new_path / f"{description}.pkl"
+    (new_path / f"{description}.json").write_text(json.dumps({
+        "data_path": str(data_path), "BATCH_SIZE": BATCH_SIZE, "EPOCHS": EPOCHS, "LEARNING_RATE": LEARNING_RATE,
+        "ENCODER_FACTOR": ENCODER_FACTOR, "CLASS_WEIGHTS": CLASS_WEIGHTS if isinstance(CLASS_WEIGHTS, str) else list(CLASS_WEIGHTS),
+        "ARCHITECTURE": _arch_name(ARCHITECTURE), "CODES": list(CODES), "self_attention": self_attention, "monitor": monitor,
+        "VALID_SCENES": VALID_SCENES, "info": info, "class_zero": class_zero, "dtype": dtype}, indent=1, default=str))
+    if transforms:
+        warnings.warn("augmentation pipelines (albumentations) are not part of the MI355X hot path; training without them")
+    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype)
+    if enable_regression:
+        raise NotImplementedError("regression mode is out of scope of the MI355X hot path")
+    if isinstance(CLASS_WEIGHTS, str):
+        if CLASS_WEIGHTS == "even":
+            CLASS_WEIGHTS = np.ones(len(CODES)) / len(CODES)
+        elif CLASS_WEIGHTS == "weighted":
+            CLASS_WEIGHTS = get_class_weights(dls.train_ds, len(CODES))
+    print(f"Train files: {len(dls.train_ds)}, Test files: {len(dls.valid_ds)}")
+    print(f"Class weights: {CLASS_WEIGHTS}")
+    learn = train_unet(class_weights=CLASS_WEIGHTS, dls=dls, architecture=ARCHITECTURE, epochs=EPOCHS, path=model_path,
+                       lr=LEARNING_RATE, encoder_factor=ENCODER_FACTOR, lr_finder=LR_FINDER, regression=enable_regression,
+                       loss_func=loss_func, monitor=monitor, existing_model=existing_model, self_attention=self_attention,
+                       export_model_summary=export_model_summary)
+    learn.export(model_path)
+    return learn

@@ -1,0 +1,479 @@
+"""The slice of the fastai ``Learner`` surface that the reference's scripts touch,
+driving the MI355X hot path.  fastai itself is not required.
+
+Kept: ctor kwargs ``dls, model, loss_func, opt_func, lr, splitter, cbs, metrics, path, model_dir, wd, wd_bn_bias,
+train_bn, moms`` (``train.py:148-154``); ``unfreeze`` (``:246``); ``fit_one_cycle(n, lr_max=slice)`` (``:247``);
+``recorder.plot_loss`` (``:253``); ``path`` / ``csv_logger.fname`` (``:257``); ``remove_cb`` / ``add_cb`` / ``dls=`` /
+``loss_func=`` / ``opt_func=`` (``:226-229,258``); ``export`` (``:373``); ``load_learner`` (``:225``, ``predict.py:161``);
+``predict(item)`` -> 3-tuple whose [2] is per-class probabilities [C,H,W] (``predict.py:193-203``);
+``get_preds``; ``summary``; callbacks ``SaveModelCallback(monitor, comp, fname)`` and ``CSVLogger`` (``train.py:209``);
+``CrossEntropyLossFlat(axis=1, weight)`` with assignable ``.func.weight`` (``train.py:195,211``); ``DiceMulti``.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import time
+from pathlib import Path
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import HipDynamicUnet
+from .optimizer import FlatAdam, xresnet_split
+from .trainer import TrainStep
+
+
+# --------------------------------------------------------------------------- schedules (callback/schedule.py)
+
+def even_mults(start: float, stop: float, n: int) -> np.ndarray:
+    if n == 1:
+        return np.array([stop])
+    step = (stop / start) ** (1 / (n - 1))
+    return np.array([start * step ** i for i in range(n)])
+
+
+def _cos(a, b, pos):
+    return a + (1 + math.cos(math.pi * (1 - pos))) * (b - a) / 2
+
+
+def combined_cos(pct, start, middle, end):
+    def f(pos):
+        if pos >= 1.0:
+            return _cos(middle, end, 1.0)
+        if pos >= pct:
+            return _cos(middle, end, (pos - pct) / (1 - pct))
+        return _cos(start, middle, pos / pct)
+    return f
+
+
+# --------------------------------------------------------------------------- loss / metric
+
+class _Func:
+    """stand-in for ``loss_func.func`` (an nn.CrossEntropyLoss in fastai): only ``.weight`` is used by the reference"""
+    def __init__(self, weight=None):
+        self.weight = weight
+
+
+class CrossEntropyLossFlat:
+    def __init__(self, axis: int = 1, weight: Optional[torch.Tensor] = None):
+        assert axis == 1
+        self.axis = axis
+        self.func = _Func(weight)
+
+    def _w(self, device):
+        w = self.func.weight
+        return None if w is None else torch.as_tensor(w, dtype=torch.float32, device=device).contiguous()
+
+    def __call__(self, logits: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        """Generic path (torch autograd): per-pixel weighted CE, mean = sum w[y] nll / sum w[y]."""
+        return torch.nn.functional.cross_entropy(logits, targ.long(), weight=self._w(logits.device))
+
+    def activation(self, x):
+        return torch.softmax(x, dim=self.axis)
+
+    def decodes(self, x):
+        return x.argmax(dim=self.axis)
+
+
+class DiceMulti:
+    """fastai ``DiceMulti(axis=1)``: inter/union per class accumulated over the validation set; nanmean of 2I/U."""
+    name = "dice_multi"
+
+    def __init__(self, axis=1):
+        self.axis = axis
+        self.reset()
+
+    def reset(self):
+        self.inter = None
+        self.union = None
+
+    def accumulate_argmax(self, pred: torch.Tensor, targ: torch.Tensor, n_cls: int):
+        p, t = pred.reshape(-1).long(), targ.reshape(-1).long()
+        cp = torch.bincount(p, minlength=n_cls)[:n_cls]
+        ct = torch.bincount(t.clamp(0, n_cls - 1), minlength=n_cls)[:n_cls]
+        inter = torch.bincount(p[p == t], minlength=n_cls)[:n_cls]
+        self.inter = inter.double() if self.inter is None else self.inter + inter.double()
+        self.union = (cp + ct).double() if self.union is None else self.union + (cp + ct).double()
+
+    def all_reduce(self):
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.inter is not None:
+            dist.all_reduce(self.inter); dist.all_reduce(self.union)
+
+    @property
+    def value(self) -> float:
+        i, u = self.inter.cpu().numpy(), self.union.cpu().numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            s = np.where(u > 0, 2.0 * i / u, np.nan)
+        return float(np.nanmean(s))
+
+
+# --------------------------------------------------------------------------- data
+
+def open_tile(path) -> np.ndarray:
+    """[C,H,W] integer/float array from .npy or (uncompressed) .tif (data.py:18-28 `open_npy` reads rasters as int32)."""
+    path = Path(path)
+    if path.suffix == ".npy":
+        a = np.load(path)
+    else:
+        from .tiffio import read_tiff
+        a, _ = read_tiff(path)
+    return a[None] if a.ndim == 2 else a
+
+
+def scale_input(a: np.ndarray, dtype: str = "int8") -> np.ndarray:
+    """utils.py:248-249,288-289 + IntToFloatTensor: int16 data is divided by 255 twice, int8 once."""
+    x = a.astype(np.int32).astype(np.float32)     # data.py:24: cast through int32 (truncates float rasters, quirk Q6)
+    if dtype == "int16":
+        x = x / 255.0
+    return x / 255.0
+
+
+class TileDataset:
+    def __init__(self, imgs: Sequence, masks: Optional[Sequence] = None, dtype: str = "int8"):
+        self.imgs, self.masks, self.dtype = list(imgs), None if masks is None else list(masks), dtype
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def __getitem__(self, i):
+        im = self.imgs[i]
+        x = scale_input(open_tile(im) if not isinstance(im, np.ndarray) else im, self.dtype)
+        if self.masks is None:
+            return torch.from_numpy(x), None
+        mk = self.masks[i]
+        y = open_tile(mk)[0] if not isinstance(mk, np.ndarray) else mk
+        return torch.from_numpy(x), torch.from_numpy(np.asarray(y).astype(np.int64))
+
+
+class DataLoader:
+    def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0):
+        self.ds, self.bs, self.shuffle, self.device, self.drop_last = ds, bs, shuffle, device, drop_last
+        self._g = np.random.default_rng(seed)
+
+    def __len__(self):
+        n = len(self.ds)
+        return n // self.bs if self.drop_last else -(-n // self.bs)
+
+    def __iter__(self):
+        idx = np.arange(len(self.ds))
+        if self.shuffle:
+            self._g.shuffle(idx)
+        for b in range(len(self)):
+            items = [self.ds[int(i)] for i in idx[b * self.bs:(b + 1) * self.bs]]
+            xb = torch.stack([x for x, _ in items]).to(self.device)
+            yb = None if items[0][1] is None else torch.stack([y for _, y in items]).to(self.device)
+            yield xb, yb
+
+
+class DataLoaders:
+    """``dls.train`` / ``dls.valid`` / ``dls.vocab`` / ``dls.device`` / ``dls.train_ds`` as the reference uses them."""
+
+    def __init__(self, train: TileDataset, valid: Optional[TileDataset], bs: int, device="cuda", vocab=None, seed=0):
+        self.device = torch.device(device)
+        self.train_ds, self.valid_ds, self.bs, self.vocab = train, valid, bs, vocab
+        self.train = DataLoader(train, bs, True, self.device, drop_last=len(train) >= bs, seed=seed)
+        self.valid = None if valid is None else DataLoader(valid, bs, False, self.device)
+
+    def test_dl(self, items, dtype=None):
+        return DataLoader(TileDataset(items, None, dtype or self.train_ds.dtype), self.bs, False, self.device)
+
+
+# --------------------------------------------------------------------------- callbacks
+
+class Callback:
+    def before_fit(self, learn): ...
+    def after_epoch(self, learn): ...
+    def after_fit(self, learn): ...
+
+
+class CSVLogger(Callback):
+    def __init__(self, fname="history.csv", append=False):
+        self.fname, self.append = Path(fname), append
+
+    def before_fit(self, learn):
+        self.path = learn.path / self.fname
+        self.path.parent.mkdir(parents=True, exist_ok=True)
+        self.file = open(self.path, "a" if self.append else "w", newline="")
+        self.writer = csv.writer(self.file)
+        self.writer.writerow(learn.recorder.metric_names)
+
+    def after_epoch(self, learn):
+        self.writer.writerow(learn.recorder.log_row)
+        self.file.flush()
+
+    def after_fit(self, learn):
+        self.file.close()
+
+
+class SaveModelCallback(Callback):
+    def __init__(self, monitor="valid_loss", comp=None, fname="best-model"):
+        self.monitor, self.fname = monitor, fname
+        self.comp = comp if comp is not None else (np.less if "loss" in monitor else np.greater)
+        self.best = None
+
+    def before_fit(self, learn):
+        self.best = None
+
+    def after_epoch(self, learn):
+        val = learn.recorder.last[self.monitor]
+        if self.best is None or self.comp(val, self.best):
+            self.best = val
+            learn.save(self.fname)
+            print(f"Better model found at epoch {learn.epoch} with {self.monitor} value: {val}.")
+
+    def after_fit(self, learn):
+        if self.best is not None:
+            learn.load(self.fname)
+
+
+class Recorder:
+    def __init__(self, metric_names):
+        self.metric_names = ["epoch", "train_loss", "valid_loss"] + list(metric_names) + ["time"]
+        self.losses: List[float] = []       # smoothed training loss per batch (AvgSmoothLoss beta=0.98)
+        self.lrs: List[float] = []
+        self.values: List[list] = []
+        self.log_row: list = []
+        self.last: dict = {}
+        self._val, self._cnt = 0.0, 0
+
+    def add_batch(self, loss: float, lr: float):
+        self._cnt += 1
+        self._val = 0.98 * self._val + 0.02 * loss          # torch.lerp(loss, val, beta)
+        self.losses.append(self._val / (1 - 0.98 ** self._cnt))
+        self.lrs.append(lr)
+
+    def plot_loss(self, skip_start=5, with_valid=True):
+        try:
+            import matplotlib.pyplot as plt
+        except Exception:
+            return None
+        plt.plot(list(range(skip_start, len(self.losses))), self.losses[skip_start:], label="train")
+        plt.legend()
+        return plt.gca()
+
+
+def Adam(model, lr, mom=0.9, sqr_mom=0.99, eps=1e-5, wd=0.01, wd_bn_bias=False, splitter=xresnet_split):
+    """opt_func: fastai Adam over the flat buffer (train.py:218 passes ``opt_func=Adam``)."""
+    return FlatAdam(model, lr, mom, sqr_mom, eps, wd, wd_bn_bias, splitter)
+
+
+# --------------------------------------------------------------------------- Learner
+
+class Learner:
+    def __init__(self, dls: DataLoaders, model: HipDynamicUnet, loss_func=None, opt_func: Callable = Adam, lr=1e-3, splitter=None,
+                 cbs=None, metrics=None, path=None, model_dir="models", wd=None, wd_bn_bias=False, train_bn=True,
+                 moms=(0.95, 0.85, 0.95)):
+        self.dls, self.model = dls, model
+        self.loss_func = loss_func if loss_func is not None else CrossEntropyLossFlat(axis=1)
+        self.opt_func, self.lr, self.splitter = opt_func, lr, splitter or xresnet_split
+        self.cbs: List[Callback] = list(cbs or [])
+        self.metrics = list(metrics or [])
+        self.path = Path(path) if path is not None else Path(".")
+        self.model_dir, self.wd, self.wd_bn_bias, self.train_bn, self.moms = model_dir, wd, wd_bn_bias, train_bn, moms
+        self.opt: Optional[FlatAdam] = None
+        self.recorder = Recorder([getattr(m, "name", type(m).__name__.lower()) for m in self.metrics])
+        self.epoch = 0
+        self.world = 1
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                self.world = dist.get_world_size()
+        except Exception:
+            pass
+
+    # -- callback plumbing the reference uses
+    @property
+    def csv_logger(self):
+        return next(c for c in self.cbs if isinstance(c, CSVLogger))
+
+    def add_cb(self, cb):
+        self.cbs.append(cb)
+        return self
+
+    def remove_cb(self, cb):
+        self.cbs = [c for c in self.cbs if not (c is cb or (isinstance(cb, type) and isinstance(c, cb)))]
+        return self
+
+    def unfreeze(self):
+        return self          # every parameter group trains (train_bn=True, nothing is frozen on this path)
+
+    def create_opt(self):
+        kw = {} if self.wd is None else {"wd": self.wd}
+        self.opt = self.opt_func(self.model, self.lr, wd_bn_bias=self.wd_bn_bias, splitter=self.splitter, **kw)
+
+    def _weights(self):
+        return self.loss_func._w(self.dls.device) if isinstance(self.loss_func, CrossEntropyLossFlat) else None
+
+    # -- training
+    def fit_one_cycle(self, n_epoch, lr_max=None, div=25.0, div_final=1e5, pct_start=0.25, wd=None, moms=None):
+        if self.opt is None:
+            self.create_opt()
+        if wd is not None:
+            self.opt.wd = wd
+        k = len(self.opt.groups)
+        if lr_max is None:
+            lr_max = self.lr
+        if isinstance(lr_max, slice):
+            lrs = even_mults(lr_max.start, lr_max.stop, k) if lr_max.start else np.array([lr_max.stop / 10] * (k - 1) + [lr_max.stop])
+        else:
+            lrs = np.array([float(lr_max)] * k)
+        lr_f = combined_cos(pct_start, lrs / div, lrs, lrs / div_final)
+        mom_f = combined_cos(pct_start, *(self.moms if moms is None else moms))
+        self._fit(n_epoch, lr_f, mom_f)
+
+    def fit(self, n_epoch, lr=None):
+        if self.opt is None:
+            self.create_opt()
+        lrs = np.array([self.lr if lr is None else lr] * len(self.opt.groups), dtype=np.float64)
+        self._fit(n_epoch, lambda p: lrs, lambda p: self.opt.mom)
+
+    def _fit(self, n_epoch, lr_f, mom_f):
+        model, opt = self.model, self.opt
+        fused = isinstance(self.loss_func, CrossEntropyLossFlat)
+        step = TrainStep(model, opt, self._weights(), self.world) if fused else None
+        n_iter = len(self.dls.train)
+        total = max(1, n_epoch * n_iter)
+        for cb in self.cbs:
+            cb.before_fit(self)
+        it = 0
+        for self.epoch in range(n_epoch):
+            t0 = time.time()
+            model.train()
+            pending = []
+            for xb, yb in self.dls.train:
+                pct = it / total
+                opt.set_lr(lr_f(pct)); opt.mom = float(mom_f(pct))
+                if fused:
+                    step.weights = self._weights()
+                    loss = step(xb, yb)
+                else:
+                    loss = self.loss_func(model(xb), yb)
+                    model.flat_grad.zero_()
+                    loss.backward()
+                    opt.step()
+                pending.append((loss.detach().reshape(1).clone(), opt.lrs[-1]))
+                it += 1
+            for l, lr in pending:                       # one host sync per epoch, not per batch
+                self.recorder.add_batch(float(l.item()), lr)
+            train_loss = self.recorder.losses[-1] if self.recorder.losses else float("nan")
+            vals = self.validate()
+            el = int(time.time() - t0)
+            row = [self.epoch, train_loss] + vals + [f"{el // 60:02d}:{el % 60:02d}"]
+            self.recorder.values.append(row[1:-1])
+            self.recorder.log_row = row
+            self.recorder.last = dict(zip(self.recorder.metric_names[1:-1], row[1:-1]))
+            print(dict(zip(self.recorder.metric_names, row)))
+            for cb in self.cbs:
+                cb.after_epoch(self)
+        for cb in self.cbs:
+            cb.after_fit(self)
+
+    @torch.no_grad()
+    def validate(self, dl=None) -> list:
+        dl = dl or self.dls.valid
+        if dl is None:
+            return [float("nan")] + [float("nan")] * len(self.metrics)
+        model = self.model
+        model.eval()
+        for m in self.metrics:
+            m.reset()
+        num = den = 0.0
+        ctx = model.ctx
+        w = self._weights()
+        for xb, yb in dl:
+            z = model._hip_forward(xb.to(model._device, torch.float32), False)
+            loss, denom = ctx.vec(self, "vloss", 1), ctx.vec(self, "vden", 1)
+            ops.ce_fwd(z, yb.contiguous(), w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
+            amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=model._device)
+            ops.softmax_argmax(z, None, amax)
+            d = float(denom.item())
+            num += float(loss.item()) * d
+            den += d
+            for m in self.metrics:
+                m.accumulate_argmax(amax, yb, z.C)
+        for m in self.metrics:
+            if hasattr(m, "all_reduce"):
+                m.all_reduce()
+        return [num / max(den, 1e-30)] + [m.value for m in self.metrics]
+
+    # -- inference (predict.py:193)
+    @torch.no_grad()
+    def get_preds(self, dl=None, with_input=False, with_decoded=False):
+        dl = dl or self.dls.valid
+        self.model.eval()
+        xs, ps, ys, ds = [], [], [], []
+        for xb, yb in dl:
+            probs, amax = self.model.predict_probs(xb)
+            ps.append(probs.cpu()); ds.append(amax.cpu())
+            if with_input:
+                xs.append(xb.cpu())
+            if yb is not None:
+                ys.append(yb.cpu())
+        res = (torch.cat(ps), torch.cat(ys) if ys else None)
+        if with_decoded:
+            res = res + (torch.cat(ds),)
+        if with_input:
+            res = (torch.cat(xs),) + res
+        return res
+
+    def predict(self, item, rm_type_tfms=None, with_input=False):
+        """(decoded mask, argmax [H,W], per-class probabilities [C,H,W]) for one tile (path or [C,H,W] array)."""
+        dl = self.dls.test_dl([item])
+        _, preds, _, dec = self.get_preds(dl=dl, with_input=True, with_decoded=True)
+        res = dec[0], dec[0], preds[0]
+        return res
+
+    # -- persistence
+    def _model_path(self, name):
+        p = self.path / self.model_dir
+        p.mkdir(parents=True, exist_ok=True)
+        return p / f"{name}.pth"
+
+    def save(self, name, with_opt=False):
+        sd = {"model": {k: v.cpu() for k, v in self.model.state_dict().items()}}
+        if with_opt and self.opt is not None:
+            sd["opt"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.opt.state_dict().items()}
+        torch.save(sd, self._model_path(name))
+
+    def load(self, name, with_opt=False):
+        sd = torch.load(self._model_path(name), map_location="cpu")
+        self.model.load_state_dict(sd["model"])
+        if with_opt and "opt" in sd and self.opt is not None:
+            self.opt.load_state_dict({k: (v.to(self.model._device) if torch.is_tensor(v) else v) for k, v in sd["opt"].items()})
+        return self
+
+    def export(self, fname="export.pkl"):
+        """state dict + the constructor arguments (fastai pickles the whole Learner; that pickle needs fastai to load)."""
+        m = self.model
+        w = self.loss_func.func.weight if isinstance(self.loss_func, CrossEntropyLossFlat) else None
+        meta = {"arch": m.arch, "n_in": m.n_in, "n_out": m.n_out, "img_size": list(m.img_size), "vocab": self.dls.vocab,
+                "dtype": self.dls.train_ds.dtype if self.dls is not None else "int8",
+                "class_weights": None if w is None else [float(v) for v in torch.as_tensor(w).cpu()]}
+        p = Path(fname)
+        p = p if p.is_absolute() else self.path / p
+        p.parent.mkdir(parents=True, exist_ok=True)
+        torch.save({"meta": meta, "model": {k: v.cpu() for k, v in m.state_dict().items()}}, p)
+
+    def summary(self) -> str:
+        m = self.model
+        n = sum(p.numel() for p in m.parameters())
+        lines = [f"HipDynamicUnet({m.arch}, n_in={m.n_in}, n_out={m.n_out}, img_size={m.img_size})", f"Total params: {n:,}",
+                 f"Parameter groups: {[sum(p.numel() for p in g) for g in self.splitter(m)]}",
+                 f"Loss: {type(self.loss_func).__name__}  Optimizer: fastai Adam (flat, HIP)"]
+        return "\n".join(lines)
+
+
+def load_learner(fname, device="cuda") -> Learner:
+    d = torch.load(fname, map_location="cpu")
+    meta = d["meta"]
+    model = HipDynamicUnet(meta["arch"], meta["n_in"], meta["n_out"], tuple(meta["img_size"]), device=device)
+    model.load_state_dict(d["model"])
+    empty = TileDataset([], None, meta.get("dtype", "int8"))
+    dls = DataLoaders(empty, None, 1, device=device, vocab=meta.get("vocab"))
+    w = meta.get("class_weights")
+    loss = CrossEntropyLossFlat(axis=1, weight=None if w is None else torch.tensor(w))
+    return Learner(dls, model, loss_func=loss, metrics=[DiceMulti()])

@@ -1,0 +1,163 @@
+"""Minimal GeoTIFF reader / writer (no GDAL, no rasterio, no tifffile: none of them is installed here).
+
+Covers what the tile workflow of the reference needs (``data.py:18-28`` reads tiles with rasterio, ``predict.py:19-52``
+writes them with GDAL): baseline TIFF, little/big endian, uncompressed, strips or tiles, chunky or planar, 8/16/32-bit
+unsigned / signed / float samples, plus the GeoTIFF georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922,
+GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams 34737, GDAL_NODATA 42113) which are passed through verbatim.
+Compressed files raise loudly.
+"""
+from __future__ import annotations
+
+import struct
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 6: ("b", 1), 7: ("B", 1), 8: ("h", 2), 9: ("i", 4),
+          10: ("ii", 8), 11: ("f", 4), 12: ("d", 8), 16: ("Q", 8)}
+GEO_TAGS = (33550, 33922, 34735, 34736, 34737, 42113)
+
+
+def _dtype(bits: int, fmt: int, bo: str) -> np.dtype:
+    kind = {1: "u", 2: "i", 3: "f"}.get(fmt, "u")
+    return np.dtype(f"{bo}{kind}{bits // 8}")
+
+
+def read_tiff(path) -> Tuple[np.ndarray, Dict]:
+    """Returns (array [C,H,W] (or [H,W] for one band), meta) with meta['geotransform'] = (ulx, xres, 0, uly, 0, -yres)
+    when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags."""
+    b = Path(path).read_bytes()
+    bo = {b"II": "<", b"MM": ">"}[b[:2]]
+    magic = struct.unpack(bo + "H", b[2:4])[0]
+    if magic != 42:
+        raise NotImplementedError(f"{path}: BigTIFF / unknown magic {magic}")
+    off = struct.unpack(bo + "I", b[4:8])[0]
+    n = struct.unpack(bo + "H", b[off:off + 2])[0]
+    tags: Dict[int, tuple] = {}
+    for i in range(n):
+        e = b[off + 2 + 12 * i: off + 14 + 12 * i]
+        tag, typ, cnt = struct.unpack(bo + "HHI", e[:8])
+        fmt, sz = _TYPES[typ]
+        total = sz * cnt
+        data = e[8:8 + total] if total <= 4 else b[struct.unpack(bo + "I", e[8:12])[0]:][:total]
+        if typ == 2:
+            tags[tag] = (data.rstrip(b"\0").decode("latin1"),)
+        else:
+            tags[tag] = struct.unpack(bo + fmt[0] * (cnt * len(fmt)), data)
+    W, H = tags[256][0], tags[257][0]
+    spp = tags.get(277, (1,))[0]
+    bits = tags.get(258, (1,))[0]
+    fmt = tags.get(339, (1,))[0]
+    if tags.get(259, (1,))[0] != 1:
+        raise NotImplementedError(f"{path}: compressed TIFF (compression={tags[259][0]}) is not supported")
+    planar = tags.get(284, (1,))[0]
+    dt = _dtype(bits, fmt, bo)
+    planes = spp if planar == 2 else 1
+    pix = 1 if planar == 2 else spp
+    out = np.zeros((planes, H, W, pix), dtype=dt.newbyteorder("="))
+    if 324 in tags:        # tiled
+        tw, th = tags[322][0], tags[323][0]
+        offs, cnts = tags[324], tags[325]
+        tx, ty = -(-W // tw), -(-H // th)
+        k = 0
+        for p in range(planes):
+            for j in range(ty):
+                for i in range(tx):
+                    t = np.frombuffer(b, dtype=dt, count=tw * th * pix, offset=offs[k]).reshape(th, tw, pix)
+                    h, w = min(th, H - j * th), min(tw, W - i * tw)
+                    out[p, j * th:j * th + h, i * tw:i * tw + w] = t[:h, :w]
+                    k += 1
+    else:
+        rps = tags.get(278, (H,))[0]
+        offs = tags[273]
+        spi = -(-H // rps)
+        for p in range(planes):
+            for s in range(spi):
+                r0 = s * rps
+                rows = min(rps, H - r0)
+                out[p, r0:r0 + rows] = np.frombuffer(b, dtype=dt, count=rows * W * pix, offset=offs[p * spi + s]).reshape(rows, W, pix)
+    arr = out[:, :, :, 0] if planar == 2 else np.moveaxis(out[0], -1, 0)
+    meta = {"tags": {t: tags[t] for t in GEO_TAGS if t in tags}, "dtype": arr.dtype, "geotransform": None}
+    if 33550 in tags and 33922 in tags:
+        sx, sy = tags[33550][0], tags[33550][1]
+        i, j, _, x, y, _ = tags[33922][:6]
+        meta["geotransform"] = (x - i * sx, sx, 0.0, y + j * sy, 0.0, -sy)
+    if 42113 in tags:
+        try:
+            meta["nodata"] = float(tags[42113][0])
+        except ValueError:
+            meta["nodata"] = None
+    return (arr[0] if arr.shape[0] == 1 else arr), meta
+
+
+def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int, tuple]] = None, nodata=None) -> None:
+    """Uncompressed, single strip, pixel-interleaved little-endian TIFF of a [C,H,W] or [H,W] array."""
+    a = np.asarray(arr)
+    if a.ndim == 2:
+        a = a[None]
+    C, H, W = a.shape
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8)
+    if a.dtype == np.int64:
+        a = a.astype(np.int32)
+    if a.dtype == np.float64:
+        a = a.astype(np.float32)
+    kind = {"u": 1, "i": 2, "f": 3}[a.dtype.kind]
+    data = np.ascontiguousarray(np.moveaxis(a, 0, -1)).astype(a.dtype.newbyteorder("<")).tobytes()
+    entries = []          # (tag, type, count, payload-bytes)
+
+    def add(tag, typ, vals):
+        if typ == 2:
+            payload = vals.encode("latin1") + b"\0"
+            cnt = len(payload)
+        else:
+            fmt = _TYPES[typ][0]
+            payload = struct.pack("<" + fmt[0] * len(vals), *vals)
+            cnt = len(vals)
+        entries.append((tag, typ, cnt, payload))
+
+    add(256, 4, [W]); add(257, 4, [H]); add(258, 3, [a.dtype.itemsize * 8] * C); add(259, 3, [1])
+    add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [C]); add(278, 4, [H]); add(279, 4, [len(data)]); add(284, 3, [1])
+    if C > 1:
+        add(338, 3, [0] * (C - 1))      # ExtraSamples: unspecified (what GDAL writes for MINISBLACK multi-band)
+    add(339, 3, [kind] * C)
+    geo = dict(tags or {})
+    if geotransform is not None:
+        ulx, xres, _, uly, _, yres = geotransform
+        geo[33550] = (abs(xres), abs(yres), 0.0)
+        geo[33922] = (0.0, 0.0, 0.0, ulx, uly, 0.0)
+    if nodata is not None:
+        geo[42113] = (str(nodata),)
+    for t in sorted(geo):
+        v = geo[t]
+        if t in (34737, 42113):
+            add(t, 2, v[0] if isinstance(v, tuple) else v)
+        elif t == 34735:
+            add(t, 3, list(v))
+        else:
+            add(t, 12, list(v))
+    entries.sort(key=lambda e: e[0])
+    n = len(entries)
+    ifd_off = 8
+    extra_off = ifd_off + 2 + 12 * n + 4
+    extra = b""
+    body = b""
+    placed = []
+    for tag, typ, cnt, payload in entries:
+        if len(payload) <= 4:
+            placed.append((tag, typ, cnt, payload.ljust(4, b"\0")))
+        else:
+            if len(extra) % 2:
+                extra += b"\0"
+            placed.append((tag, typ, cnt, struct.pack("<I", extra_off + len(extra))))
+            extra += payload
+    if len(extra) % 2:
+        extra += b"\0"
+    data_off = extra_off + len(extra)
+    for tag, typ, cnt, val in placed:
+        if tag == 273:
+            val = struct.pack("<I", data_off)
+        body += struct.pack("<HHI", tag, typ, cnt) + val
+    out = b"II" + struct.pack("<HI", 42, ifd_off) + struct.pack("<H", n) + body + struct.pack("<I", 0) + extra + data
+    Path(path).write_bytes(out)
