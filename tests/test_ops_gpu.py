@@ -408,3 +408,33 @@ def test_bad_arguments_fail_loudly(ops):
         ops.conv2d(x, wp, y, 3, 1)          # inconsistent output dims
     with pytest.raises(UnetHipError):
         ops.conv2d(x, wp, empty_ts(1, 8, 8, 16), 5, 1)   # unsupported kernel size
+
+
+@pytest.mark.parametrize("shape", [16, 32])
+def test_conv_mfma_shapes_agree(ops, shape):
+    """both MFMA instruction shapes (16x16x4 with tile skipping, 32x32x2) give the reference result on the awkward widths"""
+    from unet_amd._lib import lib
+    assert lib.unet_set_mfma_shape(shape) == 0
+    try:
+        for case in [(2, 40, 48, 100, 100, 3, 1), (1, 16, 16, 192, 96, 3, 1), (1, 32, 32, 99, 2, 1, 1), (2, 26, 26, 64, 128, 3, 2),
+                     (1, 24, 24, 36, 100, 3, 1), (1, 16, 16, 20, 52, 3, 1)]:
+            N, H, W, Cin, Cout, ks, stride = case
+            g = torch.Generator().manual_seed(sum(case))
+            x = torch.randn(N, Cin, H, W, generator=g)
+            w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+            b = torch.randn(Cout, generator=g)
+            ref = _conv_ref(x, w, b, ks, stride)
+            yt = empty_ts(N, ref.shape[2], ref.shape[3], Cout)
+            rows = ops.conv_colsum_rows(to_ts(x), ops.pack_weights(w.cuda(), 0), yt, ks, stride, 0)
+            cs_ = torch.zeros(rows, Cout, device="cuda")
+            ops.conv2d(to_ts(x), ops.pack_weights(w.cuda(), 0), yt, ks, stride, bias=b.cuda(), colsum=cs_)
+            dy = torch.randn(ref.shape, generator=g)
+            dxt = empty_ts(N, H, W, Cin)
+            ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(w.cuda(), 1), dxt, ks, stride)
+            torch.cuda.synchronize()
+            assert_close(from_ts(yt), ref, rtol=2e-4, what=f"mf{shape} fwd {case}")
+            assert_close(cs_.sum(0).cpu(), ref.sum((0, 2, 3)), rtol=2e-4, atol=1e-2, what=f"mf{shape} colsum {case}")
+            assert_close(from_ts(dxt), torch.nn.grad.conv2d_input(x.shape, w, dy, stride=stride, padding=(ks - 1) // 2), rtol=2e-4,
+                         what=f"mf{shape} dgrad {case}")
+    finally:
+        lib.unet_set_mfma_shape(16)

@@ -69,6 +69,20 @@ __device__ __forceinline__ void st_halo(const float4 (&hreg)[HIT], float* dst, i
         if (e < hpix4) *reinterpret_cast<float4*>(dst + (e >> 2) * LDK + (e & 3) * 4) = hreg[it];
     }
 }
+// Reduction-tail chunk (Cin % 16 != 0): channel c of the chunk is stored at position 4*(c%4) + c/4, so that MFMA
+// k-step kk of the b128 operand reads covers channels 4kk..4kk+3 and steps beyond the real channels are skipped.
+// The packed filter image uses the same order for that chunk (pack_weights_kernel).
+template <int HIT, int NTH>
+__device__ __forceinline__ void st_halo_tail(const float4 (&hreg)[HIT], float* dst, int hpix4, int tid) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        if (e < hpix4) {
+            float* row = dst + (e >> 2) * LDK + (e & 3);
+            row[0] = hreg[it].x; row[4] = hreg[it].y; row[8] = hreg[it].z; row[12] = hreg[it].w;
+        }
+    }
+}
 // filter slab staging: one or two float4 per thread, held in named registers (a 2-element
 // array here was demoted to scratch by the compiler)
 template <int WIT, int NTH, int BN>
@@ -89,7 +103,7 @@ __device__ __forceinline__ void st_w(const float4& w0, const float4& w1, float* 
 }
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kernel(const KArgs a) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
     constexpr int WIT = (BN * 4 + NTH - 1) / NTH;  // weight float4 items per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -139,9 +153,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs 
 
     float4 hreg[HIT];
     float4 wreg0, wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_tail = (a.Cin & 15) != 0;
 
 #define LOAD_HALO(chunk_) ld_halo<HIT, NTH>(hreg, goff, xb, (chunk_) * KC, a.Cin4, tid)
-#define STORE_HALO(dst_) st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid)
+#define STORE_HALO(dst_, chunk_) do { if (has_tail && (chunk_) == a.nchunks - 1) st_halo_tail<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); \
+                                       else st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); } while (0)
 #define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
 #define STORE_W(dst_) st_w<WIT, NTH, BN>(wreg0, wreg1, (dst_), tid)
 
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs 
     const int ntaps = ts.n;
     LOAD_HALO(0);
     LOAD_W(ts.widx[0], 0);
-    STORE_HALO(halo_buf(0));
+    STORE_HALO(halo_buf(0), 0);
     STORE_W(wts_buf(0));
     __syncthreads();
 
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs 
     const int total = a.nchunks * ntaps;
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         int ng = (a.Cin - chunk * KC + 7) >> 3;
-        ng = ng > 2 ? 2 : ng;
+        ng = (ng > 2 || (has_tail && chunk == a.nchunks - 1)) ? 2 : ng;   // the tail chunk is stored channel-transposed
         const float* hb = halo_buf(chunk & 1);
         for (int t = 0; t < ntaps; ++t, ++s) {
             const bool has_next = (s + 1) < total;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs 
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][kk], bv4[n][kk], acc[m][n], 0, 0, 0);
             }
             if (has_next) STORE_W(wts_buf((s + 1) & 1));
-            if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1));
+            if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1), chunk + 1);
             __syncthreads();
         }
     }
@@ -294,6 +310,239 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const KArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same workgroup geometry on v_mfma_f32_16x16x4_f32 (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C: col=l&15,
+// row=4*(l>>4)+reg).  Each wave owns (2*MT) x (2*NT) tiles of 16x16; the LDS traffic per MFMA cycle is the
+// same as the 32x32x2 form (one ds_read_b128 per operand tile per 16-channel chunk = 4 k-steps), but
+//   * output-channel tiles that lie entirely beyond Cout are SKIPPED per wave (uniform branch): produced
+//     channel counts are padded to 16 instead of 32/64/128 (Cout = 96 exact, 100 -> 112, 192 exact);
+//   * a reduction tail of r < 16 channels costs ceil(r/4) MFMA steps (ds_read_b32 operands) instead of 4.
+template <int TW, int MT, int NT, int WM, int WN, int HIT>
+__global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_kernel(const KArgs a) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
+    constexpr int WIT = (BN * 4 + NTH - 1) / NTH;
+    constexpr int M16 = 2 * MT, N16 = 2 * NT;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const TapSet& ts = a.taps[blockIdx.z];
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.ntn; bid /= a.ntn;
+    const int mtile = bid;
+    const int tx_t = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty_t = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int oy0 = ty_t * TH, ox0 = tx_t * TW;
+    const int n0 = nt * BN;
+
+    const int S = a.S;
+    const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
+    const int HPIX = HH * HW;
+    int* s_tapoff = reinterpret_cast<int*>(smem);
+    int* s_widx = reinterpret_cast<int*>(smem) + 16;
+    float* lds0 = smem + 32;
+    auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDK); };
+    auto wts_buf = [&](int b) -> float* { return lds0 + 2 * HPIX * LDK + b * (BN * LDK); };
+    if (tid < 9) {
+        const int t = tid < ts.n ? tid : 0;
+        s_tapoff[tid] = ((ts.dy[t] - ts.min_dy) * HW + (ts.dx[t] - ts.min_dx)) * LDK;
+        s_widx[tid] = ts.widx[t];
+    }
+
+    const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
+    const int iy0 = oy0 * S + ts.min_dy, ix0 = ox0 * S + ts.min_dx;
+    int goff[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        const int p = e >> 2, q = e & 3;
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool inb = (e < HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        goff[it] = inb ? ((iy * a.IW + ix) * a.x_cs + a.x_co + 4 * q) : -1;
+    }
+
+    float4 hreg[HIT];
+    float4 wreg0, wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_tail = (a.Cin & 15) != 0;
+
+#define LOAD_HALO(chunk_) ld_halo<HIT, NTH>(hreg, goff, xb, (chunk_) * KC, a.Cin4, tid)
+#define STORE_HALO(dst_, chunk_) do { if (has_tail && (chunk_) == a.nchunks - 1) st_halo_tail<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); \
+                                       else st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); } while (0)
+#define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
+#define STORE_W(dst_) st_w<WIT, NTH, BN>(wreg0, wreg1, (dst_), tid)
+
+    // operand row bases (floats) WITHOUT the k-lane term: full chunks add 4*kq (b128), tails add 4*j + kq (b32)
+    int abase[M16], bbase[N16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m) {
+        const int pix = (wm * M16 + m) * 16 + l15;
+        const int ty = pix / TW, tx = pix % TW;
+        abase[m] = ((ty * S) * HW + tx * S) * LDK;
+    }
+#pragma unroll
+    for (int n = 0; n < N16; ++n) bbase[n] = ((wn * N16 + n) * 16 + l15) * LDK;
+    // number of 16-wide output-channel tiles of this wave that contain a real channel
+    int nvalid = (a.Cout - n0 - wn * N16 * 16 + 15) >> 4;
+    nvalid = nvalid < 0 ? 0 : (nvalid > N16 ? N16 : nvalid);
+
+    f32x4 acc[M16][N16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m)
+#pragma unroll
+        for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntaps = ts.n;
+    LOAD_HALO(0);
+    LOAD_W(ts.widx[0], 0);
+    STORE_HALO(halo_buf(0), 0);
+    STORE_W(wts_buf(0));
+    __syncthreads();
+
+    int s = 0;
+    const int total = a.nchunks * ntaps;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const int rem = a.Cin - chunk * KC;      // real reduction channels left in this chunk
+        const int ksteps = rem >= KC ? 4 : ((rem + 3) >> 2);   // tail chunk: channel-transposed, step kk = channels 4kk..4kk+3
+        const float* hb = halo_buf(chunk & 1);
+        for (int t = 0; t < ntaps; ++t, ++s) {
+            const bool has_next = (s + 1) < total;
+            if (has_next) {
+                const bool wrap = (t + 1 == ntaps);
+                LOAD_W(s_widx[wrap ? 0 : t + 1], wrap ? chunk + 1 : chunk);
+            }
+            const bool halo_next = (chunk + 1 < a.nchunks);
+            if (t == 0 && halo_next) LOAD_HALO(chunk + 1);
+
+            const float* wb = wts_buf(s & 1);
+            const float* ha = hb + s_tapoff[t];
+            {
+                float av[M16][4], bv[N16][4];
+#pragma unroll
+                for (int m = 0; m < M16; ++m) {
+                    const float4 f = *reinterpret_cast<const float4*>(ha + abase[m] + 4 * kq);
+                    av[m][0] = f.x; av[m][1] = f.y; av[m][2] = f.z; av[m][3] = f.w;
+                }
+#pragma unroll
+                for (int n = 0; n < N16; ++n) {
+                    const float4 f = *reinterpret_cast<const float4*>(wb + bbase[n] + 4 * kq);
+                    bv[n][0] = f.x; bv[n][1] = f.y; bv[n][2] = f.z; bv[n][3] = f.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk < ksteps) {
+#pragma unroll
+                        for (int n = 0; n < N16; ++n) {
+                            if (n < nvalid) {
+#pragma unroll
+                                for (int m = 0; m < M16; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][kk], bv[n][kk], acc[m][n], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (has_next) STORE_W(wts_buf((s + 1) & 1));
+            if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1), chunk + 1);
+            __syncthreads();
+        }
+    }
+#undef LOAD_HALO
+#undef STORE_HALO
+#undef LOAD_W
+#undef STORE_W
+
+    // ---- epilogue (phased as in the 32x32 kernel) ----
+    const bool relu = a.flags & UNET_CONV_RELU;
+    const int OS = a.OS;
+    const size_t img_pix = (size_t)img * a.OH * a.OW;
+    float* yb = a.y + img_pix * a.y_cs + a.y_co;
+    const float* resb = a.res ? a.res + img_pix * a.res_cs + a.res_co : nullptr;
+    const float* maskb = a.mask ? a.mask + img_pix * a.mask_cs + a.mask_co : nullptr;
+    // pixel indices of this lane's 4 accumulator rows for every M tile
+    int pidx[M16][4];
+    bool pval[M16][4];
+#pragma unroll
+    for (int m = 0; m < M16; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pix = (wm * M16 + m) * 16 + 4 * kq + r;
+            const int ty = pix / TW, tx = pix % TW;
+            const int oyt = oy0 + ty, oxt = ox0 + tx;
+            const int oy = oyt * OS + ts.py, ox = oxt * OS + ts.px;
+            pval[m][r] = oyt < a.TSH && oxt < a.TSW && oy < a.OH && ox < a.OW;
+            pidx[m][r] = pval[m][r] ? (oy * a.OW + ox) : 0;
+        }
+#pragma unroll
+    for (int n = 0; n < N16; ++n) {
+        if (n >= nvalid) continue;
+        const int cout = n0 + (wn * N16 + n) * 16 + l15;
+        const bool cvalid = cout < a.Cout;
+        const int cc = cvalid ? cout : 0;
+        const float bvv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
+        float csum = 0.f, csq = 0.f;
+        float v[M16][4];
+#pragma unroll
+        for (int m = 0; m < M16; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[m][r] = acc[m][n][r] + bvv;
+        if (resb != nullptr) {
+            float rv[M16][4];
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[m][r] = resb[pidx[m][r] * a.res_cs + cc];
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] += rv[m][r];
+        }
+        if (relu) {
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.f);
+        }
+        if (maskb != nullptr) {
+            float mv[M16][4];
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mv[m][r] = maskb[pidx[m][r] * a.mask_cs + cc];
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = mv[m][r] > 0.f ? v[m][r] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < M16; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (cvalid && pval[m][r]) {
+                    yb[pidx[m][r] * a.y_cs + cout] = v[m][r];
+                    csum += v[m][r];
+                    csq += v[m][r] * v[m][r];
+                }
+            }
+        if (a.colsum != nullptr) {
+            csum += __shfl_xor(csum, 16);
+            csq += __shfl_xor(csq, 16);
+            csum += __shfl_xor(csum, 32);
+            csq += __shfl_xor(csq, 32);
+            if (kq == 0 && cvalid) {
+                const size_t row = ((size_t)blockIdx.z * a.mtiles + mtile) * WM + wm;
+                a.colsum[row * a.Cout + cout] = csum;
+                if (a.colsumsq != nullptr) a.colsumsq[row * a.Cout + cout] = csq;
+            }
+        }
+    }
+    // tiles skipped by this wave still owe zeros to the column-sum rows (their channels are >= Cout: nothing to write)
+}
+
 // ------------------------------------------------------------------ packing
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int T,
@@ -305,7 +554,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int o = (int)(j % outPad); j /= outPad;
         const int chunk = (int)(j % nchunks);
         const int tap = (int)(j / nchunks);
-        const int r = chunk * 16 + rr;
+        const int red = mode == 0 ? Cin : Cout;
+        const bool tail = (red & 15) != 0 && chunk == nchunks - 1;
+        const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         float v = 0.f;
         if (mode == 0) {
             if (o < Cout && r < Cin) v = w[((size_t)o * Cin + r) * T + tap];
@@ -318,9 +569,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 // ------------------------------------------------------------------ host side
 
+// MFMA shape of the conv kernels: 16 = v_mfma_f32_16x16x4_f32 with per-tile skipping (default), 32 = v_mfma_f32_32x32x2_f32
+static int g_mfma_shape = 16;
+
 struct Plan {
     KArgs k;
-    int tw, bn, hit, nparity;
+    int tw, bn, hit, nparity, mf;
     size_t lds_bytes;
     dim3 grid;
 };
@@ -411,6 +665,7 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     const int th = 128 / p->tw;
     p->bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     p->hit = (k.S == 2) ? 10 : 4;
+    p->mf = g_mfma_shape;
     k.tiles_y = unet::cdiv(k.TSH, th);
     k.tiles_x = unet::cdiv(k.TSW, p->tw);
     k.ntn = unet::cdiv(d->Cout, p->bn);
@@ -429,6 +684,17 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
 int launch_cfg(const Plan& p, hipStream_t st) {
+    if (p.mf == 16) {
+        auto kern = conv_igemm16_kernel<TW, MT, NT, WM, WN, HIT>;
+        static size_t configured = 0;  // per instantiation
+        if (p.lds_bytes > configured) {
+            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = 160 * 1024;
+        }
+        hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k);
+        UNET_CHECK_LAUNCH();
+        return UNET_OK;
+    }
     auto kern = conv_igemm_kernel<TW, MT, NT, WM, WN, HIT>;
     static size_t configured = 0;  // per instantiation
     if (p.lds_bytes > configured) {
@@ -466,6 +732,12 @@ extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
     if (rc != UNET_OK) return rc;
     const int wm = (p.bn == 32) ? 4 : 2;
     return p.nparity * p.k.mtiles * wm;
+}
+
+extern "C" int unet_set_mfma_shape(int shape) {
+    UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
+    g_mfma_shape = shape;
+    return UNET_OK;
 }
 
 extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
