@@ -80,6 +80,7 @@ int unet_conv2d_variant(const unet_conv_desc* d);
 /* MFMA instruction shape used by the conv / wgrad kernels: 16 (v_mfma_f32_16x16x4_f32, 16-channel granularity, default)
  * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */
 int unet_set_mfma_shape(int shape);
+int unet_set_wgrad_mfma_shape(int shape);
 
 /* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].
  * mode 0 (FWD):   wp[tap][chunk][coutPad][16]  reduction over Cin

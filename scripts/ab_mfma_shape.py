@@ -15,11 +15,11 @@ torch.cuda.synchronize()
 res = {16: [], 32: []}
 for rnd in range(4):
     for shape in (16, 32):
-        lib.unet_set_mfma_shape(shape)
+        lib.unet_set_wgrad_mfma_shape(shape)
         step(x, y); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3): step(x, y)
         torch.cuda.synchronize()
         res[shape].append((time.perf_counter() - t0) / 3 * 1e3)
 for k, v in res.items():
-    print(f"mfma {k}: ms/step median {sorted(v)[len(v)//2]:.2f} min {min(v):.2f}  -> {16e3/min(v):.1f} tiles/s", flush=True)
+    print(f"wgrad mfma {k}: ms/step median {sorted(v)[len(v)//2]:.2f} min {min(v):.2f}  -> {16e3/min(v):.1f} tiles/s", flush=True)

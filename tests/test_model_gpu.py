@@ -89,7 +89,7 @@ def test_train_step_gradients(arch, n_in, n_out, size, bs):
             #  on some tensors there; that case is held by the smooth-network test and the global criterion below)
             scale = g6.abs().max().item() + 1e-30
             e = (gh.double() - g6).abs().max().item() / scale
-            assert e < max(2e-3, 50 * (gc.double() - g6).abs().max().item() / scale), f"tail gradient {n}: rel err {e:.2e}"
+            assert e < max(1e-2, 50 * (gc.double() - g6).abs().max().item() / scale), f"tail gradient {n}: rel err {e:.2e}"
     gh, gc, g6 = torch.cat(g_hip), torch.cat(g_cpu), torch.cat(g_64)
     e_hip, e_cpu = _rel_l2(gh, g6), _rel_l2(gc, g6)
     cos = torch.nn.functional.cosine_similarity(gh.double(), g6, dim=0).item()

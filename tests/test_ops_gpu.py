@@ -438,3 +438,27 @@ def test_conv_mfma_shapes_agree(ops, shape):
                          what=f"mf{shape} dgrad {case}")
     finally:
         lib.unet_set_mfma_shape(16)
+
+
+def test_wgrad_mfma_shapes_agree(ops):
+    from unet_amd._lib import lib
+    for shape in (32, 16):
+        assert lib.unet_set_wgrad_mfma_shape(shape) == 0
+        try:
+            for case in [(2, 40, 48, 100, 100, 3, 1), (1, 16, 16, 192, 96, 3, 1), (2, 26, 26, 64, 128, 3, 2), (2, 16, 16, 100, 5, 1, 1),
+                         (1, 24, 24, 36, 52, 3, 1)]:
+                N, H, W, Cin, Cout, ks, stride = case
+                g = torch.Generator().manual_seed(sum(case))
+                pad = (ks - 1) // 2
+                OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+                x = torch.randn(N, Cin, H, W, generator=g)
+                dy = torch.randn(N, Cout, OH, OW, generator=g)
+                ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, ks, ks), dy, stride=stride, padding=pad)
+                xt, dyt = to_ts(x), to_ts(dy)
+                ws = torch.empty(ops.wgrad_workspace(xt, dyt, ks, stride), device="cuda")
+                dw = torch.empty((Cout, Cin, ks, ks), device="cuda")
+                ops.conv2d_wgrad(xt, dyt, dw, ks, stride, ws)
+                torch.cuda.synchronize()
+                assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"wgrad mf{shape} {case}")
+        finally:
+            lib.unet_set_wgrad_mfma_shape(32)

@@ -83,6 +83,7 @@ _sig = {
     "unet_conv2d": (i, [C.POINTER(ConvDesc), vp]),
     "unet_conv2d_variant": (i, [C.POINTER(ConvDesc)]),
     "unet_set_mfma_shape": (i, [i]),
+    "unet_set_wgrad_mfma_shape": (i, [i]),
     "unet_pack_weights_size": (sz, [i, i, i, i]),
     "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
     "unet_conv2d_wgrad_workspace": (sz, [C.POINTER(WgradDesc)]),

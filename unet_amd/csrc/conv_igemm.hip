@@ -385,10 +385,12 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
         abase[m] = ((ty * S) * HW + tx * S) * LDK;
     }
 #pragma unroll
-    for (int n = 0; n < N16; ++n) bbase[n] = ((wn * N16 + n) * 16 + l15) * LDK;
-    // number of 16-wide output-channel tiles of this wave that contain a real channel
-    int nvalid = (a.Cout - n0 - wn * N16 * 16 + 15) >> 4;
-    nvalid = nvalid < 0 ? 0 : (nvalid > N16 ? N16 : nvalid);
+    // 16-wide output-channel tiles are dealt round-robin to the WN waves (tile n of this wave = block tile n*WN + wn), so the
+    // tiles that survive the Cout cut-off are balanced between the waves' MFMA pipes
+    for (int n = 0; n < N16; ++n) bbase[n] = ((n * WN + wn) * 16 + l15) * LDK;
+    // number of this wave's tiles that contain a real channel: tiles n with (n*WN + wn)*16 < Cout - n0
+    int nvalid = ((a.Cout - n0 + 15) / 16 - wn + WN - 1) / WN;
+    nvalid = (a.Cout - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
 
     f32x4 acc[M16][N16];
 #pragma unroll
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
 #pragma unroll
     for (int n = 0; n < N16; ++n) {
         if (n >= nvalid) continue;
-        const int cout = n0 + (wn * N16 + n) * 16 + l15;
+        const int cout = n0 + (n * WN + wn) * 16 + l15;
         const bool cvalid = cout < a.Cout;
         const int cc = cvalid ? cout : 0;
         const float bvv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
@@ -574,7 +576,7 @@ static int g_mfma_shape = 16;
 
 struct Plan {
     KArgs k;
-    int tw, bn, hit, nparity, mf;
+    int tw, bm, bn, hit, nparity, mf;
     size_t lds_bytes;
     dim3 grid;
 };
@@ -662,10 +664,20 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     }
 
     p->tw = k.TSW >= 32 ? 32 : (k.TSW >= 16 ? 16 : 8);
-    const int th = 128 / p->tw;
     p->bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+    p->bm = 128;
     p->hit = (k.S == 2) ? 10 : 4;
     p->mf = g_mfma_shape;
+    // small problems (deep 16x16 / 32x32 stages): shrink the tile until the grid can fill 256 CUs x 2
+    auto blocks = [&](int bm, int bn) {
+        const int th_ = bm / p->tw;
+        return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(d->Cout, bn) * p->nparity;
+    };
+    if (p->bn >= 64 && blocks(128, p->bn) < 400) {
+        p->bm = 64;
+        if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
+    }
+    const int th = p->bm / p->tw;
     k.tiles_y = unet::cdiv(k.TSH, th);
     k.tiles_x = unet::cdiv(k.TSW, p->tw);
     k.ntn = unet::cdiv(d->Cout, p->bn);
@@ -708,6 +720,10 @@ int launch_cfg(const Plan& p, hipStream_t st) {
 
 template <int TW, int HIT>
 int launch_bn(const Plan& p, hipStream_t st) {
+    if (p.bm == 64) {
+        if (p.bn == 64) return launch_cfg<TW, 1, 1, 2, 2, HIT>(p, st);
+        return launch_cfg<TW, 1, 2, 2, 2, HIT>(p, st);
+    }
     switch (p.bn) {
         case 32: return launch_cfg<TW, 1, 1, 4, 1, HIT>(p, st);
         case 64: return launch_cfg<TW, 2, 1, 2, 2, HIT>(p, st);
@@ -730,7 +746,7 @@ extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
     Plan p;
     int rc = make_plan(d, &p);
     if (rc != UNET_OK) return rc;
-    const int wm = (p.bn == 32) ? 4 : 2;
+    const int wm = (p.bn == 32 && p.bm == 128) ? 4 : 2;
     return p.nparity * p.k.mtiles * wm;
 }
 
@@ -744,7 +760,7 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     Plan p;
     int rc = make_plan(d, &p);
     if (rc != UNET_OK) return rc;
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0);
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0);
 }
 
 extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {

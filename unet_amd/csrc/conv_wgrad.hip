@@ -17,6 +17,8 @@
 // Replaces the autograd weight-gradient ATen kernels for fastai ConvLayer convs
 // (reference train.py:247-250 -> loss.backward()).
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,7 @@ constexpr int BC = 64;  // input channels per block
 
 struct WArgs {
     const float* x; const float* dy; float* part;
+    float* bpart;   // optional [splits][Cout] partial column sums of dy (bias gradient), written by the cblk == 0 workgroups
     int x_cs, x_co, dy_cs, dy_co;
     int N, IH, IW, Cin, Cin4, OH, OW, Cout, Cout4;
     int tiles_y, tiles_x, total_tiles, tiles_per_block;
@@ -117,9 +120,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     const float* abase = dyT + h * BK + wk * 32 + l31;                  // + (2*step) * BK
     const float* bbase = xh + (h * S) * BC + wc * 32 + l31;             // + window offset
 
+    // bias gradient: threads 0..63 of the first channel-block column sum the staged dy tile (pads are zero)
+    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
+    float bsum = 0.f;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         stage_tile(tile);
         __syncthreads();
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) bsum += dyT[p * BK + tid];
+        }
 #pragma unroll
         for (int step = 0; step < PT / 2; ++step) {
             // pixel 2*step + h ; 2*step is even and PTW is even, so px = (2*step % PTW) + h, py = 2*step / PTW
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         __syncthreads();
     }
 
+    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
     // ---- write partials: part[split][tap][k][c] ----
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * T * KC_;
@@ -146,6 +157,163 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (k < a.Cout && c < a.Cin) pb[(size_t)t * KC_ + (size_t)k * a.Cin + c] = acc[t][r];
+        }
+}
+
+// Same decomposition on v_mfma_f32_16x16x4_f32: each wave owns 2x2 tiles of 16x16 per tap and skips the tiles that lie
+// entirely beyond Cout / Cin, so channel counts are padded to 16 instead of 64 (100x100 costs 49 of 64 tiles, 96x96 36).
+//   A[i=l&15][kk=l>>4] = dy[pixel 4*step+kk][k0 + 16*mt + i],  B[kk][j=l&15] = x[pixel shifted by tap][c0 + 16*nt + j]
+template <int PTW, int S, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad16_kernel(const WArgs a) {
+    constexpr int PT = (S == 1) ? 64 : 32;
+    constexpr int PTH = PT / PTW;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int T = KS * KS;
+    constexpr int HH = (PTH - 1) * S + KS, HW = (PTW - 1) * S + KS, HPIX = HH * HW;
+    constexpr int DIT = (PT * 16 + 255) / 256;
+    constexpr int XIT = (HPIX * 16 + 255) / 256;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // LDS row stride (floats): the 4 k-lanes (kq) of a 16x16x4 operand read 4 different pixel rows; rows must start
+    // 16 banks apart inside a 32-lane group: 80 (== 16 mod 32) for unit pixel stride, 72 for stride-2 inputs (2*72 == 16 mod 32)
+    constexpr int LD = (S == 1) ? 80 : 72;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dyT = smem;
+    float* xh = smem + PT * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
+    const int k0 = kblk * BK, c0 = cblk * BC;
+    const int split = blockIdx.y;
+    const int tile_begin = split * a.tiles_per_block;
+    int tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    // which of this wave's 2x2 16-tiles hold real channels (uniform per wave)
+    const bool mv0 = k0 + wk * 32 < a.Cout, mv1 = k0 + wk * 32 + 16 < a.Cout;
+    const bool nv0 = c0 + wc * 32 < a.Cin, nv1 = c0 + wc * 32 + 16 < a.Cin;
+
+    f32x4 acc[2][2][T];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[i][j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage_tile = [&](int tile) {
+        int b = tile;
+        const int tx = b % a.tiles_x; b /= a.tiles_x;
+        const int ty = b % a.tiles_y;
+        const int img = b / a.tiles_y;
+        const int oy0 = ty * PTH, ox0 = tx * PTW;
+        const float* dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
+        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
+        {
+            float4 r[DIT];
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                const int p = e >> 4, q = e & 15;
+                const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
+                const bool ok = (e < PT * 16) && oy < a.OH && ox < a.OW && (k0 + 4 * q) < a.Cout4;
+                r[it] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                if (e < PT * 16) *reinterpret_cast<float4*>(dyT + (e >> 4) * LD + (e & 15) * 4) = r[it];
+            }
+        }
+        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+        constexpr int XB = 4;
+#pragma unroll
+        for (int base = 0; base < XIT; base += XB) {
+            float4 r[XB];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int e = tid + (base + j) * 256;
+                const int p = e >> 4, q = e & 15;
+                const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+                const bool ok = (e < HPIX * 16) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
+                r[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int e = tid + (base + j) * 256;
+                if (e < HPIX * 16) *reinterpret_cast<float4*>(xh + (e >> 4) * LD + (e & 15) * 4) = r[j];
+            }
+        }
+    };
+
+    // lane kq handles pixel 4*step + kq of the tile: px = (4*step % PTW) + kq, py = 4*step / PTW (PTW is a multiple of 4)
+    const float* abase = dyT + kq * LD + wk * 32 + l15;
+    const float* bbase = xh + (kq * S) * LD + wc * 32 + l15;
+
+    // one pixel tile: 16 steps x T taps x up to 4 MFMAs; M1/N1 = second 16-row / 16-column tile of this wave is real
+    auto compute = [&](auto m1_tag, auto n1_tag) {
+        constexpr bool M1 = decltype(m1_tag)::value, N1 = decltype(n1_tag)::value;
+#pragma unroll
+        for (int step = 0; step < PT / 4; ++step) {
+            const int py = (4 * step) / PTW, px = (4 * step) % PTW;
+            const float a0 = abase[(4 * step) * LD];
+            const float a1 = M1 ? abase[(4 * step) * LD + 16] : 0.f;
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int off = ((py * S + r) * HW + px * S + s) * LD;
+                    const int t = r * KS + s;
+                    const float b0 = bbase[off];
+                    acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0][t], 0, 0, 0);
+                    if constexpr (M1) acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0][t], 0, 0, 0);
+                    if constexpr (N1) {
+                        const float b1 = bbase[off + 16];
+                        acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1][t], 0, 0, 0);
+                        if constexpr (M1) acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1][t], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    using T1 = std::true_type;
+    using T0 = std::false_type;
+
+    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
+    float bsum = 0.f;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        stage_tile(tile);
+        __syncthreads();
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
+        }
+        if (mv0 && nv0) {            // (a wave whose first tile is empty has nothing to do)
+            if (mv1 && nv1) compute(T1{}, T1{});
+            else if (mv1) compute(T1{}, T0{});
+            else if (nv1) compute(T0{}, T1{});
+            else compute(T0{}, T0{});
+        }
+        __syncthreads();
+    }
+
+    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    const size_t KC_ = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)split * T * KC_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 32 + 16 * j + l15;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = k0 + wk * 32 + 16 * i + 4 * kq + r;
+                    if (k < a.Cout && c < a.Cin) pb[(size_t)t * KC_ + (size_t)k * a.Cin + c] = acc[i][j][t][r];
+                }
         }
 }
 
@@ -172,10 +340,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ dbias, int splits, int Cout) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    double s = 0.0;
+    for (int sp = 0; sp < splits; ++sp) s += (double)bpart[(size_t)sp * Cout + c];
+    dbias[c] = (float)s;
+}
+
 struct WPlan {
     WArgs k;
     int ptw, splits, T;
-    size_t lds_bytes;
+    size_t lds_bytes, lds_bytes16;
 };
 
 int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
@@ -216,11 +392,28 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     p->splits = unet::cdiv(k.total_tiles, tpb);
     const int hh = (pth - 1) * d->stride + d->ks, hw = (p->ptw - 1) * d->stride + d->ks;
     p->lds_bytes = (size_t)(pt * BK + hh * hw * BC) * sizeof(float);
+    p->lds_bytes16 = (size_t)(pt + hh * hw) * (d->stride == 1 ? 80 : 72) * sizeof(float);
+    return UNET_OK;
+}
+
+static int g_wgrad_mfma_shape = 32;   // the 16x16x4 wgrad form measured slower (register pressure): opt-in only
+
+template <int PTW, int S, int KS>
+int launch_w16(const WPlan& p, hipStream_t st) {
+    auto kern = wgrad16_kernel<PTW, S, KS>;
+    static bool configured = false;
+    if (!configured) {
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes16, st, p.k);
+    UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
 
 template <int PTW, int S, int KS>
 int launch_w(const WPlan& p, hipStream_t st) {
+    if (g_wgrad_mfma_shape == 16) return launch_w16<PTW, S, KS>(p, st);
     auto kern = wgrad_kernel<PTW, S, KS>;
     static bool configured = false;
     if (!configured) {
@@ -241,19 +434,28 @@ int launch_w_ptw(const WPlan& p, int ks, int stride, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int unet_set_wgrad_mfma_shape(int shape) {
+    UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
+    g_wgrad_mfma_shape = shape;
+    return UNET_OK;
+}
+
 extern "C" size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d) {
     WPlan p;
     if (make_wplan(d, &p) != UNET_OK) return 0;
-    return (size_t)p.splits * p.T * d->Cout * d->Cin;
+    // split-K partials of dW followed by the [splits][Cout] partial column sums of dy (bias gradient)
+    return (size_t)p.splits * p.T * d->Cout * d->Cin + (size_t)p.splits * d->Cout;
 }
 
 extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     WPlan p;
     int rc = make_wplan(d, &p);
     if (rc != UNET_OK) return rc;
-    const size_t need = (size_t)p.splits * p.T * d->Cout * d->Cin;
+    const size_t npart = (size_t)p.splits * p.T * d->Cout * d->Cin;
+    const size_t need = npart + (size_t)p.splits * d->Cout;
     UNET_CHECK_ARG(d->workspace != nullptr && d->workspace_floats >= need, "wgrad: workspace too small (%zu < %zu floats)",
                    d->workspace_floats, need);
+    p.k.bpart = d->dbias != nullptr ? d->workspace + npart : nullptr;
     hipStream_t st = (hipStream_t)stream;
     switch (p.ptw) {
         case 32: rc = launch_w_ptw<32>(p, d->ks, d->stride, st); break;
@@ -266,10 +468,9 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
                        p.splits, p.T, KC_, d->accumulate);
     UNET_CHECK_LAUNCH();
     if (d->dbias != nullptr) {
-        // bias gradient = column sums of dy; workspace is free again after the reduce (stream ordered)
-        const long long P = (long long)d->N * d->OH * d->OW;
-        UNET_CHECK_ARG(d->workspace_floats >= unet_colsum_workspace(P, d->Cout), "wgrad: workspace too small for dbias");
-        return unet_colsum(d->dy, d->dy_cs, d->dy_co, P, d->Cout, d->dbias, d->workspace, stream);
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(unet::cdiv(d->Cout, 128)), dim3(128), 0, st, p.k.bpart, d->dbias, p.splits,
+                           d->Cout);
+        UNET_CHECK_LAUNCH();
     }
     return UNET_OK;
 }

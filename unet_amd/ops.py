@@ -176,10 +176,7 @@ def _wgrad_desc(x: TS, dy: TS, dw, dbias, ks, stride, ws, accumulate) -> WgradDe
 def wgrad_workspace(x: TS, dy: TS, ks, stride, with_bias=False) -> int:
     d = _wgrad_desc(x, dy, torch.empty(0), None, ks, stride, None, 0)
     d.dw = 1  # non-null placeholder for validation
-    n = lib.unet_conv2d_wgrad_workspace(C.byref(d))
-    if with_bias:
-        n = max(n, lib.unet_colsum_workspace(dy.P, dy.C))
-    return int(n)
+    return int(lib.unet_conv2d_wgrad_workspace(C.byref(d)))
 
 
 def conv2d_wgrad(x: TS, dy: TS, dw: torch.Tensor, ks: int, stride: int, ws: torch.Tensor, dbias=None, accumulate=False):
