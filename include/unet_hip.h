@@ -88,6 +88,9 @@ int unet_set_wgrad_mfma_shape(int shape);
  * pads are zero filled; chunk = 16 reduction channels; *Pad = roundup(.,128). */
 size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode); /* floats */
 int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream);
+/* 1x1 "weights" that are themselves activations (self-attention operands): element (out o, reduction r) = w[o*so + r*sr];
+ * produces the same packed image as mode 0 with ks = 1 (size unet_pack_weights_size(O, R, 1, 0)). */
+int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream);
 
 /* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
  * Replaces the autograd weight-gradient of the same nn.Conv2d modules.
@@ -196,6 +199,14 @@ int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const
 /* probs NCHW [N,C,H,W] (what Learner.predict returns, predict.py:196-203) and argmax uint8/int64 mask */
 int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, int H, int W, int C,
                         float* probs_nchw /*or NULL*/, int64_t* argmax /*or NULL*/, void* stream);
+
+/* ------------------------------------------------------- self-attention --
+ * fastai SelfAttention (layers.py; DynamicUnet(self_attention=True), params_and_main.py:81-83): beta = softmax(f^T g, dim=1),
+ * o = gamma * h beta + x.  The matrix products run on unet_conv2d / unet_conv2d_wgrad with per-image operands packed by
+ * unet_pack_weights_strided; these two kernels are the softmax over one attention row (all key positions) and its adjoint. */
+int unet_row_softmax(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, void* stream);
+int unet_row_softmax_bwd(const float* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co,
+                         float* dx, int dx_cs, int dx_co, long long P, int C, void* stream);
 
 /* ------------------------------------------------------------ optimiser --
  * fastai Adam (optimizer.py: weight_decay, average_grad(dampening), average_sqr_grad,

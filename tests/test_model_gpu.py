@@ -225,3 +225,46 @@ def test_state_dict_roundtrip_and_indexing():
     n1 = sum(p.numel() for l in model[0][3:] for p in l.parameters())
     n2 = sum(p.numel() for l in model[1:] for p in l.parameters())
     assert (n0, n1, n2) == (29056, 21275136, 19940385)
+
+
+@pytest.mark.parametrize("size,bs", [((64, 64), 2), ((128, 96), 1)])
+def test_self_attention_forward_and_gradients(size, bs):
+    """DynamicUnet(self_attention=True) (reference default with extra parameters, params_and_main.py:81-83): eval logits /
+    masks and, on a ReLU-flip-free network, every gradient incl. gamma and the spectral-normed projections."""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(5)
+    ref = O.DynamicUnet("xresnet34", 4, 5, size, self_attention=True)
+    O.randomize_bn_and_zero_gammas(ref, seed=6)
+    sa = ref.layers[5].conv2[2]
+    with torch.no_grad():
+        sa.gamma.fill_(0.6)
+    model = HipDynamicUnet("xresnet34", 4, 5, size, self_attention=True)
+    model.load_state_dict(ref.state_dict())
+    x, y = O.synthetic_batch(bs, 4, size[0], size[1], 5)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z_ref = ref(x)
+        z = model(x.cuda()).cpu()
+    assert (z - z_ref).abs().max().item() < 1e-3
+    assert torch.equal(z.argmax(1), z_ref.argmax(1))
+    # smooth variant for strict gradient parity
+    _make_all_active(ref)
+    model.load_state_dict(ref.state_dict())
+    ref.train(); model.train()
+    loss_ref = O.CrossEntropyLossFlat()(ref(x), y)
+    loss_ref.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), None)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    worst = ("", 0.0)
+    for (n, p), (n2, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == n2
+        e = (p.grad.cpu() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12)
+        if e > worst[1]:
+            worst = (n, e)
+    print("SA smooth worst", worst)
+    assert worst[1] < 3e-3, worst
+    # the power-iteration buffers advanced identically
+    for (n, b), (_, b2) in zip(model.named_buffers(), ref.named_buffers()):
+        if "weight_u" in n or "weight_v" in n:
+            assert (b.cpu() - b2).abs().max().item() < 1e-5, n

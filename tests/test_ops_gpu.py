@@ -462,3 +462,32 @@ def test_wgrad_mfma_shapes_agree(ops):
                 assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"wgrad mf{shape} {case}")
         finally:
             lib.unet_set_wgrad_mfma_shape(32)
+
+
+def test_row_softmax_and_strided_pack(ops):
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(2, 300, 3, 5, generator=g) * 3).requires_grad_(True)     # [N, C, H, W]: softmax over C per pixel
+    y = torch.softmax(x, dim=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xt = to_ts(x.detach())
+    yt = empty_ts(2, 3, 5, 300)
+    ops.row_softmax(xt, yt)
+    dxt = to_ts(dy)
+    ops.row_softmax_bwd(yt, dxt, dxt)          # in place
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), y.detach(), rtol=1e-5, atol=1e-7, what="row softmax")
+    assert_close(from_ts(dxt), x.grad, rtol=1e-4, atol=1e-7, what="row softmax bwd")
+    # strided pack: a [O, R] matrix stored transposed inside a wider activation buffer behaves like a 1x1 filter
+    O_, R = 52, 36
+    act = torch.randn(R, 80, generator=g)                 # rows r, O values at columns 8..8+O
+    w = act[:, 8:8 + O_].t().contiguous()                 # [O, R]
+    xin = torch.randn(1, R, 6, 7, generator=g)
+    ref = F.conv2d(xin, w.view(O_, R, 1, 1))
+    actd = act.cuda()
+    wp = torch.empty(ops.lib.unet_pack_weights_size(O_, R, 1, 0), device="cuda")
+    ops.pack_weights_strided(actd.data_ptr() + 8 * 4, 1, 80, O_, R, wp)
+    out = empty_ts(1, 6, 7, O_)
+    ops.conv2d(to_ts(xin), wp, out, 1)
+    torch.cuda.synchronize()
+    assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv")

@@ -86,6 +86,9 @@ _sig = {
     "unet_set_wgrad_mfma_shape": (i, [i]),
     "unet_pack_weights_size": (sz, [i, i, i, i]),
     "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
+    "unet_pack_weights_strided": (i, [vp, ll, ll, vp, i, i, vp]),
+    "unet_row_softmax": (i, [vp, i, i, vp, i, i, ll, i, vp]),
+    "unet_row_softmax_bwd": (i, [vp, i, i, vp, i, i, vp, i, i, ll, i, vp]),
     "unet_conv2d_wgrad_workspace": (sz, [C.POINTER(WgradDesc)]),
     "unet_conv2d_wgrad": (i, [C.POINTER(WgradDesc), vp]),
     "unet_bn_stats_rows": (i, [ll]),

@@ -569,6 +569,21 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// 1x1 "weights" taken from an activation matrix (self-attention: the per-image operands F, G, H are activations):
+// element (out o, reduction r) = w[o*so + r*sr]; same packed image as pack_weights_kernel with T = 1.
+__global__ void pack_weights_strided_kernel(const float* __restrict__ w, long long so, long long sr, float* __restrict__ wp, int O, int R,
+                                            int nchunks, int outPad, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i & 15);
+        size_t j = i >> 4;
+        const int o = (int)(j % outPad);
+        const int chunk = (int)(j / outPad);
+        const bool tail = (R & 15) != 0 && chunk == nchunks - 1;
+        const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
+        wp[i] = (o < O && r < R) ? w[(long long)o * so + (long long)r * sr] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 
 // MFMA shape of the conv kernels: 16 = v_mfma_f32_16x16x4_f32 with per-tile skipping (default), 32 = v_mfma_f32_32x32x2_f32
@@ -775,6 +790,16 @@ extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;
     const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
     return (size_t)T * unet::cdiv(red, KC) * unet::roundup(out, 128) * KC;
+}
+
+extern "C" int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream) {
+    UNET_CHECK_ARG(w && wp && O > 0 && R > 0, "pack_weights_strided: bad args");
+    const int nchunks = unet::cdiv(R, KC), outPad = unet::roundup(O, 128);
+    const size_t total = (size_t)nchunks * outPad * KC;
+    hipLaunchKernelGGL(pack_weights_strided_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, w, so, sr,
+                       wp, O, R, nchunks, outPad, total);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
 }
 
 extern "C" int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream) {

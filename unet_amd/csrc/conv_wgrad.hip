@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const WArgs a) {
                         if constexpr (M1) acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1][t], 0, 0, 0);
                     }
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     using T1 = std::true_type;
@@ -290,12 +291,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const WArgs a) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
         }
+#ifdef UNET_WGRAD16_NOSKIP
+        compute(T1{}, T1{});
+#else
         if (mv0 && nv0) {            // (a wave whose first tile is empty has nothing to do)
             if (mv1 && nv1) compute(T1{}, T1{});
             else if (mv1) compute(T1{}, T0{});
             else if (nv1) compute(T0{}, T1{});
             else compute(T0{}, T0{});
         }
+#endif
         __syncthreads();
     }
 

@@ -634,6 +634,51 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------- row softmax (self-attention)
+// y[p][:] = softmax(x[p][:]) over C contiguous channels; one workgroup per row, wavefront + LDS reductions.
+__device__ __forceinline__ float block_reduce(float v, bool is_max) {
+    __shared__ float sh[4];
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+                                                          int y_co, long long P, int C) {
+    for (long long p = blockIdx.x; p < P; p += gridDim.x) {
+        const float* xr = x + (size_t)p * x_cs + x_co;
+        float* yr = y + (size_t)p * y_cs + y_co;
+        float m = -INFINITY;
+        for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, xr[c]);
+        m = block_reduce(m, true);
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += expf(xr[c] - m);
+        s = block_reduce(s, false);
+        const float inv = 1.f / s;
+        for (int c = threadIdx.x; c < C; c += 256) yr[c] = expf(xr[c] - m) * inv;
+    }
+}
+
+// dx[p][c] = y[p][c] * (dy[p][c] - sum_c' y[p][c'] dy[p][c'])
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __restrict__ y, int y_cs, int y_co, const float* __restrict__ dy,
+                                                              int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co,
+                                                              long long P, int C) {
+    for (long long p = blockIdx.x; p < P; p += gridDim.x) {
+        const float* yr = y + (size_t)p * y_cs + y_co;
+        const float* gr = dy + (size_t)p * dy_cs + dy_co;
+        float* dr = dx + (size_t)p * dx_cs + dx_co;
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += yr[c] * gr[c];
+        s = block_reduce(s, false);
+        for (int c = threadIdx.x; c < C; c += 256) dr[c] = yr[c] * (gr[c] - s);
+    }
+}
+
 // ----------------------------------------------------------------- Adam
 struct AdamArgs {
     float decay[4];     // 1 - lr*wd per group
@@ -948,6 +993,22 @@ extern "C" int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, in
     UNET_CHECK_ARG(z && N > 0 && H > 0 && W > 0 && C > 0 && C <= CE_MAXC && z_co + C <= z_cs, "softmax_argmax: bad args");
     hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, z, z_cs, z_co, N, (long long)H * W, C,
                        probs_nchw, argmax);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_row_softmax(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, void* stream) {
+    UNET_CHECK_ARG(x && y && P > 0 && C > 0 && x_co + C <= x_cs && y_co + C <= y_cs, "row_softmax: bad args");
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_row_softmax_bwd(const float* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs,
+                                    int dx_co, long long P, int C, void* stream) {
+    UNET_CHECK_ARG(y && dy && dx && P > 0 && C > 0 && y_co + C <= y_cs && dy_co + C <= dy_cs && dx_co + C <= dx_cs, "row_softmax_bwd: bad args");
+    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, y, y_cs, y_co, dy, dy_cs, dy_co, dx,
+                       dx_cs, dx_co, P, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

@@ -54,12 +54,14 @@ class HipDynamicUnet(nn.Module):
         middle = nn.Sequential(ConvLayer(ni, ni * 2, norm=None), ConvLayer(ni * 2, ni, norm=None))
         layers: List[nn.Module] = [enc, post_bn, nn.ReLU(), middle]
         xc = ni
+        prev_sa = False
         for i, idx in enumerate(self.sz_chg_idxs):
             not_final = i != len(self.sz_chg_idxs) - 1
             sa = self_attention and (i == len(self.sz_chg_idxs) - 3)
-            blk = UnetBlock(xc, enc.skip_channels[idx], final_div=not_final, blur=True, self_attention=sa)
+            blk = UnetBlock(xc, enc.skip_channels[idx], final_div=not_final, blur=True, self_attention=sa, up_is_relu=not prev_sa)
             layers.append(blk)
             xc = blk.out_channels
+            prev_sa = sa
         layers.append(PixelShuffle_ICNR(xc))
         layers.append(_Marker("ResizeToOrig"))
         layers.append(_Marker("MergeLayer(dense=True)"))

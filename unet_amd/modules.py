@@ -171,7 +171,7 @@ class ConvLayer(nn.Sequential):
     """conv [-> BN] [-> ReLU]; norm 'batch' | 'batchzero' (encoder) or None (decoder: bias, no norm)."""
     forward = _no_forward
 
-    def __init__(self, ni, nf, ks=3, stride=1, norm: Optional[str] = "batch", act=True, bias_std=0.01):
+    def __init__(self, ni, nf, ks=3, stride=1, norm: Optional[str] = "batch", act=True, bias_std=0.01, xtra: Optional[nn.Module] = None):
         bn = norm in ("batch", "batchzero")
         conv = nn.Conv2d(ni, nf, ks, stride=stride, padding=(ks - 1) // 2, bias=not bn)
         with torch.no_grad():
@@ -188,6 +188,8 @@ class ConvLayer(nn.Sequential):
             layers.append(b)
         if act:
             layers.append(nn.ReLU())
+        if xtra is not None:
+            layers.append(xtra)
         super().__init__(*layers)
         self.has_bn, self.has_act = bn, act
         self.cx = _ConvExec(conv)
@@ -367,8 +369,9 @@ class PixelShuffle_ICNR(nn.Sequential):
             ops.shuffle_blur(yc, tmp, self.blur)
             ops.resize_nearest(tmp, dst)
 
-    def hip_bwd(self, ctx: Ctx, d_dst: TS) -> TS:
-        """d_dst = dL/d(dst slice).  Returns dL/d(pre-activation of the producer of up_in) (masked)."""
+    def hip_bwd(self, ctx: Ctx, d_dst: TS, mask_input: bool = True) -> TS:
+        """d_dst = dL/d(dst slice).  Returns dL/d(pre-activation of the producer of up_in) (masked by up_in > 0 when up_in is
+        a ReLU output, i.e. mask_input)."""
         cl: ConvLayer = self[0]
         up_in: TS = ctx.saved[(id(cl), "x")]
         yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
@@ -379,7 +382,7 @@ class PixelShuffle_ICNR(nn.Sequential):
             tmp = ctx.act(self, "dup", up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
             ops.resize_nearest_bwd(d_dst, tmp)
             ops.shuffle_blur_bwd(tmp, yc, dyc, self.blur)
-        return cl.bwd_from_dy(ctx, dyc, mask=up_in)
+        return cl.bwd_from_dy(ctx, dyc, mask=up_in if mask_input else None)
 
 
 def icnr_init(x: torch.Tensor, scale=2, init=nn.init.kaiming_normal_) -> torch.Tensor:
@@ -389,6 +392,115 @@ def icnr_init(x: torch.Tensor, scale=2, init=nn.init.kaiming_normal_) -> torch.T
     k = k.contiguous().view(ni2, nf, -1).repeat(1, 1, scale ** 2)
     return k.contiguous().view([nf, ni, h, w]).transpose(0, 1)
 
+
+
+# --------------------------------------------------------------------------
+# fastai layers.py: SelfAttention (DynamicUnet(self_attention=True): params_and_main.py:81-83, train.py:141-144)
+# --------------------------------------------------------------------------
+
+class SelfAttention(nn.Module):
+    """x -> gamma * (h beta) + x with f,g,h = spectral-normed 1x1 projections, beta = softmax(f^T g, dim=1).
+
+    Device program (NHWC, rows = positions): QKV = X [Wq;Wk;Wv]^T in ONE 1x1 conv; per image b the N x N products run on the
+    MFMA conv / wgrad kernels with operands packed from activations (unet_pack_weights_strided):
+        T[j][i] = sum_c G[j][c] F[i][c]      (= S^T)          P = row-softmax(T)  (= beta^T)
+        O[j][c] = sum_i P[j][i] H[i][c]                        out = gamma * O + X
+    Spectral normalisation (legacy torch.nn.utils.spectral_norm: one power iteration per training forward) acts on three
+    tiny matrices and stays in torch; its backward is torch autograd on those matrices, fed with the HIP weight gradient."""
+    forward = _no_forward
+
+    def __init__(self, n_channels):
+        super().__init__()
+        c8 = n_channels // 8
+        self.query = nn.Sequential(nn.utils.spectral_norm(nn.Conv1d(n_channels, c8, 1, bias=False)))
+        self.key = nn.Sequential(nn.utils.spectral_norm(nn.Conv1d(n_channels, c8, 1, bias=False)))
+        self.value = nn.Sequential(nn.utils.spectral_norm(nn.Conv1d(n_channels, n_channels, 1, bias=False)))
+        self.gamma = nn.Parameter(torch.tensor([0.0]))
+        self.C, self.c8 = n_channels, c8
+        assert c8 % 4 == 0, "self-attention needs n_channels divisible by 32"
+
+    @staticmethod
+    def _normed_weight(seq: nn.Sequential) -> torch.Tensor:
+        m = seq[0]
+        for hook in m._forward_pre_hooks.values():      # SpectralNorm.__call__: power iteration (training) + W / sigma
+            hook(m, None)
+        return m.weight
+
+    def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
+        B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
+        N, CQ = H * W, 2 * c8 + C_
+        dev = x.buf.device
+        with torch.enable_grad():
+            wcat = torch.cat([self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)], 0)
+            wcat = wcat.reshape(CQ, C_, 1, 1)
+        ctx.saved[(id(self), "wcat")] = wcat
+        wq = wcat.detach().contiguous()
+        wp = ctx.vec(self, "wp_f", ops.lib.unet_pack_weights_size(CQ, C_, 1, 0))
+        ops.pack_weights(wq, 0, wp)
+        qkv = ctx.act(self, "qkv", B, H, W, CQ)
+        ops.conv2d(x, wp, qkv, 1)
+        T = ctx.act(self, "T", B, H, W, N)
+        wpa = ctx.vec(self, "wp_a", max(ops.lib.unet_pack_weights_size(N, max(c8, C_), 1, 0), ops.lib.unet_pack_weights_size(C_, N, 1, 0)))
+        img = N * CQ * 4      # bytes per image of qkv
+        for b in range(B):
+            ops.pack_weights_strided(qkv.ptr + b * img, CQ, 1, N, c8, wpa)                       # (o=i, r=c) = F_b[i][c]
+            ops.conv2d(TS(qkv.buf[b:b + 1], c8, c8), wpa, TS(T.buf[b:b + 1], 0, N), 1)           # T_b = G_b F_b^T
+        P = ctx.act(self, "P", B, H, W, N)
+        ops.row_softmax(T, P)
+        O = ctx.act(self, "O", B, H, W, C_)
+        for b in range(B):
+            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, 1, CQ, C_, N, wpa)              # (o=c, r=i) = H_b[i][c]
+            ops.conv2d(TS(P.buf[b:b + 1], 0, N), wpa, TS(O.buf[b:b + 1], 0, C_), 1)              # O_b = P_b H_b
+        gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
+        gvec.copy_(self.gamma.data.expand(C_))
+        out = ctx.act(self, "out", B, H, W, C_)
+        ops.affine_act(O, out, gvec, zvec, x2=x)
+        ctx.saved[(id(self), "x")] = x
+        return out
+
+    def hip_bwd(self, ctx: Ctx, dout: TS) -> TS:
+        """dout = dL/d(out).  Returns dL/dx."""
+        x: TS = ctx.saved[(id(self), "x")]
+        B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
+        N, CQ = H * W, 2 * c8 + C_
+        qkv, P, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "P", B, H, W, N), ctx.act(self, "O", B, H, W, C_)
+        gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
+        self.gamma.grad.copy_((O.view() * dout.view()).sum().reshape(1))
+        dO = ctx.act(self, "dO", B, H, W, C_)
+        ops.affine_act(dout, dO, gvec, zvec)
+        dqkv = ctx.act(self, "dqkv", B, H, W, CQ)
+        dP = ctx.act(self, "dP", B, H, W, N)
+        wpa = ctx.vec(self, "wp_a", max(ops.lib.unet_pack_weights_size(N, max(c8, C_), 1, 0), ops.lib.unet_pack_weights_size(C_, N, 1, 0)))
+        tmp = ctx.vec(self, "tmp", N * C_)
+        img = N * CQ * 4
+        for b in range(B):
+            dO_b, P_b = TS(dO.buf[b:b + 1], 0, C_), TS(P.buf[b:b + 1], 0, N)
+            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, CQ, 1, N, C_, wpa)              # (o=i, r=c) = H_b[i][c]
+            ops.conv2d(dO_b, wpa, TS(dP.buf[b:b + 1], 0, N), 1)                                   # dP_b = dO_b H_b^T
+            n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
+            ops.conv2d_wgrad(dO_b, P_b, tmp, 1, 1, ctx.workspace(n))                              # dH_b = P_b^T dO_b  -> [N][C]
+            ops.copy_slice(TS(tmp[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8, C_))
+        ops.row_softmax_bwd(P, dP, dP)                                                            # dT in place
+        for b in range(B):
+            dT_b, G_b = TS(dP.buf[b:b + 1], 0, N), TS(qkv.buf[b:b + 1], c8, c8)
+            ops.pack_weights_strided(qkv.ptr + b * img, 1, CQ, c8, N, wpa)                       # (o=c, r=i) = F_b[i][c]
+            ops.conv2d(dT_b, wpa, TS(dqkv.buf[b:b + 1], c8, c8), 1)                               # dG_b = dT_b F_b
+            n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
+            ops.conv2d_wgrad(G_b, dT_b, tmp, 1, 1, ctx.workspace(n))                              # dF_b = dT_b^T G_b -> [N][c8]
+            ops.copy_slice(TS(tmp[:N * c8].view(1, H, W, c8), 0, c8), TS(dqkv.buf[b:b + 1], 0, c8))
+        # back through the fused QKV projection
+        wcat: torch.Tensor = ctx.saved[(id(self), "wcat")]
+        dw = ctx.vec(self, "dwcat", CQ * C_).view(CQ, C_, 1, 1)
+        n = ops.wgrad_workspace(x, dqkv, 1, 1)
+        ops.conv2d_wgrad(x, dqkv, dw, 1, 1, ctx.workspace(n))
+        wpd = ctx.vec(self, "wp_d", ops.lib.unet_pack_weights_size(CQ, C_, 1, 1))
+        ops.pack_weights(wcat.detach().contiguous(), 1, wpd)
+        dx = ctx.act(self, "dx", B, H, W, C_)
+        ops.conv2d_dgrad(dqkv, wpd, dx, 1, 1, res=dout)                                           # + identity branch
+        for seq in (self.query, self.key, self.value):
+            seq[0].weight_orig.grad.zero_()
+        wcat.backward(dw)                                                                         # spectral-norm backward (torch, tiny)
+        return dx
 
 # --------------------------------------------------------------------------
 # decoder blocks (vision/models/unet.py)
@@ -404,10 +516,8 @@ def _bias_relu_layer_fwd(ctx: Ctx, cl: ConvLayer, x: TS) -> TS:
 class UnetBlock(nn.Module):
     forward = _no_forward
 
-    def __init__(self, up_in_c, x_in_c, final_div=True, blur=True, self_attention=False):
+    def __init__(self, up_in_c, x_in_c, final_div=True, blur=True, self_attention=False, up_is_relu=True):
         super().__init__()
-        if self_attention:
-            raise NotImplementedError("self_attention=True is not built yet on the HIP path (SURVEY.md A12)")
         self.shuf = PixelShuffle_ICNR(up_in_c, up_in_c // 2, blur=blur)
         self.bn = nn.BatchNorm2d(x_in_c, eps=BN_EPS, momentum=BN_MOM)
         with torch.no_grad():
@@ -415,11 +525,15 @@ class UnetBlock(nn.Module):
         ni = up_in_c // 2 + x_in_c
         nf = ni if final_div else ni // 2
         self.conv1 = ConvLayer(ni, nf, norm=None)
-        self.conv2 = ConvLayer(nf, nf, norm=None)
+        self.conv2 = ConvLayer(nf, nf, norm=None, xtra=SelfAttention(nf) if self_attention else None)
         self.relu = nn.ReLU()
-        _kaiming_init(self.conv1, self.conv2)
+        _kaiming_init(self.conv1, self.conv2[0])
         self.cu, self.cs, self.ni, self.out_channels = up_in_c // 2, x_in_c, ni, nf
         self.bx = _BNExec(self.bn)
+        self.__dict__["sa"] = self.conv2[2] if self_attention else None
+        # is the tensor this block up-samples a ReLU output (then the ReLU backward is fused as a dgrad mask)?  Not when the
+        # previous block ends in self-attention.
+        self.up_is_relu = up_is_relu
 
     def hip_fwd(self, ctx: Ctx, up_in: TS, s: TS) -> TS:
         X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
@@ -428,19 +542,26 @@ class UnetBlock(nn.Module):
         ops.affine_act(s, X.sub(self.cu, self.cs), scale, shift, relu=True)
         ctx.saved[(id(self), "s")] = s
         t1 = _bias_relu_layer_fwd(ctx, self.conv1, X)
-        return _bias_relu_layer_fwd(ctx, self.conv2, t1)
+        t2 = _bias_relu_layer_fwd(ctx, self.conv2, t1)
+        return t2 if self.sa is None else self.sa.hip_fwd(ctx, t2)
 
     def hip_bwd(self, ctx: Ctx, dt2_pre: TS, dskip: TS, dskip_accumulate: bool) -> TS:
-        """dt2_pre = masked gradient w.r.t. conv2's pre-activation.  Writes dL/d(skip) into dskip and returns the
-        masked gradient w.r.t. the pre-activation of the producer of up_in."""
+        """dt2_pre = masked gradient w.r.t. conv2's pre-activation (or, when the block ends in self-attention, the plain
+        gradient w.r.t. the block output).  Writes dL/d(skip) into dskip and returns the gradient for the producer of up_in
+        (masked by its ReLU when up_is_relu)."""
         s: TS = ctx.saved[(id(self), "s")]
         X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
         t1: TS = ctx.saved[(id(self.conv2), "x")]
+        if self.sa is not None:
+            t2 = ctx.act(self.conv2, "a", s.N, s.H, s.W, self.out_channels)
+            d_t2 = self.sa.hip_bwd(ctx, dt2_pre)
+            dt2_pre = ctx.act(self, "dt2", s.N, s.H, s.W, self.out_channels)
+            ops.relu_mask(d_t2, t2, dt2_pre)
         dt1 = self.conv2.bwd_from_dy(ctx, dt2_pre, mask=t1)
         dX = self.conv1.bwd_from_dy(ctx, dt1, mask=X)          # relu(cat) backward fused
         assert not dskip_accumulate
         self.bx.bwd(ctx, dX.sub(self.cu, self.cs), None, s, dskip)
-        return self.shuf.hip_bwd(ctx, dX.sub(0, self.cu))
+        return self.shuf.hip_bwd(ctx, dX.sub(0, self.cu), mask_input=self.up_is_relu)
 
 
 def _kaiming_init(*mods):

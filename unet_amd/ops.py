@@ -89,6 +89,21 @@ def pack_weights(w: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None)
     return out
 
 
+def pack_weights_strided(w_base_ptr: int, so: int, sr: int, O: int, R: int, out: torch.Tensor) -> torch.Tensor:
+    """packed 1x1 filter image whose (out o, reduction r) element is the float at w_base_ptr + 4*(o*so + r*sr)"""
+    assert out.numel() >= lib.unet_pack_weights_size(O, R, 1, 0)
+    check(lib.unet_pack_weights_strided(w_base_ptr, so, sr, out.data_ptr(), O, R, _stream()), "pack_weights_strided")
+    return out
+
+
+def row_softmax(x: "TS", y: "TS"):
+    check(lib.unet_row_softmax(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, _stream()), "row_softmax")
+
+
+def row_softmax_bwd(y: "TS", dy: "TS", dx: "TS"):
+    check(lib.unet_row_softmax_bwd(y.ptr, y.cs, y.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, y.P, y.C, _stream()), "row_softmax_bwd")
+
+
 def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, bias=None, res: Optional[TS] = None,
                mask: Optional[TS] = None, relu=False, colsum=None, colsumsq=None) -> ConvDesc:
     d = ConvDesc()
