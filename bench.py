@@ -5,9 +5,9 @@ DynamicUnet (BASELINE.json configs[1]: batch 16 per MI355X; configs[2]: the same
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0.  `value` = tiles processed by all ranks / wall time of the K timed steps (max over
-ranks), inputs resident in HBM.  `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM 3x3 conv, the
-100->100 @512x512 layer of the final ResBlock): algorithmic FLOPs of that launch / its mean duration measured
-with events on the launch stream inside the timed region.  `cpu_baseline` = the torch-CPU oracle of the same step
+ranks), inputs resident in HBM.  `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv,
+all launches of its main instantiation: forward and input-gradient of every wide layer): summed algorithmic FLOPs /
+summed launch durations measured with events on the launch stream inside the timed region.  `cpu_baseline` = the torch-CPU oracle of the same step
 on this host's cores, on a bounded sample (rank 0, N=1 only).
 """
 from __future__ import annotations
@@ -109,7 +109,7 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     from unet_amd import ops as _ops
-    DOMINANT = 32 * 10000 + 128 * 10 + 0    # conv_igemm_kernel<32,2,2,2,2,4>: all wide 3x3 / 1x1 convs, fwd and dgrad
+    DOMINANT = 32 * 10000 + 128 * 10 + 0    # conv_igemm16_kernel<32,2,2,2,2,4>: all wide 3x3 / 1x1 convs, fwd and dgrad
     log(f"model ready: {sum(p.numel() for p in model.parameters())} params, batch {args.batch}/gpu, world {world}")
     for i in range(args.warmup):
         step(x, y)
@@ -143,7 +143,7 @@ def main():
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"      # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
         if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("conv_igemm_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch")
+            traffic = json.loads(pmc.read_text()).get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "512x512 tiles/sec fwd+bwd (4-ch->5-class U-Net)", "value": round(value, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -154,7 +154,7 @@ def main():
             "loss": round(float(loss.item()), 5),
             "step_tflops": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
             "step_frac_of_f32_peak": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3 / (PEAK_F32_TFLOPS * world), 4),
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<32,2,2,2,2,4> (fp32-MFMA implicit GEMM: every wide 3x3/1x1 "
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
                                                      "conv, forward and input-gradient)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,

@@ -216,6 +216,15 @@ int unet_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* 
                    const float* lr /*[4] host*/, float mom, float sqr_mom, float eps, float wd, int step,
                    float grad_scale, void* stream);
 
+/* hipGraph-friendly form: the hyper-parameter block (unet_adam_hyper_floats() floats, filled on the host by
+ * unet_adam_fill_hyper and copied to the device by the caller before each replay) is read from device memory, so a captured
+ * step can be replayed with a new lr / momentum / step count. */
+int unet_adam_hyper_floats(void);
+int unet_adam_fill_hyper(float* hyper_host, const float* lr /*[4]*/, float mom, float sqr_mom, float eps, float wd, int step,
+                         float grad_scale);
+int unet_adam_step_dev(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n,
+                       const float* hyper_dev, void* stream);
+
 /* ------------------------------------------------- overlap-merge (predict) --
  * predict.py:284-326: sum softmax probabilities of overlapping tiles into a
  * mosaic + hit counter, divide, argmax. */

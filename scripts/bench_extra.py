@@ -11,31 +11,32 @@ def synth(b, c, s, ncls, seed=1):
     return (torch.randint(0, 256, (b, c, s, s), generator=g).float() / 255).cuda(), torch.randint(0, ncls, (b, s, s), generator=g).cuda()
 
 
-def train_rate(arch, c, ncls, s, b, sa=False, steps=4):
+def train_rate(arch, c, ncls, s, b, sa=False, steps=4, graph=False):
     torch.manual_seed(0)
     m = HipDynamicUnet(arch, c, ncls, (s, s), self_attention=sa); m.train()
-    opt = FlatAdam(m, [1e-5, 3e-5, 1e-4]); st = TrainStep(m, opt, torch.full((ncls,), 1.0 / ncls, device='cuda'))
+    opt = FlatAdam(m, [1e-5, 3e-5, 1e-4]); st = TrainStep(m, opt, torch.full((ncls,), 1.0 / ncls, device='cuda'), use_graph=graph)
     x, y = synth(b, c, s, ncls)
-    for _ in range(2): st(x, y)
+    for _ in range(4): st(x, y)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): st(x, y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    r = {"what": f"train {arch} {c}ch {s}x{s} {ncls}cls B={b} sa={sa}", "ms_per_step": round(dt * 1e3, 2), "tiles_per_s": round(b / dt, 2),
+    r = {"what": f"train {arch} {c}ch {s}x{s} {ncls}cls B={b} sa={sa} graph={graph}", "ms_per_step": round(dt * 1e3, 2), "tiles_per_s": round(b / dt, 2),
          "mem_GB": round(m.memory_bytes() / 2**30, 2)}
     print(json.dumps(r), flush=True)
     del m, opt, st
     torch.cuda.empty_cache()
 
 
-def predict_rate(arch, c, ncls, s, b, steps=5):
+def predict_rate(arch, c, ncls, s, b, steps=5, graph=False):
     torch.manual_seed(0)
     m = HipDynamicUnet(arch, c, ncls, (s, s)); m.eval()
     x, _ = synth(b, c, s, ncls)
-    for _ in range(2): m.predict_probs(x)
+    f = m.predict_probs_graphed if graph else m.predict_probs
+    for _ in range(3): f(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps): m.predict_probs(x)
+    for _ in range(steps): f(x)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"what": f"predict {arch} {c}ch {s}x{s} B={b} (eval fwd + softmax + argmax)", "ms_per_batch": round(dt * 1e3, 2),
+    print(json.dumps({"what": f"predict {arch} {c}ch {s}x{s} B={b} graph={graph} (eval fwd + softmax + argmax)", "ms_per_batch": round(dt * 1e3, 2),
                       "tiles_per_s": round(b / dt, 2), "fwd_TFLOPs": round(b / dt * 255.846 / 1e3, 1) if arch == 'xresnet34' and s == 512 else None}), flush=True)
     del m
     torch.cuda.empty_cache()
@@ -45,5 +46,9 @@ which = sys.argv[1:] or ["sa", "predict", "cfg1", "cfg4"]
 if "sa" in which: train_rate("xresnet34", 4, 5, 512, 16, sa=True)
 if "predict" in which:
     predict_rate("xresnet34", 4, 5, 512, 16); predict_rate("xresnet34", 4, 5, 512, 1)
-if "cfg1" in which: train_rate("xresnet18", 3, 2, 256, 2)
+if "cfg1" in which:
+    train_rate("xresnet18", 3, 2, 256, 2, steps=20); train_rate("xresnet18", 3, 2, 256, 2, steps=20, graph=True)
+if "graph" in which:
+    predict_rate("xresnet34", 4, 5, 512, 1, steps=20); predict_rate("xresnet34", 4, 5, 512, 1, steps=20, graph=True)
+    train_rate("xresnet34", 4, 5, 512, 16, graph=True)
 if "cfg4" in which: train_rate("xresnet50", 8, 10, 1024, 2, steps=2)

@@ -269,3 +269,45 @@ def test_self_attention_forward_and_gradients(size, bs):
     for (n, b), (_, b2) in zip(model.named_buffers(), ref.named_buffers()):
         if "weight_u" in n or "weight_v" in n:
             assert (b.cpu() - b2).abs().max().item() < 1e-5, n
+
+
+def test_hipgraph_step_and_predict_match_eager():
+    """A captured + replayed training step (incl. the device-side Adam hyper-parameters following a changing lr / momentum)
+    and a captured predict give exactly what the eager launch stream gives."""
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    torch.manual_seed(11)
+    ref = O.DynamicUnet("xresnet18", 4, 5, (64, 64))
+    sd = ref.state_dict()
+    xs = [O.synthetic_batch(2, 4, 64, 64, 5, seed=s) for s in range(6)]
+    outs = []
+    for use_graph in (False, True):
+        model = HipDynamicUnet("xresnet18", 4, 5, (64, 64))
+        model.load_state_dict(sd)
+        model.train()
+        opt = FlatAdam(model, [1e-4, 3e-4, 1e-3])
+        step = TrainStep(model, opt, None, 1, use_graph=use_graph)
+        losses = []
+        for i, (x, y) in enumerate(xs):
+            opt.set_lr([1e-4 * (i + 1), 3e-4, 1e-3 / (i + 1)])
+            opt.mom = 0.95 - 0.01 * i
+            losses.append(step(x.cuda(), y.cuda()).clone())
+        torch.cuda.synchronize()
+        assert (step._graph is not None) == use_graph
+        outs.append((torch.stack(losses).cpu(), model.flat_param.clone().cpu(), model))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7), (outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-6
+    model = outs[1][2]
+    model.eval()
+    x = xs[0][0].cuda()
+    p0, a0 = model.predict_probs(x)
+    p0, a0 = p0.clone(), a0.clone()
+    for _ in range(2):
+        p1, a1 = model.predict_probs_graphed(x)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(a0, a1)
+    x2 = xs[1][0].cuda()
+    p2, _ = model.predict_probs_graphed(x2)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, model.predict_probs(x2)[0])

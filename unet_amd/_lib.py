@@ -118,6 +118,9 @@ _sig = {
     "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),
     "unet_softmax_argmax": (i, [vp, i, i, i, i, i, i, vp, vp, vp]),
     "unet_adam_step": (i, [vp, vp, vp, vp, vp, ll, c_float_p, f, f, f, f, i, f, vp]),
+    "unet_adam_hyper_floats": (i, []),
+    "unet_adam_fill_hyper": (i, [c_float_p, c_float_p, f, f, f, f, i, f]),
+    "unet_adam_step_dev": (i, [vp, vp, vp, vp, vp, ll, vp, vp]),
     "unet_mosaic_accumulate": (i, [vp, i, i, i, vp, vp, i, i, i, i, vp]),
     "unet_mosaic_finalize": (i, [vp, vp, i, i, i, vp, vp]),
 }

@@ -686,6 +686,26 @@ struct AdamArgs {
     float mom, one_minus_mom, sqr_mom, one_minus_sqr, debias2, eps, grad_scale;
 };
 
+// hyper-parameters read from DEVICE memory (hipGraph replay: the host refreshes the 15 floats before each replay)
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, const uint8_t* __restrict__ code, long long n,
+                                                       const AdamArgs* __restrict__ ap) {
+    const AdamArgs a = *ap;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int cd = code[i];
+        const int grp = cd & 3;
+        float pv = p[i];
+        const float gv = g[i] * a.grad_scale;
+        if (cd & 4) pv *= a.decay[grp];
+        const float mv = m[i] * a.mom + a.one_minus_mom * gv;
+        const float vv = v[i] * a.sqr_mom + a.one_minus_sqr * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float den = sqrtf(vv / a.debias2) + a.eps;
+        p[i] = pv + a.step_size[grp] * (mv / den);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const uint8_t* __restrict__ code, long long n, AdamArgs a) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -1013,10 +1033,28 @@ extern "C" int unet_row_softmax_bwd(const float* y, int y_cs, int y_co, const fl
     return UNET_OK;
 }
 
-extern "C" int unet_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n, const float* lr, float mom,
-                              float sqr_mom, float eps, float wd, int step, float grad_scale, void* stream) {
-    UNET_CHECK_ARG(p && g && m && v && code && lr && n > 0 && step >= 1, "adam_step: bad args");
-    AdamArgs a;
+static void fill_adam_args(AdamArgs& a, const float* lr, float mom, float sqr_mom, float eps, float wd, int step, float grad_scale);
+
+extern "C" int unet_adam_hyper_floats(void) { return (int)(sizeof(AdamArgs) / sizeof(float)); }
+
+/* host helper: the hyper-parameter block unet_adam_step_dev reads from device memory */
+extern "C" int unet_adam_fill_hyper(float* hyper_host, const float* lr, float mom, float sqr_mom, float eps, float wd, int step,
+                                    float grad_scale) {
+    UNET_CHECK_ARG(hyper_host && lr && step >= 1, "adam_fill_hyper: bad args");
+    fill_adam_args(*reinterpret_cast<AdamArgs*>(hyper_host), lr, mom, sqr_mom, eps, wd, step, grad_scale);
+    return UNET_OK;
+}
+
+extern "C" int unet_adam_step_dev(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n, const float* hyper_dev,
+                                  void* stream) {
+    UNET_CHECK_ARG(p && g && m && v && code && hyper_dev && n > 0, "adam_step_dev: bad args");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST, p, g, m, v, code, n,
+                       reinterpret_cast<const AdamArgs*>(hyper_dev));
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+static void fill_adam_args(AdamArgs& a, const float* lr, float mom, float sqr_mom, float eps, float wd, int step, float grad_scale) {
     const double debias1 = 1.0 - pow((double)mom, (double)step);
     const double debias2 = 1.0 - pow((double)sqr_mom, (double)step);
     for (int i = 0; i < 4; ++i) {
@@ -1026,10 +1064,18 @@ extern "C" int unet_adam_step(float* p, const float* g, float* m, float* v, cons
     a.mom = mom; a.one_minus_mom = (float)(1.0 - (double)mom);
     a.sqr_mom = sqr_mom; a.one_minus_sqr = (float)(1.0 - (double)sqr_mom);
     a.debias2 = (float)debias2; a.eps = eps; a.grad_scale = grad_scale;
+}
+
+extern "C" int unet_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* code, long long n, const float* lr, float mom,
+                              float sqr_mom, float eps, float wd, int step, float grad_scale, void* stream) {
+    UNET_CHECK_ARG(p && g && m && v && code && lr && n > 0 && step >= 1, "adam_step: bad args");
+    AdamArgs a;
+    fill_adam_args(a, lr, mom, sqr_mom, eps, wd, step, grad_scale);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST, p, g, m, v, code, n, a);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+
 
 extern "C" int unet_mosaic_accumulate(const float* probs_nchw, int C, int th, int tw, float* mosaic, int32_t* count, int MH, int MW, int y0,
                                       int x0, void* stream) {

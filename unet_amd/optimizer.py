@@ -62,6 +62,10 @@ class FlatAdam:
         self.code = torch.from_numpy(code).to(dev)
         self.step_count = 0
         self.grad_scale = 1.0
+        # hipGraph mode: hyper-parameters live in a device block refreshed by the host before each replay
+        nh = ops.lib.unet_adam_hyper_floats()
+        self._hyper_host = torch.zeros(nh, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(nh)
+        self._hyper_dev = torch.zeros(nh, dtype=torch.float32, device=dev)
 
     def set_lr(self, lr):
         k = len(self.groups)
@@ -73,6 +77,23 @@ class FlatAdam:
         m = self.model
         ops.adam_step(m.flat_param, m.flat_grad, self.grad_avg, self.sqr_avg, self.code, self.lrs, self.mom, self.sqr_mom,
                       self.eps, self.wd, self.step_count, self.grad_scale)
+        m.mark_weights_dirty()
+
+    def upload_hyper(self, step: int):
+        """host -> device copy of (lr, momentum, de-bias terms ...) for step number `step` (stream ordered, no sync)"""
+        import ctypes as C
+        arr = (C.c_float * 4)(*(self.lrs + [0.0] * (4 - len(self.lrs))))
+        hp = C.cast(self._hyper_host.data_ptr(), C.POINTER(C.c_float))
+        ops.check(ops.lib.unet_adam_fill_hyper(hp, arr, float(self.mom), float(self.sqr_mom), float(self.eps), float(self.wd), int(step),
+                                               float(self.grad_scale)), "adam_fill_hyper")
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def step_from_device_hyper(self):
+        """the launch that gets captured in a hipGraph: every hyper-parameter is read from self._hyper_dev"""
+        m = self.model
+        ops.check(ops.lib.unet_adam_step_dev(m.flat_param.data_ptr(), m.flat_grad.data_ptr(), self.grad_avg.data_ptr(),
+                                             self.sqr_avg.data_ptr(), self.code.data_ptr(), m.flat_param.numel(),
+                                             self._hyper_dev.data_ptr(), ops._stream()), "adam_step_dev")
         m.mark_weights_dirty()
 
     def zero_grad(self):

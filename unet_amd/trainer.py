@@ -15,18 +15,56 @@ from .optimizer import FlatAdam
 
 
 class TrainStep:
+    """use_graph=True (single GPU): after two eager warm-up calls the whole step -- ~700 launches -- is captured once in a
+    hipGraph (torch.cuda.CUDAGraph on the launch stream) and replayed; inputs are copied into static buffers and the Adam
+    hyper-parameters (lr, momentum, step count) are refreshed in a device block before each replay.  Pays when the step is
+    launch-bound (small tiles / small batches: BASELINE configs[0]); at batch 16 of 512x512 tiles the GPU is never idle."""
+
     def __init__(self, model: HipDynamicUnet, opt: FlatAdam, class_weights: Optional[torch.Tensor] = None, world: int = 1,
-                 max_bucket_elems: int = 16 << 20):
+                 max_bucket_elems: int = 16 << 20, use_graph: bool = False):
         self.model, self.opt, self.world = model, opt, world
         self.weights = class_weights
+        self.use_graph = use_graph and world == 1
+        self._graph = None
+        self._calls = 0
+        self._xs = self._ys = self._loss = None
         self.reducer: Optional[GradReducer] = None
         if world > 1:
             bounds = [model._decoder_offset] + list(model._enc_child_offset.values())
             self.reducer = GradReducer(model.flat_grad, bounds, max_bucket_elems)
             model.grad_ready_hook = self.reducer.ready_down_to
 
+    def _graphed(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        m, opt = self.model, self.opt
+        if self._graph is not None and (tuple(x.shape) != tuple(self._xs.shape)):
+            self._graph = None                      # new geometry: re-capture
+            self._calls = 0
+        if self._graph is None:
+            if self._calls < 2:                     # eager warm-up: allocates every persistent buffer / workspace
+                self._calls += 1
+                loss = m.forward_loss_backward(x, y, self.weights, grad_scale=1.0)
+                opt.step()
+                return loss
+            self._xs = x.to(m._device, torch.float32).clone()
+            self._ys = y.to(m._device, torch.int64).clone()
+            opt.upload_hyper(opt.step_count + 1)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._loss = m.forward_loss_backward(self._xs, self._ys, self.weights, grad_scale=1.0)
+                opt.step_from_device_hyper()
+            # (the capture itself does not execute the step)
+        self._xs.copy_(x, non_blocking=True)
+        self._ys.copy_(y, non_blocking=True)
+        opt.step_count += 1
+        opt.upload_hyper(opt.step_count)
+        self._graph.replay()
+        return self._loss
+
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """x [B,C,H,W] fp32, y [B,H,W] int64 (device tensors).  Returns the (rank-local) loss as a device scalar."""
+        if self.use_graph:
+            return self._graphed(x, y)
         if self.reducer is not None:
             self.reducer.reset()
         loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0 / self.world)
