@@ -12,14 +12,14 @@ g = torch.Generator().manual_seed(1)
 x = (torch.randint(0, 256, (16, 4, 512, 512), generator=g).float() / 255).cuda(); y = torch.randint(0, 5, (16, 512, 512), generator=g).cuda()
 for _ in range(2): step(x, y)
 torch.cuda.synchronize()
-res = {16: [], 32: []}
+res = {0: [], 1: []}
 for rnd in range(4):
-    for shape in (16, 32):
-        lib.unet_set_wgrad_mfma_shape(shape)
+    for shape in (0, 1):
+        lib.unet_set_wgrad_narrow(shape)
         step(x, y); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3): step(x, y)
         torch.cuda.synchronize()
         res[shape].append((time.perf_counter() - t0) / 3 * 1e3)
 for k, v in res.items():
-    print(f"wgrad mfma {k}: ms/step median {sorted(v)[len(v)//2]:.2f} min {min(v):.2f}  -> {16e3/min(v):.1f} tiles/s", flush=True)
+    print(f"wgrad narrow={k}: ms/step median {sorted(v)[len(v)//2]:.2f} min {min(v):.2f}  -> {16e3/min(v):.1f} tiles/s", flush=True)

@@ -9,7 +9,7 @@ B = 16
 LAYERS = [  # name, H, Cin, Cout, ks
     ("res100", 512, 100, 100, 3), ("u3c1", 256, 192, 96, 3), ("u3c2", 256, 96, 96, 3), ("u2", 128, 256, 256, 3),
     ("u1", 64, 384, 384, 3), ("u0", 32, 512, 512, 3), ("mid", 16, 512, 1024, 3), ("l4", 16, 512, 512, 3), ("l1", 128, 64, 64, 3),
-    ("shuf8", 256, 96, 384, 1),
+    ("shuf8", 256, 96, 384, 1), ("stem1", 256, 32, 32, 3), ("stem2", 256, 32, 64, 3),
 ]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 
@@ -33,7 +33,7 @@ for name, H, Cin, Cout, ks in LAYERS:
     gf = 2.0 * B * H * H * Cin * Cout * ks * ks / 1e9
     row = f"{name:8s} {gf:8.1f} GF |"
     for shape in (32, 16):
-        lib.unet_set_mfma_shape(shape); lib.unet_set_wgrad_mfma_shape(shape)
+        lib.unet_set_mfma_shape(shape); lib.unet_set_wgrad_mfma_shape(32); lib.unet_set_wgrad_narrow(1 if shape == 16 else 0)
         tf = timeit(lambda: ops.conv2d(x, wf, y, ks, 1))
         td = timeit(lambda: ops.conv2d_dgrad(y, wd, x, ks, 1))
         tw = timeit(lambda: ops.conv2d_wgrad(x, y, dw, ks, 1, ws))

@@ -491,3 +491,30 @@ def test_row_softmax_and_strided_pack(ops):
     ops.conv2d(to_ts(xin), wp, out, 1)
     torch.cuda.synchronize()
     assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv")
+
+
+def test_wgrad_narrow_kernel(ops):
+    """narrow-output weight gradient (64 < Cout <= 112, 3x3 s1, W >= 32; opt-in) against torch, incl. bias gradient and ragged tiles"""
+    from unet_amd._lib import lib
+    lib.unet_set_wgrad_narrow(1)
+    try:
+        _narrow_cases(ops)
+    finally:
+        lib.unet_set_wgrad_narrow(0)
+
+
+def _narrow_cases(ops):
+    for case in [(2, 40, 48, 100, 100), (1, 34, 64, 192, 96), (2, 32, 32, 96, 96), (1, 37, 45, 36, 100), (1, 32, 40, 250, 80)]:
+        N, H, W, Cin, Cout = case
+        g = torch.Generator().manual_seed(sum(case))
+        x = torch.randn(N, Cin, H, W, generator=g)
+        dy = torch.randn(N, Cout, H, W, generator=g)
+        ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, padding=1)
+        xt, dyt = to_ts(x), to_ts(dy)
+        ws = torch.empty(ops.wgrad_workspace(xt, dyt, 3, 1), device="cuda")
+        dw = torch.empty((Cout, Cin, 3, 3), device="cuda")
+        db = torch.empty(Cout, device="cuda")
+        ops.conv2d_wgrad(xt, dyt, dw, 3, 1, ws, dbias=db)
+        torch.cuda.synchronize()
+        assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"narrow wgrad {case}")
+        assert_close(db.cpu(), dy.sum((0, 2, 3)), rtol=3e-4, atol=1e-4, what=f"narrow dbias {case}")
