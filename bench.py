@@ -84,6 +84,8 @@ def main():
     from unet_amd.distributed import broadcast_parameters, init_from_env
     rank, local_rank, world = init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}: launch with torch.distributed.run"
+    if os.environ.get("UNET_FORCE_DEVICE") is not None:      # rehearsal of the N>1 path on a single GPU (with UNET_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["UNET_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -27,7 +27,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # UNET_DIST_BACKEND=gloo lets several ranks share ONE GPU for rehearsals (RCCL refuses duplicate devices)
+            backend = os.environ.get("UNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("UNET_FORCE_DEVICE") is not None:
+            local_rank = int(os.environ["UNET_FORCE_DEVICE"])
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
