@@ -1,0 +1,99 @@
+"""CPU suite for the host-side Learner surface: schedules, recorder smoothing, DiceMulti, CSV format, GeoTIFF I/O,
+input scaling -- checked against the oracle's restatement of fastai where one exists."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from unet_amd import learner as L
+from unet_amd.tiffio import read_tiff, write_tiff
+
+
+def test_schedules_match_oracle():
+    lrs = L.even_mults(1e-4, 1e-3, 3)
+    assert np.allclose(lrs, O.even_mults(1e-4, 1e-3, 3))
+    f, g = L.combined_cos(0.25, lrs / 25, lrs, lrs / 1e5), O.combined_cos(0.25, lrs / 25, lrs, lrs / 1e5)
+    m, n = L.combined_cos(0.25, 0.95, 0.85, 0.95), O.combined_cos(0.25, 0.95, 0.85, 0.95)
+    for p in np.linspace(0, 1, 41):
+        assert np.allclose(f(float(p)), g(float(p))) and abs(m(float(p)) - n(float(p))) < 1e-12
+
+
+def test_dice_multi_matches_oracle():
+    g = torch.Generator().manual_seed(0)
+    a, b = L.DiceMulti(), O.DiceMulti()
+    for _ in range(3):
+        logits = torch.randn(2, 4, 9, 7, generator=g)
+        targ = torch.randint(0, 4, (2, 9, 7), generator=g)
+        a.accumulate_argmax(logits.argmax(1), targ, 4)
+        b.accumulate(logits, targ)
+    assert abs(a.value - b.value) < 1e-12
+    c = L.DiceMulti()
+    c.accumulate_argmax(torch.zeros(1, 2, 2, dtype=torch.long), torch.zeros(1, 2, 2, dtype=torch.long), 3)
+    assert c.value == 1.0          # absent classes are skipped (nanmean)
+
+
+def test_recorder_smoothing_is_fastai_avgsmoothloss():
+    r = L.Recorder(["dice_multi"])
+    assert r.metric_names == ["epoch", "train_loss", "valid_loss", "dice_multi", "time"]     # history.csv:1 of the reference
+    val, vals = 0.0, [2.0, 1.0, 0.5]
+    for i, v in enumerate(vals, 1):
+        r.add_batch(v, 1e-3)
+        val = 0.98 * val + 0.02 * v
+        assert abs(r.losses[-1] - val / (1 - 0.98 ** i)) < 1e-12
+
+
+def test_cross_entropy_flat_surface():
+    w = torch.tensor([0.2, 0.3, 0.5])
+    lf = L.CrossEntropyLossFlat(axis=1)
+    lf.func.weight = w                                  # train.py:211 assigns it
+    z = torch.randn(2, 3, 4, 5)
+    y = torch.randint(0, 3, (2, 4, 5))
+    assert abs(float(lf(z, y)) - float(O.CrossEntropyLossFlat(weight=w)(z, y))) < 1e-6
+    assert torch.equal(lf.decodes(z), z.argmax(1)) and torch.allclose(lf.activation(z).sum(1), torch.ones(2, 4, 5))
+
+
+def test_input_scaling_quirk():
+    a = np.array([[[0, 255], [128, 64]]], dtype=np.uint8)
+    assert np.allclose(L.scale_input(a, "int8"), a / 255.0)
+    b = np.array([[[0, 65025]]], dtype=np.uint16)
+    assert np.allclose(L.scale_input(b, "int16"), b / 255.0 / 255.0)      # utils.py:248-249 + IntToFloatTensor
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.uint16, np.int16, np.float32])
+def test_geotiff_roundtrip(tmp_path, dt):
+    a = (np.random.default_rng(0).random((4, 13, 17)) * 200).astype(dt)
+    gt = (500000.0, 0.2, 0.0, 5800000.0, 0.0, -0.2)
+    write_tiff(tmp_path / "a.tif", a, geotransform=gt, nodata=0)
+    b, meta = read_tiff(tmp_path / "a.tif")
+    assert b.dtype == a.dtype and np.array_equal(a, b) and meta["geotransform"] == gt and meta["nodata"] == 0.0
+    write_tiff(tmp_path / "m.tif", a[0])
+    m, meta = read_tiff(tmp_path / "m.tif")
+    assert m.shape == (13, 17) and np.array_equal(m, a[0]) and meta["geotransform"] is None
+
+
+def test_geotiff_reads_foreign_writer(tmp_path):
+    from PIL import Image
+    a = (np.random.default_rng(1).random((9, 11)) * 255).astype(np.uint8)
+    Image.fromarray(a).save(tmp_path / "p.tif")
+    b, _ = read_tiff(tmp_path / "p.tif")
+    assert np.array_equal(a, b)
+    rgb = (np.random.default_rng(2).random((8, 8, 3)) * 255).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "c.tif")
+    c, _ = read_tiff(tmp_path / "c.tif")
+    assert np.array_equal(c, np.moveaxis(rgb, -1, 0))
+    with pytest.raises(NotImplementedError):
+        Image.fromarray(a).save(tmp_path / "z.tif", compression="tiff_lzw")
+        read_tiff(tmp_path / "z.tif")
+
+
+def test_dataloaders_batches(tmp_path):
+    g = np.random.default_rng(3)
+    imgs = [g.integers(0, 255, (4, 8, 8)).astype(np.uint8) for _ in range(5)]
+    masks = [g.integers(0, 3, (8, 8)).astype(np.uint8) for _ in range(5)]
+    dls = L.DataLoaders(L.TileDataset(imgs, masks), L.TileDataset(imgs[:2], masks[:2]), bs=2, device="cpu", vocab=["a", "b", "c"])
+    xs = list(dls.train)
+    assert len(xs) == 2 and xs[0][0].shape == (2, 4, 8, 8) and xs[0][0].dtype == torch.float32 and xs[0][1].dtype == torch.int64
+    assert float(xs[0][0].max()) <= 1.0
+    assert len(list(dls.valid)) == 1
