@@ -1,7 +1,7 @@
 """Configuration + driver of the tile workflow (reference ``params_and_main.py:21-180``) on the MI355X hot path.
 
-Edit the globals, then run ``python params_and_main.py``.  ``Create_tiles`` (GDAL/rasterio raster splitting,
-``create_tiles_unet.py``) is outside the hot path and raises; ``Train`` and ``Predict`` run on the GPU.
+Edit the globals, then run ``python params_and_main.py``.  ``Create_tiles`` is CPU preprocessing (``create_tiles_unet.py``, numpy + unet_amd.tiffio instead of GDAL/rasterio);
+``Train`` and ``Predict`` run on the GPU.
 """
 from __future__ import annotations
 
@@ -71,7 +71,9 @@ def main():
         self_attention, ENCODER_FACTOR, LR_FINDER, loss_func, monitor = False, 10, None, None, "dice_multi"
         ARCHITECTURE, transforms = xresnet34, False
     if Create_tiles:
-        raise NotImplementedError("raster tiling (create_tiles_unet.split_raster) is outside the MI355X hot path")
+        from create_tiles_unet import split_raster
+        split_raster(path_to_raster=image_path, path_to_mask=mask_path, base_dir=base_dir, patch_size=patch_size,
+                     patch_overlap=patch_overlap, split=split, max_empty=max_empty, class_zero=class_zero)
     if Train:
         from train import train_func
         train_func(data_path, existing_model, model_path, description, BATCH_SIZE, visualize_data_example, enable_regression,

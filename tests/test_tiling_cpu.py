@@ -1,0 +1,47 @@
+"""CPU suite: raster tiling (window rule, emptiness filter, geotransforms, split) and the flip augmentation slicing rule."""
+import numpy as np
+import torch
+
+import create_tiles_unet as T
+from unet_amd.learner import FlipAugment
+from unet_amd.tiffio import read_tiff, write_tiff
+
+
+def test_window_rule_matches_survey_example():
+    ws = T.compute_windows(20000, 20000, 512, 0.2)
+    xs = sorted({w[0] for w in ws})
+    assert len(ws) == 49 * 49 and xs[:3] == [0, 410, 820] and xs[-2:] == [19270, 19488]
+    assert T.compute_windows(800, 1200, 400, 0.0) == [(x, y, 400, 400) for y in (0, 400) for x in (0, 400, 800)]
+    assert [w[0] for w in T.compute_windows(400, 1000, 400, 0.0)] == [0, 400, 600]             # last window flush with the edge
+
+
+def test_split_raster_end_to_end(tmp_path):
+    g = np.random.default_rng(0)
+    img = g.integers(1, 255, (4, 300, 420)).astype(np.uint8)
+    mask = g.integers(1, 4, (300, 420)).astype(np.uint8)
+    img[:, :100, :100] = 0            # an empty corner: that tile must be dropped
+    mask[:100, :100] = 0
+    gt = (1000.0, 0.5, 0.0, 2000.0, 0.0, -0.5)
+    write_tiff(tmp_path / "r.tif", img, geotransform=gt)
+    write_tiff(tmp_path / "m.tif", mask, geotransform=gt)
+    counts = T.split_raster(tmp_path / "r.tif", tmp_path / "m.tif", tmp_path / "out", patch_size=100, patch_overlap=0.0,
+                            split=[0.75, 0.25], max_empty=0.9, seed=1)
+    n_windows = len(T.compute_windows(300, 420, 100, 0.0))
+    assert n_windows == 15 and counts["trai"] + counts["vali"] == 14 and counts["trai"] == 10
+    tiles = sorted((tmp_path / "out" / "trai" / "img_tiles").glob("*.tif"))
+    t, meta = read_tiff(tiles[0])
+    idx = int(tiles[0].stem.split("_")[-1])
+    x, y, _, _ = T.compute_windows(300, 420, 100, 0.0)[idx]
+    assert np.array_equal(t, img[:, y:y + 100, x:x + 100])
+    assert meta["geotransform"] == (1000.0 + x * 0.5, 0.5, 0.0, 2000.0 - y * 0.5, 0.0, -0.5)
+    m, _ = read_tiff(tmp_path / "out" / "trai" / "mask_tiles" / tiles[0].name)
+    assert np.array_equal(m, mask[y:y + 100, x:x + 100])
+
+
+def test_flip_augment_slicing_rule():
+    x = torch.arange(4 * 1 * 2 * 3, dtype=torch.float32).view(4, 1, 2, 3)
+    y = torch.arange(4 * 2 * 3).view(4, 2, 3)
+    a, b = FlipAugment(1.0, 0.0, n_transform_imgs=1.0)(x.clone(), y.clone())
+    assert torch.equal(a, x) and torch.equal(b, y)                  # quirk Q7: default touches nothing
+    a, b = FlipAugment(1.0, 0.0, n_transform_imgs=0.5)(x.clone(), y.clone())
+    assert torch.equal(a[:2], x[:2].flip(-1)) and torch.equal(a[2:], x[2:]) and torch.equal(b[:2], y[:2].flip(-1))

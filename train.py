@@ -16,8 +16,8 @@ import numpy as np
 import torch
 
 from unet_amd import xresnet34  # noqa: F401  (architecture tokens, like `from fastai.vision.all import xresnet34`)
-from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, Learner, SaveModelCallback,
-                              TileDataset, load_learner, open_tile)
+from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, FlipAugment, Learner,
+                              SaveModelCallback, TileDataset, load_learner, open_tile)
 from unet_amd.model import HipDynamicUnet
 
 
@@ -43,7 +43,7 @@ def get_class_weights(ds: TileDataset, n_cls: int, max_tiles: int = 1200) -> np.
     return cnt.sum() / np.maximum(cnt, 1)
 
 
-def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda") -> DataLoaders:
+def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda", train_tfm=None) -> DataLoaders:
     data_path = Path(data_path)
     dtype = dtype or get_datatype(data_path)
     sets = {}
@@ -51,7 +51,7 @@ def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda") -> DataLoa
         imgs = _tiles(data_path / split / "img_tiles")
         masks = [data_path / split / "mask_tiles" / p.name for p in imgs]
         sets[split] = TileDataset(imgs, masks, dtype)
-    return DataLoaders(sets["trai"], sets["vali"], bs, device=device, vocab=list(codes))
+    return DataLoaders(sets["trai"], sets["vali"], bs, device=device, vocab=list(codes), train_tfm=train_tfm)
 
 
 def unet_learner_MS(dls, arch, pretrained=True, loss_func=None, norm_type=None, opt_func=Adam, lr=1e-3, splitter=None, cbs=None,
@@ -113,9 +113,14 @@ def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, v
         "ENCODER_FACTOR": ENCODER_FACTOR, "CLASS_WEIGHTS": CLASS_WEIGHTS if isinstance(CLASS_WEIGHTS, str) else list(CLASS_WEIGHTS),
         "ARCHITECTURE": _arch_name(ARCHITECTURE), "CODES": list(CODES), "self_attention": self_attention, "monitor": monitor,
         "VALID_SCENES": VALID_SCENES, "info": info, "class_zero": class_zero, "dtype": dtype}, indent=1, default=str))
+    tfm = None
     if transforms:
-        warnings.warn("augmentation pipelines (albumentations) are not part of the MI355X hot path; training without them")
-    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype)
+        # the reference's default aug_pipe is HorizontalFlip + VerticalFlip (params_and_main.py:105-115); any other
+        # albumentations pipeline is not available here (albumentations is not installed)
+        if aug_pipe is not None and not isinstance(aug_pipe, FlipAugment):
+            warnings.warn("only the built-in flip augmentation is available on this path; using it instead of aug_pipe")
+        tfm = aug_pipe if isinstance(aug_pipe, FlipAugment) else FlipAugment(n_transform_imgs=n_transform_imgs)
+    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, train_tfm=tfm)
     if enable_regression:
         raise NotImplementedError("regression mode is out of scope of the MI355X hot path")
     if isinstance(CLASS_WEIGHTS, str):

@@ -150,9 +150,10 @@ class TileDataset:
 
 
 class DataLoader:
-    def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0):
+    def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0, batch_tfm=None):
         self.ds, self.bs, self.shuffle, self.device, self.drop_last = ds, bs, shuffle, device, drop_last
         self._g = np.random.default_rng(seed)
+        self.batch_tfm = batch_tfm
 
     def __len__(self):
         n = len(self.ds)
@@ -166,20 +167,43 @@ class DataLoader:
             items = [self.ds[int(i)] for i in idx[b * self.bs:(b + 1) * self.bs]]
             xb = torch.stack([x for x, _ in items]).to(self.device)
             yb = None if items[0][1] is None else torch.stack([y for _, y in items]).to(self.device)
+            if self.batch_tfm is not None and yb is not None:
+                xb, yb = self.batch_tfm(xb, yb)
             yield xb, yb
 
 
 class DataLoaders:
     """``dls.train`` / ``dls.valid`` / ``dls.vocab`` / ``dls.device`` / ``dls.train_ds`` as the reference uses them."""
 
-    def __init__(self, train: TileDataset, valid: Optional[TileDataset], bs: int, device="cuda", vocab=None, seed=0):
+    def __init__(self, train: TileDataset, valid: Optional[TileDataset], bs: int, device="cuda", vocab=None, seed=0, train_tfm=None):
         self.device = torch.device(device)
         self.train_ds, self.valid_ds, self.bs, self.vocab = train, valid, bs, vocab
-        self.train = DataLoader(train, bs, True, self.device, drop_last=len(train) >= bs, seed=seed)
+        self.train = DataLoader(train, bs, True, self.device, drop_last=len(train) >= bs, seed=seed, batch_tfm=train_tfm)
         self.valid = None if valid is None else DataLoader(valid, bs, False, self.device)
 
     def test_dl(self, items, dtype=None):
         return DataLoader(TileDataset(items, None, dtype or self.train_ds.dtype), self.bs, False, self.device)
+
+
+class FlipAugment:
+    """The reference's default augmentation (params_and_main.py:105-115: horizontal / vertical flips) applied on the device
+    with the slicing rule of SegmentationAlbumentationsTransform.encodes (utils.py:239-295): only the FIRST
+    ``n_transform - B`` images of a batch are touched, n_transform = ceil(B * n_transform_imgs) -- so with the shipped default
+    n_transform_imgs = 1 the slice is empty and NOTHING is augmented (quirk Q7, reproduced, not fixed)."""
+
+    def __init__(self, p_h=0.5, p_v=0.5, n_transform_imgs=1.0, seed=0):
+        self.p_h, self.p_v, self.n, self.g = p_h, p_v, n_transform_imgs, np.random.default_rng(seed)
+
+    def __call__(self, xb: torch.Tensor, yb: torch.Tensor):
+        B = xb.shape[0]
+        n_transform = math.ceil(B * self.n)
+        idx = list(range(B))[:n_transform - B]
+        for i in idx:
+            if self.g.random() < self.p_h:
+                xb[i] = xb[i].flip(-1); yb[i] = yb[i].flip(-1)
+            if self.g.random() < self.p_v:
+                xb[i] = xb[i].flip(-2); yb[i] = yb[i].flip(-2)
+        return xb, yb
 
 
 # --------------------------------------------------------------------------- callbacks
