@@ -81,6 +81,7 @@ int unet_conv2d_variant(const unet_conv_desc* d);
  * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */
 int unet_set_mfma_shape(int shape);
 int unet_set_wgrad_mfma_shape(int shape);
+int unet_set_wgrad_1x1(int on);      /* 128x128-tiled GEMM kernel for 1x1 weight gradients on/off (default on) */
 int unet_set_wgrad_narrow(int on);   /* narrow-output (Cout <= 112) weight-gradient kernel on/off (default on) */
 
 /* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].

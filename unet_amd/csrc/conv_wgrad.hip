@@ -446,6 +446,106 @@ __global__ __launch_bounds__(192, 3) void wgrad_narrow_kernel(const WArgs a) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 weight gradient = a plain GEMM dW[k][c] = sum_p dy[p][k] x[p][c] over FLAT pixels (PixelShuffle_ICNR convs,
+// identity-path convs, head, self-attention products).  The 64x64-tiled kernel stages 512 B per pixel for 8 kFLOP
+// (L2->LDS bound, ~46 TFLOP/s); here a workgroup owns 128 x 128 channels (each wave 64 x 64 = 2x2 MFMA tiles, 64
+// accumulator VGPRs), i.e. twice the FLOPs per staged byte, with the next pixel tile prefetched into registers.
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const WArgs a, long long P) {
+    constexpr int PT = 64, LDW = 128, IT = PT * 32 / 256;     // 8 float4 per thread per operand
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dyT = smem;                 // [PT][128]
+    float* xT = smem + PT * LDW;       // [PT][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
+    const int k0 = kblk * 128, c0 = cblk * 128;
+    const int split = blockIdx.y;
+    const long long tile_begin = (long long)split * a.tiles_per_block;
+    long long tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rd[IT], rx[IT];
+    auto load_tile = [&](long long tile) {
+        const long long p0 = tile * PT;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = tid + it * 256;
+            const int p = e >> 5, q = e & 31;
+            const long long pp = p0 + p;
+            const bool okp = pp < P;
+            rd[it] = (okp && (k0 + 4 * q) < a.Cout4) ? *reinterpret_cast<const float4*>(a.dy + (size_t)pp * a.dy_cs + a.dy_co + k0 + 4 * q)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[it] = (okp && (c0 + 4 * q) < a.Cin4) ? *reinterpret_cast<const float4*>(a.x + (size_t)pp * a.x_cs + a.x_co + c0 + 4 * q)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = tid + it * 256;
+            *reinterpret_cast<float4*>(dyT + e * 4) = rd[it];
+            *reinterpret_cast<float4*>(xT + e * 4) = rx[it];
+        }
+    };
+
+    const float* abase = dyT + h * LDW + wk * 64 + l31;
+    const float* bbase = xT + h * LDW + wc * 64 + l31;
+    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < 128;
+    float bsum = 0.f;
+
+    if (tile_begin < tile_end) {
+        load_tile(tile_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (long long tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) load_tile(tile + 1);
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) bsum += dyT[p * LDW + tid];
+        }
+#pragma unroll
+        for (int step = 0; step < PT / 2; ++step) {
+            const float a0 = abase[(2 * step) * LDW], a1 = abase[(2 * step) * LDW + 32];
+            const float b0 = bbase[(2 * step) * LDW], b1 = bbase[(2 * step) * LDW + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (has_next) store_tile();
+        __syncthreads();
+    }
+
+    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    const size_t KC_ = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)split * KC_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (k < a.Cout && c < a.Cin) pb[(size_t)k * a.Cin + c] = acc[i][j][r];
+            }
+        }
+}
+
 // dw[(k*Cin + c)*T + t] (=|+=) sum_split part[split][t][k][c]
 // one thread per (t, k*Cin+c): reads are coalesced along c for every split, 8 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T,
@@ -481,10 +581,11 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float*
 // 5-25 % in isolation, but inside the full step it measured 25-40 % slower than the 64x64-tiled kernel on the same launches
 // (run-to-run 9.0 .. 13.8 ms on the 100->100 layer): left for a later round, see DESIGN.md.
 static int g_wgrad_narrow = 0;
+static int g_wgrad_1x1 = 1;           // 128x128-tiled GEMM kernel for 1x1 weight gradients
 
 struct WPlan {
     WArgs k;
-    int ptw, splits, T, narrow;
+    int ptw, splits, T, narrow, gemm1x1;
     size_t lds_bytes, lds_bytes16;
 };
 
@@ -526,6 +627,14 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         k.tiles_x = unet::cdiv(d->OW, 32);
         k.total_tiles = d->N * k.tiles_y * k.tiles_x;
         cols = unet::cdiv(d->Cin, 16);
+    }
+    p->gemm1x1 = (d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
+    if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
+        k.kt = unet::cdiv(d->Cout, 128);
+        k.ct = unet::cdiv(d->Cin, 128);
+        k.total_tiles = unet::cdiv((long long)d->N * d->OH * d->OW, 64);
+        k.tiles_y = k.tiles_x = 1;
+        cols = k.kt * k.ct;
     }
     // aim for ~512 workgroups (256 CUs x 2 resident; 1024 for the 3-wave narrow kernel); at least 4 tiles per block
     int want = 512 / cols;
@@ -592,6 +701,11 @@ extern "C" size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d) {
     return (size_t)p.splits * p.T * d->Cout * d->Cin + (size_t)p.splits * d->Cout;
 }
 
+extern "C" int unet_set_wgrad_1x1(int on) {
+    g_wgrad_1x1 = on ? 1 : 0;
+    return UNET_OK;
+}
+
 extern "C" int unet_set_wgrad_narrow(int on) {
     g_wgrad_narrow = on ? 1 : 0;
     return UNET_OK;
@@ -607,7 +721,17 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
                    d->workspace_floats, need);
     p.k.bpart = d->dbias != nullptr ? d->workspace + npart : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (p.narrow) {
+    if (p.gemm1x1) {
+        static bool configured = false;
+        if (!configured) {
+            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        hipLaunchKernelGGL(wgrad1x1_kernel, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), (size_t)2 * 64 * 128 * sizeof(float), st, p.k,
+                           (long long)d->N * d->OH * d->OW);
+        UNET_CHECK_LAUNCH();
+        rc = UNET_OK;
+    } else if (p.narrow) {
         auto kern = wgrad_narrow_kernel<32>;
         static bool configured = false;
         if (!configured) {

@@ -215,7 +215,7 @@ class HipDynamicUnet(nn.Module):
         head: ConvLayer = L[nb + 4]
         o: TS = ctx.saved[(id(head), "x")]
         do = head.bwd_from_dy(ctx, dz, mask=o)                  # masked by relu of the final ResBlock
-        dX = L[nb + 3].bwd_nonorm(ctx, do)
+        dX = L[nb + 3].bwd_nonorm(ctx, do, dx_channels=self.up_c)    # no gradient for the network-input channels of the concat
         d = L[nb].hip_bwd(ctx, dX.sub(0, self.up_c))            # -> masked grad wrt UnetBlock 3 conv2 pre-activation
         dskips: Dict[int, TS] = {}
         for k in range(len(self.sz_chg_idxs) - 1, -1, -1):

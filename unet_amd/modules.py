@@ -230,14 +230,21 @@ class ConvLayer(nn.Sequential):
         self.bx.bwd(ctx, da, a if self.has_act else None, y, dy)
         return self.bwd_from_dy(ctx, dy, need_dx, dx_res)
 
-    def bwd_from_dy(self, ctx: Ctx, dy: TS, need_dx=True, dx_res: Optional[TS] = None, mask: Optional[TS] = None) -> Optional[TS]:
-        """dy = dL/d(conv output).  wgrad (+bias) then dgrad; `mask` fuses the ReLU backward of the producer of x."""
+    def bwd_from_dy(self, ctx: Ctx, dy: TS, need_dx=True, dx_res: Optional[TS] = None, mask: Optional[TS] = None,
+                    dx_channels: Optional[int] = None) -> Optional[TS]:
+        """dy = dL/d(conv output).  wgrad (+bias) then dgrad; `mask` fuses the ReLU backward of the producer of x.
+        dx_channels: only the first dx_channels input channels need a gradient (the rest is the network input)."""
         x: TS = ctx.saved[(id(self), "x")]
         self.cx.bwd_w(ctx, x, dy)
         if not need_dx:
             return None
         dx = ctx.act(self, "dx", x.N, x.H, x.W, x.C)
-        self.cx.bwd_x(dy, dx, res=dx_res, mask=mask)
+        if dx_channels is not None and dx_channels < x.C and (dx_channels + 127) // 128 == (x.C + 127) // 128:
+            # same packed-filter padding: the kernel simply produces fewer channels
+            self.cx.bwd_x(dy, dx.sub(0, dx_channels), res=None if dx_res is None else dx_res.sub(0, dx_channels),
+                          mask=None if mask is None else mask.sub(0, dx_channels))
+        else:
+            self.cx.bwd_x(dy, dx, res=dx_res, mask=mask)
         return dx
 
 
@@ -332,13 +339,14 @@ class ResBlock(nn.Module):
         ctx.saved[(id(c2), "x")] = t1
         return out
 
-    def bwd_nonorm(self, ctx: Ctx, dout_pre: TS) -> TS:
+    def bwd_nonorm(self, ctx: Ctx, dout_pre: TS, dx_channels: Optional[int] = None) -> TS:
         """dout_pre = dL/d(pre-activation of the block output), i.e. already masked by (out > 0).
-        Returns dL/dx (x is not a ReLU output here: it is the dense concat)."""
+        Returns dL/dx (x is not a ReLU output here: it is the dense concat); only its first dx_channels channels are
+        computed when given (the trailing channels of the concat are the network input)."""
         c1, c2 = self.convpath[0], self.convpath[1]
         t1: TS = ctx.saved[(id(c2), "x")]
         dt1 = c2.bwd_from_dy(ctx, dout_pre, mask=t1)
-        return c1.bwd_from_dy(ctx, dt1, dx_res=dout_pre)
+        return c1.bwd_from_dy(ctx, dt1, dx_res=dout_pre, dx_channels=dx_channels)
 
 
 class PixelShuffle_ICNR(nn.Sequential):
