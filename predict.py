@@ -39,7 +39,11 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
                      AOI=None, year=None, validation_vision=True, class_zero=False, batch_size=16):
     if regression:
         raise NotImplementedError("regression mode is out of scope of the MI355X hot path")
-    learn = load_learner(Path(predict_model))
+    # cfg5: one process per GPU (torch.distributed.run); tile i goes to rank i mod world, the merge mosaic is summed with RCCL
+    from unet_amd.distributed import init_from_env
+    import torch.distributed as dist
+    rank, local_rank, world = init_from_env()
+    learn = load_learner(Path(predict_model), device=f"cuda:{local_rank}" if world > 1 else "cuda")
     model = learn.model
     path = Path(predict_path)
     output_folder = path.parent if merge else path.parent / ("predicted_tiles_" + Path(predict_model).stem)
@@ -53,12 +57,14 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
         gts = np.array([[g[0][0], 0, g[0][1], g[0][3], 0, g[0][5]] for g in geos], dtype=np.float64)
     results = []          # (tile index, probs [C,H,W] device tensor) when merging
     mosaic = count = None
-    for b0 in range(0, len(tiles), batch_size):
-        chunk = tiles[b0:b0 + batch_size]
+    mine = list(range(rank, len(tiles), world))
+    for b0 in range(0, len(mine), batch_size):
+        ids = mine[b0:b0 + batch_size]
+        chunk = [tiles[i] for i in ids]
         x = torch.from_numpy(np.stack([scale_input(open_tile(t), dtype) for t in chunk]))
-        probs, amax = model.predict_probs(x.cuda())
+        probs, amax = model.predict_probs(x.to(model._device))
         for j, t in enumerate(chunk):
-            i = b0 + j
+            i = ids[j]
             gt, tags = geos[i]
             if merge:
                 results.append((i, probs[j]))
@@ -77,8 +83,14 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
     if validation_vision:
         pass  # per-tile majority-class confusion plots (predict.py:56-143) are reporting, out of scope
     if not merge:
+        if world > 1:
+            dist.barrier()
         print(f"Prediction stored in {output_folder}.")
         return output_folder
+    if world > 1:       # every rank needs every tile's size for the mosaic extent
+        sizes = torch.from_numpy(gts[:, [1, 4]].copy()).to(model._device)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
+        gts[:, [1, 4]] = sizes.cpu().numpy()
     # ---- overlap merge (predict.py:257-355): mosaic extent from the tiles' geotransforms
     ulx_full, uly_full = gts[:, 0].min(), gts[:, 3].max()
     xres, yres = gts[0, 2], gts[0, 5]
@@ -88,7 +100,7 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
     if len(set(gts[:, 1])) != 1 or len(set(gts[:, 4])) != 1:
         warnings.warn("Not all tiles have the same resolution.")
     MW, MH = round((lrx_full - ulx_full) / xres), round((lry_full - uly_full) / yres)
-    C = results[0][1].shape[0]
+    C = model.n_out
     print(f"True merged raster size: {C * MH * MW * 4 / (1024 ** 2): .1f}MB.")
     if large_file:
         # int8 path of the reference: probabilities * 31 rounded to int8, integer division by the hit counter (host)
@@ -99,16 +111,23 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
             q = np.around(p.cpu().numpy() * ((128 / 4) - 1)).astype(np.int8)
             merged[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += q
             counter[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += 1
+        if world > 1:
+            raise NotImplementedError("large_file merge is single-process (int8 host arrays)")
         m = counter > 0
         merged[m] //= counter[m]
         amax_full = merged.argmax(axis=0)
     else:
-        mosaic = torch.zeros((C, MH, MW), dtype=torch.float32, device="cuda")
-        count = torch.zeros((MH, MW), dtype=torch.int32, device="cuda")
+        mosaic = torch.zeros((C, MH, MW), dtype=torch.float32, device=model._device)
+        count = torch.zeros((MH, MW), dtype=torch.int32, device=model._device)
         for i, p in results:
             x0, y0 = round((gts[i, 0] - ulx_full) / xres), round((gts[i, 3] - uly_full) / yres)
             ops.mosaic_accumulate(p.contiguous(), mosaic, count, int(y0), int(x0))
-        am = torch.empty((MH, MW), dtype=torch.uint8, device="cuda")
+        if world > 1:   # partial (sum-probs, hit-count) rasters of the ranks -> one mosaic
+            dist.all_reduce(mosaic)
+            dist.all_reduce(count)
+            if rank != 0:
+                return None
+        am = torch.empty((MH, MW), dtype=torch.uint8, device=model._device)
         ops.mosaic_finalize(mosaic, count, am)
         merged, amax_full = mosaic.cpu().numpy(), am.cpu().numpy()
     if all_classes:
