@@ -311,3 +311,45 @@ def test_hipgraph_step_and_predict_match_eager():
     p2, _ = model.predict_probs_graphed(x2)
     torch.cuda.synchronize()
     assert torch.equal(p2, model.predict_probs(x2)[0])
+
+
+def test_reference_default_patch_size_400():
+    """patch_size = 400 is the reference default (params_and_main.py:36): 400 -> 200 -> 100 -> 50 -> 25 -> 13 exercises
+    ceil-mode pooling and the nearest-resize branch of every UnetBlock (13*2 = 26 != 25)."""
+    ref, model = _pair("xresnet34", 4, 5, (400, 400))
+    x, y = O.synthetic_batch(1, 4, 400, 400, 5)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z_ref = ref(x)
+    probs, amax = model.predict_probs(x.cuda())
+    z = model.logits_ts().view().permute(0, 3, 1, 2).cpu()
+    # random running statistics inflate this eval pass to logits of O(250): the 1e-3 bar is meant for O(10) logits
+    assert (z - z_ref).abs().max().item() < 1e-3 * max(1.0, z_ref.abs().max().item() / 20)
+    assert torch.equal(amax.cpu(), torch.softmax(z_ref, 1).argmax(1))
+
+
+def test_odd_geometry_train_step_smooth():
+    """non-square, non-/32 tile, batch 3: gradients through the resize / ceil-pool adjoints (flip-free network)."""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(8)
+    ref = O.DynamicUnet("xresnet18", 4, 3, (208, 176))
+    O.randomize_bn_and_zero_gammas(ref, seed=9)
+    _make_all_active(ref)
+    model = HipDynamicUnet("xresnet18", 4, 3, (208, 176))
+    model.load_state_dict(ref.state_dict())
+    x, y = O.synthetic_batch(3, 4, 208, 176, 3)
+    ref.train(); model.train()
+    loss_ref = O.CrossEntropyLossFlat()(ref(x), y)
+    loss_ref.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), None)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    worst = max(((p.grad.cpu() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12), n)
+                for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()))
+    assert worst[0] < 3e-3, worst
+    # a second geometry through the same model object (buffers are keyed by shape)
+    x2, y2 = O.synthetic_batch(1, 4, 96, 128, 3, seed=3)
+    ref.zero_grad()
+    l2r = O.CrossEntropyLossFlat()(ref(x2), y2)
+    l2 = model.forward_loss_backward(x2.cuda(), y2.cuda(), None)
+    assert abs(l2.item() - l2r.item()) < 1e-4 * max(1.0, abs(l2r.item()))

@@ -14,7 +14,7 @@ LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libunet_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", str(REPO / "include"), "-I", str(CSRC),
-         "-Wno-unused-value"]
+         "-Wno-unused-value"] + os.environ.get("UNET_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():

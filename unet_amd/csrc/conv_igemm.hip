@@ -434,6 +434,9 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
                     const float4 f = *reinterpret_cast<const float4*>(wb + bbase[n] + 4 * kq);
                     bv[n][0] = f.x; bv[n][1] = f.y; bv[n][2] = f.z; bv[n][3] = f.w;
                 }
+#ifdef UNET_CONV_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (kk < ksteps) {
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
                         }
                     }
                 }
+#ifdef UNET_CONV_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             if (has_next) STORE_W(wts_buf((s + 1) & 1));
             if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1), chunk + 1);
