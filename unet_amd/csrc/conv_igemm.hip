@@ -39,6 +39,9 @@ struct TapSet {
     int ext_y, ext_x;   // halo extent beyond (T-1)*S
     int py, px;         // output parity offsets (OS == 2)
     signed char dy[9], dx[9], widx[9];
+    // the same tables packed 4 bits per tap for scalar decoding (16x16x4 kernel): dpack nibble t = (dy - min_dy) | (dx - min_dx) << 2,
+    // wpack nibble t = widx
+    unsigned long long dpack, wpack;
 };
 
 struct KArgs {
@@ -310,6 +313,85 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
     }
 }
 
+// ---- explicitly scheduled global loads for the 16x16x4 kernel -------------------------------------------------
+// The compiler's s_waitcnt insertion merges the wait state of conditional loads conservatively (it drained vmcnt to 0 in
+// the middle of the MFMA stream: a full L2 round trip per stage).  The main loop therefore issues its loads as inline asm
+// (SGPR base + 32-bit lane offset) and places the vmcnt waits itself; vmcnt counts in issue order, and every path issues a
+// fixed number of loads per stage (invalid items load from a clamped, always addressable offset and are zeroed later).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+// wave-uniform pointer -> SGPR pair for the saddr form.  The leading s_nop 4 of every load group covers the "VALU writes
+// SGPR -> VMEM reads it" hazard (5 wait states): the compiler's hazard recognizer does not look inside inline asm.
+__device__ __forceinline__ u64 sgpr_ptr(const void* p) {
+    const u64 b = reinterpret_cast<u64>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return ((u64)hi << 32) | lo;
+}
+// operand-B tiles of one stage: tiles 0/1 at p + {0, TSTR}, tiles 2/3 at p + 2*TSTR + {0, TSTR}; one lane offset
+template <int TSTR, int N>
+__device__ __forceinline__ void gld_b(v4f (&d)[N], unsigned voff, const char* p) {
+    static_assert(N == 2 || N == 4, "operand-B tiles per wave");
+    const u64 s0 = sgpr_ptr(p);
+    if constexpr (N == 2) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:%4"
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(voff), "s"(s0), "n"(TSTR));
+    } else {
+        const u64 s1 = sgpr_ptr(p + 2 * TSTR);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:%7\n\t"
+                     "global_load_dwordx4 %2, %4, %6\n\tglobal_load_dwordx4 %3, %4, %6 offset:%7"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(voff), "s"(s0), "s"(s1), "n"(TSTR));
+    }
+}
+// The halo items of one chunk: one base, one lane offset per item.  Executed in EVERY stage with `on` = all ones (fetch) or
+// 0 (EXEC is cleared around the loads: nothing is fetched, the registers keep their values).  For the compiler the halo
+// registers are thus one unbroken chain of tied asm operands -- no conditional definition, no phi, hence no register copy
+// it could schedule between a load and its wait.
+template <int N>
+__device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], const void* p, bool fetch) {
+    static_assert(N == 4 || N == 10, "halo items per thread");
+    const u64 sb = sgpr_ptr(p);
+    const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
+    u64 sv;
+    if constexpr (N == 4) {
+        asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+                     "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
+                     "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [sv] "=&s"(sv)
+                     : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [sb] "s"(sb), [on] "s"(on)
+                     : "scc");   // s_and_saveexec writes SCC
+    } else {
+        asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+                     "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
+                     "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
+                     "global_load_dwordx4 %[h4], %[o4], %[sb]\n\tglobal_load_dwordx4 %[h5], %[o5], %[sb]\n\t"
+                     "global_load_dwordx4 %[h6], %[o6], %[sb]\n\tglobal_load_dwordx4 %[h7], %[o7], %[sb]\n\t"
+                     "global_load_dwordx4 %[h8], %[o8], %[sb]\n\tglobal_load_dwordx4 %[h9], %[o9], %[sb]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]),
+                       [h6] "+v"(h[6]), [h7] "+v"(h[7]), [h8] "+v"(h[8]), [h9] "+v"(h[9]), [sv] "=&s"(sv)
+                     : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]),
+                       [o6] "v"(vo[6]), [o7] "v"(vo[7]), [o8] "v"(vo[8]), [o9] "v"(vo[9]), [sb] "s"(sb), [on] "s"(on)
+                     : "scc");   // s_and_saveexec writes SCC
+    }
+}
+// s_waitcnt vmcnt(0) that also "defines" every register the outstanding loads write (operand-B tiles and halo items), so
+// that no consumer is scheduled above it
+template <int NB, int NH>
+__device__ __forceinline__ void wait_loads(v4f (&b)[NB], v4f (&h)[NH]) {
+    static_assert((NB == 2 || NB == 4) && (NH == 4 || NH == 10), "register groups");
+    // ONE statement (a tied operand's input copy, if the compiler ever made one, must not be able to slip in front of the
+    // s_waitcnt of a sibling statement); 14 tied operands = 28 of the 30 asm operands allowed
+#define UNET_H4 "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
+#define UNET_H10 UNET_H4, "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]), "+v"(h[8]), "+v"(h[9])
+    if constexpr (NB == 2 && NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H4);
+    else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H10);
+    else if constexpr (NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H4);
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H10);
+#undef UNET_H4
+#undef UNET_H10
+}
+
 // ------------------------------------------------------------------------------------------------
 // Same workgroup geometry on v_mfma_f32_16x16x4_f32 (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C: col=l&15,
 // row=4*(l>>4)+reg).  Each wave owns (2*MT) x (2*NT) tiles of 16x16; the LDS traffic per MFMA cycle is the
@@ -320,38 +402,42 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
 __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_kernel(const KArgs a) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
-    constexpr int WIT = (BN * 4 + NTH - 1) / NTH;
     constexpr int M16 = 2 * MT, N16 = 2 * NT;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is made a scalar so that everything derived from it (tile skipping, operand bases) is wave-uniform
+    // control flow (s_cbranch) instead of exec masking
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, kq = lane >> 4;
     const TapSet& ts = a.taps[blockIdx.z];
 
+    // block coordinates (the divisions run on the VALU: readfirstlane returns the results to SGPRs, so that all the
+    // pointer arithmetic derived from them is scalar)
     int bid = blockIdx.x;
-    const int nt = bid % a.ntn; bid /= a.ntn;
-    const int mtile = bid;
-    const int tx_t = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty_t = bid % a.tiles_y;
-    const int img = bid / a.tiles_y;
+    const int nt = __builtin_amdgcn_readfirstlane(bid % a.ntn); bid /= a.ntn;
+    const int mtile = __builtin_amdgcn_readfirstlane(bid);
+    const int tx_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_x); bid /= a.tiles_x;
+    const int ty_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_y);
+    const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
     const int oy0 = ty_t * TH, ox0 = tx_t * TW;
     const int n0 = nt * BN;
 
     const int S = a.S;
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
     const int HPIX = HH * HW;
-    int* s_tapoff = reinterpret_cast<int*>(smem);
-    int* s_widx = reinterpret_cast<int*>(smem) + 16;
+    // LDS map: [0,32) unused | halo[2].  The filter operand never touches LDS in this kernel: the packed image
+    // wp[tap][chunk][col][16] is already in MFMA B-operand order (lane (kq, l15) of tile n needs the float4 at
+    // [col = tile*16 + l15][4kq..4kq+3]: 64 lanes = one contiguous 1 KiB), so every wave loads its own tiles
+    // global -> VGPR one stage ahead (L1/L2 hits: all blocks stream the same slab) and the only barrier left is the
+    // one per 16-channel chunk that hands over the halo tile (was: one per tap).
     float* lds0 = smem + 32;
     auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDK); };
-    auto wts_buf = [&](int b) -> float* { return lds0 + 2 * HPIX * LDK + b * (BN * LDK); };
-    if (tid < 9) {
-        const int t = tid < ts.n ? tid : 0;
-        s_tapoff[tid] = ((ts.dy[t] - ts.min_dy) * HW + (ts.dx[t] - ts.min_dx)) * LDK;
-        s_widx[tid] = ts.widx[t];
-    }
+    // tap tables: 4-bit fields of two scalars, decoded on the SALU (no LDS lookup, no lgkmcnt round trip per stage)
+    const unsigned long long dpack = ts.dpack, wpack = ts.wpack;
+#define TAP_OFF(t_) ({ const unsigned d_ = (unsigned)(dpack >> (4 * (t_))); (int)(((d_ & 3u) * HW + ((d_ >> 2) & 3u)) * LDK); })
+#define TAP_WIDX(t_) ((int)((unsigned)(wpack >> (4 * (t_))) & 15u))
 
     const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
     const int iy0 = oy0 * S + ts.min_dy, ix0 = ox0 * S + ts.min_dx;
@@ -366,31 +452,45 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
         goff[it] = inb ? ((iy * a.IW + ix) * a.x_cs + a.x_co + 4 * q) : -1;
     }
 
-    float4 hreg[HIT];
-    float4 wreg0, wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    v4f hreg[HIT];
     const bool has_tail = (a.Cin & 15) != 0;
 
-#define LOAD_HALO(chunk_) ld_halo<HIT, NTH>(hreg, goff, xb, (chunk_) * KC, a.Cin4, tid)
-#define STORE_HALO(dst_, chunk_) do { if (has_tail && (chunk_) == a.nchunks - 1) st_halo_tail<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); \
-                                       else st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); } while (0)
-#define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
-#define STORE_W(dst_) st_w<WIT, NTH, BN>(wreg0, wreg1, (dst_), tid)
+    // halo items: always HIT loads; an item outside the image / beyond the channels loads offset 0 and is zeroed at the store
+#define HALO_OK(it_, c0_) (goff[it_] >= 0 && ((c0_) + 4 * ((tid + (it_) * NTH) & 3)) < a.Cin4)
+#define LOAD_HALO(chunk_, on_) do { const int c0_ = (chunk_) * KC; unsigned vo_[HIT]; \
+        if (on_) { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = HALO_OK(it, c0_) ? (unsigned)(goff[it] + c0_) * 4u : 0u; } \
+        else { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = 0u; } \
+        gld_halo<HIT>(hreg, vo_, xb, (on_)); } while (0)
+#define STORE_HALO(dst_, chunk_) do { const int c0_ = (chunk_) * KC; const bool tail_ = has_tail && (chunk_) == a.nchunks - 1; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) { \
+            const int e_ = tid + it * NTH; \
+            if (e_ < HPIX * 4) { \
+                const v4f v_ = HALO_OK(it, c0_) ? hreg[it] : (v4f){0.f, 0.f, 0.f, 0.f}; \
+                if (tail_) { float* row_ = (dst_) + (e_ >> 2) * LDK + (e_ & 3); row_[0] = v_.x; row_[4] = v_.y; row_[8] = v_.z; row_[12] = v_.w; } \
+                else *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDK + (e_ & 3) * 4) = v_; \
+            } } } while (0)
 
-    // operand row bases (floats) WITHOUT the k-lane term: full chunks add 4*kq (b128), tails add 4*j + kq (b32)
-    int abase[M16], bbase[N16];
+    // A-operand row bases (floats) inside the halo tile
+    int abase[M16];
 #pragma unroll
     for (int m = 0; m < M16; ++m) {
         const int pix = (wm * M16 + m) * 16 + l15;
         const int ty = pix / TW, tx = pix % TW;
-        abase[m] = ((ty * S) * HW + tx * S) * LDK;
+        abase[m] = ((ty * S) * HW + tx * S) * LDK + 4 * kq;
     }
-#pragma unroll
     // 16-wide output-channel tiles are dealt round-robin to the WN waves (tile n of this wave = block tile n*WN + wn), so the
     // tiles that survive the Cout cut-off are balanced between the waves' MFMA pipes
-    for (int n = 0; n < N16; ++n) bbase[n] = ((n * WN + wn) * 16 + l15) * LDK;
     // number of this wave's tiles that contain a real channel: tiles n with (n*WN + wn)*16 < Cout - n0
     int nvalid = ((a.Cout - n0 + 15) / 16 - wn + WN - 1) / WN;
     nvalid = (a.Cout - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    // operand B: uniform slab pointer + one 32-bit per-lane byte offset (tile n is n * WN * 16 columns = n * WN KiB further),
+    // loaded unconditionally (the packed image is padded to the block's 128 columns) so every stage issues exactly N16 loads
+    const unsigned lane_b = (unsigned)(((wn * 16 + l15) * KC + 4 * kq) * sizeof(float));
+    const char* wbase = reinterpret_cast<const char*>(a.wp + (size_t)n0 * KC);
+    const size_t slab_b = (size_t)a.coutPad * KC * sizeof(float);
+    constexpr int TSTR = WN * 16 * KC * 4;    // bytes between two of this wave's tiles (<= 2 KiB: fits the immediate offset)
+    v4f b0[N16], b1[N16];
+#define LOAD_B(dst_, widx_, chunk_) gld_b<TSTR, N16>((dst_), lane_b, wbase + (size_t)((widx_) * a.nchunks + (chunk_)) * slab_b)
 
     f32x4 acc[M16][N16];
 #pragma unroll
@@ -399,70 +499,90 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
         for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ntaps = ts.n;
-    LOAD_HALO(0);
-    LOAD_W(ts.widx[0], 0);
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+    LOAD_HALO(0, true);
+    LOAD_B(b0, ts.widx[0], 0);
+    wait_loads(b0, hreg);
     STORE_HALO(halo_buf(0), 0);
-    STORE_W(wts_buf(0));
     __syncthreads();
 
-    int s = 0;
-    const int total = a.nchunks * ntaps;
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const int rem = a.Cin - chunk * KC;      // real reduction channels left in this chunk
-        const int ksteps = rem >= KC ? 4 : ((rem + 3) >> 2);   // tail chunk: channel-transposed, step kk = channels 4kk..4kk+3
-        const float* hb = halo_buf(chunk & 1);
-        for (int t = 0; t < ntaps; ++t, ++s) {
-            const bool has_next = (s + 1) < total;
-            if (has_next) {
-                const bool wrap = (t + 1 == ntaps);
-                LOAD_W(s_widx[wrap ? 0 : t + 1], wrap ? chunk + 1 : chunk);
-            }
-            const bool halo_next = (chunk + 1 < a.nchunks);
-            if (t == 0 && halo_next) LOAD_HALO(chunk + 1);
+    // Stage = (chunk, tap).  The loop body is written twice (operand B ping-pongs between b0 and b1 without register copies).
+    // Loads in flight: the next stage's B tiles and, during the first tap of a chunk, the next chunk's halo items; both are
+    // issued at the top of a stage and waited for at its end (behind the stage's 64 MFMAs).
+    int t = 0, chunk = 0;
+    int ksteps = a.Cin >= KC ? 4 : ((a.Cin + 3) >> 2);   // tail chunk: channel-transposed, step kk = channels 4kk..4kk+3
+    const float* hb = halo_buf(0);
+    // Every stage ends in ONE wait asm that (re)defines both the B tiles and the halo registers, on every path, so the
+    // compiler has no merge point of its own between a load and its wait where it could copy a register that is still in
+    // flight; tests/test_isa_cpu.py checks the generated ISA for exactly that.
+#define STAGE_BODY(bu_, bl_, FULL_) do { \
+        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks);   /* EXEC-masked off in the other stages */ \
+        /* after the last stage: a dummy reload of slab 0 keeps the number of loads per stage fixed */ \
+        LOAD_B(bl_, has_next_ ? TAP_WIDX(tn_) : 0, has_next_ ? cn_ : 0); \
+        const float* ha_ = hb + TAP_OFF(t); \
+        float av_[M16][4]; \
+        _Pragma("unroll") for (int m = 0; m < M16; ++m) { \
+            const float4 f_ = *reinterpret_cast<const float4*>(ha_ + abase[m]); \
+            av_[m][0] = f_.x; av_[m][1] = f_.y; av_[m][2] = f_.z; av_[m][3] = f_.w; \
+        } \
+        if (FULL_) {   /* full 16-channel chunk: one uniform branch per 16-wide output tile, 16 MFMAs behind each */ \
+            _Pragma("unroll") for (int n = 0; n < N16; ++n) { \
+                if (n < nvalid) { \
+                    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) \
+                        _Pragma("unroll") for (int m = 0; m < M16; ++m) \
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[m][kk], (bu_)[n][kk], acc[m][n], 0, 0, 0); \
+                } \
+            } \
+        } else {       /* may be the tail chunk: k-steps beyond the real channels are skipped as well */ \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
+                if (kk < ksteps) { \
+                    _Pragma("unroll") for (int n = 0; n < N16; ++n) { \
+                        if (n < nvalid) { \
+                            _Pragma("unroll") for (int m = 0; m < M16; ++m) \
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[m][kk], (bu_)[n][kk], acc[m][n], 0, 0, 0); \
+                        } \
+                    } \
+                } \
+            } \
+        } \
+        wait_loads(bl_, hreg); \
+    } while (0)
+#define STAGE(bu_, bl_, FULL_) do { \
+        int tn_ = t + 1, cn_ = chunk; \
+        if (tn_ == ntaps) { tn_ = 0; cn_ = chunk + 1; } \
+        const bool has_next_ = cn_ < a.nchunks; \
+        STAGE_BODY(bu_, bl_, FULL_); \
+        if (tn_ == 0 && has_next_) { \
+            STORE_HALO(halo_buf(cn_ & 1), cn_); \
+            __syncthreads(); \
+            hb = halo_buf(cn_ & 1); \
+            const int rem_ = a.Cin - cn_ * KC; \
+            ksteps = rem_ >= KC ? 4 : ((rem_ + 3) >> 2); \
+        } \
+        t = tn_; chunk = cn_; \
+    } while (0)
 
-            const float* wb = wts_buf(s & 1);
-            const float* ha = hb + s_tapoff[t];
-            {
-                float av[M16][4], bv[N16][4];
-#pragma unroll
-                for (int m = 0; m < M16; ++m) {
-                    const float4 f = *reinterpret_cast<const float4*>(ha + abase[m] + 4 * kq);
-                    av[m][0] = f.x; av[m][1] = f.y; av[m][2] = f.z; av[m][3] = f.w;
-                }
-#pragma unroll
-                for (int n = 0; n < N16; ++n) {
-                    const float4 f = *reinterpret_cast<const float4*>(wb + bbase[n] + 4 * kq);
-                    bv[n][0] = f.x; bv[n][1] = f.y; bv[n][2] = f.z; bv[n][3] = f.w;
-                }
-#ifdef UNET_CONV_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kk < ksteps) {
-#pragma unroll
-                        for (int n = 0; n < N16; ++n) {
-                            if (n < nvalid) {
-#pragma unroll
-                                for (int m = 0; m < M16; ++m)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][kk], bv[n][kk], acc[m][n], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-#ifdef UNET_CONV_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
-            if (has_next) STORE_W(wts_buf((s + 1) & 1));
-            if (t == ntaps - 1 && halo_next) STORE_HALO(halo_buf((chunk + 1) & 1), chunk + 1);
-            __syncthreads();
-        }
+    // The stages of the full 16-channel chunks run first (an even number of them, so that the b0/b1 roles line up), with
+    // compile-time 4 k-steps; the remaining stages -- the tail chunk when Cin % 16 != 0 -- run the guarded form.
+    const int total = a.nchunks * ntaps;
+    const int total_full = ((has_tail ? a.nchunks - 1 : a.nchunks) * ntaps) & ~1;
+    for (int s = 0; s < total_full; s += 2) {
+        STAGE(b0, b1, true);
+        STAGE(b1, b0, true);
     }
+    for (int s = total_full; s < total; s += 2) {
+        STAGE(b0, b1, false);
+        if (s + 1 < total) STAGE(b1, b0, false);
+    }
+#undef STAGE_BODY
+#undef TAP_OFF
+#undef TAP_WIDX
+#undef STAGE
+#undef HALO_OK
 #undef LOAD_HALO
 #undef STORE_HALO
-#undef LOAD_W
-#undef STORE_W
+#undef LOAD_B
 
     // ---- epilogue (phased as in the 32x32 kernel) ----
     const bool relu = a.flags & UNET_CONV_RELU;
@@ -684,6 +804,17 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
             }
     }
 
+    for (int z = 0; z < p->nparity; ++z) {
+        TapSet& t = k.taps[z];
+        t.dpack = 0; t.wpack = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const int dyi = t.dy[i] - t.min_dy, dxi = t.dx[i] - t.min_dx;
+            UNET_CHECK_ARG(dyi >= 0 && dyi < 4 && dxi >= 0 && dxi < 4 && t.widx[i] >= 0 && t.widx[i] < 16, "conv: tap table out of range");
+            t.dpack |= (unsigned long long)(dyi | (dxi << 2)) << (4 * i);
+            t.wpack |= (unsigned long long)t.widx[i] << (4 * i);
+        }
+    }
+
     p->tw = k.TSW >= 32 ? 32 : (k.TSW >= 16 ? 16 : 8);
     p->bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     p->bm = 128;
@@ -709,7 +840,8 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
         if (hh * hw > max_hpix) max_hpix = hh * hw;
     }
     UNET_CHECK_ARG(max_hpix * 4 <= p->hit * 256, "conv: halo tile too large (%d pixels)", max_hpix);
-    p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + 2 * p->bn * LDK) * sizeof(float);
+    // the 16x16x4 kernel keeps no filter slab in LDS (operand B goes global -> VGPR)
+    p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + (p->mf == 16 ? 0 : 2 * p->bn * LDK)) * sizeof(float);
     p->grid = dim3((unsigned)((long long)k.mtiles * k.ntn), 1, (unsigned)p->nparity);
     UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");
     return UNET_OK;
