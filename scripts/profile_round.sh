@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU-side evidence run for profiles/: bench line, rocprofv3 kernel stats, two separate PMC passes (HBM traffic), SQ pass.
+# usage (from the repo root, through gpurun): bash scripts/profile_round.sh <tag>
+TAG=${1:-r01_x}
+R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+tail -1 $OUT/bench.json | cut -c1-200
+export TMPDIR=/tmp; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1 || { echo "stats pass failed"; exit 1; }
+echo stats done
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { echo "write pass failed"; exit 1; }
+echo write done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 || { echo "sq pass failed"; exit 1; }
+echo sq done

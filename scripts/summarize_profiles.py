@@ -1,0 +1,77 @@
+"""Turn gpurun_out/prof_<tag>/ (written by scripts/profile_round.sh on the GPU box) into the committed summaries:
+profiles/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_summary.csv and profiles/pmc_traffic.json.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 counts a 128-B read as 64 B in FETCH_SIZE
+(MI355X_MICROARCH.md, HBM / rocprofv3 section); the two counters come from SEPARATE passes.
+usage: python scripts/summarize_profiles.py <tag>
+"""
+import collections, csv, glob, json, re, shutil, sys
+from pathlib import Path
+
+tag = sys.argv[1]
+root = Path(__file__).resolve().parent.parent
+src = root / "gpurun_out" / f"prof_{tag}"
+dst = root / "profiles"
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    return name.replace(" ", "")
+
+
+def pmc(dirname):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    f = glob.glob(str(src / dirname / "*" / "*_counter_collection.csv"))
+    if not f:
+        return out
+    for r in csv.DictReader(open(f[0])):
+        out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def durations(dirname):
+    out = collections.defaultdict(list)
+    f = glob.glob(str(src / dirname / "*" / "*_kernel_trace.csv"))
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            out[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return out
+
+
+shutil.copy(src / "bench.json", dst / f"{tag}_bench.json")
+stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))[0]
+shutil.copy(stats, dst / f"{tag}_bench_kernel_stats.csv")
+
+fetch, write, sq, sqdur = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), durations("pmc_sq")
+traffic = {}
+rows = []
+for k in sorted(set(fetch) | set(write) | set(sq)):
+    fa = fetch[k].get("FETCH_SIZE", [])
+    wa = write[k].get("WRITE_SIZE", [])
+    row = {"kernel": k, "launches": len(fa) or len(wa)}
+    if fa and wa:
+        f_avg, w_avg = sum(fa) / len(fa), sum(wa) / len(wa)
+        hbm = (2 * f_avg + w_avg) * 1024
+        row.update(FETCH_SIZE_KB_avg=round(f_avg, 1), WRITE_SIZE_KB_avg=round(w_avg, 1), hbm_bytes_per_launch=int(hbm))
+        traffic[k] = {"launches_sampled": len(fa), "FETCH_SIZE_KB_avg": round(f_avg, 1), "WRITE_SIZE_KB_avg": round(w_avg, 1),
+                      "hbm_bytes_per_launch": int(hbm),
+                      "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B reads as 64 B); WRITE_SIZE as is"}
+    if k in sq and sq[k].get("SQ_BUSY_CU_CYCLES"):
+        busy = sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / max(1.0, 4 * sum(sq[k]["SQ_BUSY_CU_CYCLES"]))
+        row["mfma_busy_frac"] = round(busy, 4)
+        d = sqdur.get(k)
+        if d:
+            row["eff_clock_ghz"] = round(sum(sq[k]["GRBM_GUI_ACTIVE"]) / 8 / sum(d), 3)
+    rows.append(row)
+cols = ["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch", "mfma_busy_frac", "eff_clock_ghz"]
+with open(dst / f"{tag}_pmc_summary.csv", "w", newline="") as fh:
+    w = csv.DictWriter(fh, fieldnames=cols)
+    w.writeheader()
+    for r in rows:
+        w.writerow(r)
+json.dump(traffic, open(dst / "pmc_traffic.json", "w"), indent=1)
+print(open(dst / f"{tag}_bench.json").read()[-1200:])
+for r in sorted(rows, key=lambda r: -r.get("hbm_bytes_per_launch", 0))[:8]:
+    print(r)

@@ -31,7 +31,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 16;   // reduction channels per chunk
-constexpr int LDK = 20;  // LDS row length in floats (16 + 4 pad)
+constexpr int LDK = 20;  // LDS row length in floats (16 + 4 pad); 24 would make the 16x16x4 operand reads conflict-free, measured no gain
 
 struct TapSet {
     int n;              // number of taps
