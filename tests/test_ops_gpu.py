@@ -128,6 +128,12 @@ WGRAD_CASES = [
     (2, 16, 16, 128, 256, 1, 1),
     (2, 32, 32, 100, 5, 1, 1),
     (4, 64, 64, 64, 64, 3, 1),        # several split-K partials
+    # narrow-output kernel (taps flattened into the column dimension): 80 < Cout <= 112, width >= 32
+    (1, 33, 64, 192, 96, 3, 1),       # two input-channel chunks of 96, 6 output tiles x 7 column tiles per wave
+    (2, 32, 40, 96, 96, 3, 1),        # ragged last tile row (40 = 32 + 8)
+    (1, 35, 37, 100, 112, 3, 1),      # full 7 output tiles
+    (2, 34, 32, 36, 100, 3, 1),       # short chunk: 9 * 36 = 324 columns, most column blocks idle
+    (1, 32, 33, 230, 84, 3, 1),       # three chunks of 80/80/70 channels (chunk width not a divisor of Cin)
 ]
 
 

@@ -35,6 +35,7 @@ struct WArgs {
     int N, IH, IW, Cin, Cin4, OH, OW, Cout, Cout4;
     int tiles_y, tiles_x, total_tiles, tiles_per_block;
     int kt, ct;  // number of k / c block tiles
+    int cw, nnb; // narrow-output kernel: input-channel chunk width, column blocks per chunk
 };
 
 template <int PTW, int S, int KS>
@@ -323,127 +324,161 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Narrow-output weight gradient (3x3, stride 1, Cout <= 112, image width >= 32): the 100->100 pair of the final ResBlock and
-// the 96-wide last UnetBlock.  16-channel granularity with EVEN work per wave: a workgroup = 3 waves = the 3 filter rows of
-// ONE 16-wide input-channel tile; every wave keeps all (<= 7) output-channel tiles x its 3 taps live (21 f32x4
-// accumulators) and reads 7 + 3 operands per 21 MFMAs (v_mfma_f32_16x16x4_f32).  grid = (input-channel tiles, pixel splits);
-// 37 KB of LDS and < 168 VGPRs let 4 workgroups (12 waves, 3 per SIMD) share a CU, which hides the tile staging.
-template <int PTW>
-__global__ __launch_bounds__(192, 3) void wgrad_narrow_kernel(const WArgs a) {
-    constexpr int PT = 64, PTH = PT / PTW, LD = 112, NT = 192;
-    constexpr int HWW = PTW + 2, HHH = PTH + 2, HPIX = HHH * HWW;
-    constexpr int DIT = (PT * 28 + NT - 1) / NT;     // dy float4 items per thread (rows of 28 float4)
-    constexpr int XIT = (HPIX * 4 + NT - 1) / NT;    // x  float4 items per thread (rows of 4 float4)
+// Narrow-output weight gradient (3x3, stride 1, 80 < Cout <= 112, image width >= 32): the 100->100 pair of the final ResBlock
+// and the 96-wide last UnetBlock, where the 64x64-tiled kernel pads both channel counts to 128 (1.64x / 1.78x the MFMAs).
+// GEMM view with the filter taps FLATTENED into the N dimension:
+//     dW[k][n] = sum_p dy[p][k] * X[p][n],   n = t * CW + c  (tap t, channel c of a <= 112-wide input-channel chunk)
+// so that M = Cout pads to 16 and N = 9 * CW pads to 16 ONCE (100x100: 7 x 57 tiles of 16x16 instead of 8 x 8 x 9 / 4).
+// A wave owns all KT output-channel tiles x NTW column tiles (35 or 42 f32x4 accumulators), a workgroup of 4 waves
+// 4 * NTW consecutive column tiles; grid = (chunks x column blocks, pixel splits).  Pixel tile = one image row of 32 pixels,
+// tiles walk down a column strip; dy tile [32][112] and a ring of 3 input rows [3 x 34][112] in LDS (60 KB: two workgroups per CU).  Row stride 112 = 16 mod 32 makes the
+// two pixel rows of a 32-lane ds_read_b32 group hit disjoint banks.
+//   v_mfma_f32_16x16x4_f32: A[i=l&15][kk=l>>4] = dy[pixel 4*step+kk][16*mt + i]
+//                           B[kk=l>>4][j=l&15] = x[pixel 4*step+kk shifted by tap(n)][c(n)],  n = 16*tile + j
+template <int KT, int NTW>
+__global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
+    constexpr int PT = 32, HW = 34, HPIX = 3 * HW, LD = 112, Q = LD / 4;
+    constexpr int DIT = (PT * Q + 255) / 256, XIT = (HPIX * Q + 255) / 256;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dyT = smem;               // [PT][112]            all output channels (zero padded); 112 == 16 (mod 32): conflict-free k-lanes
-    float* xh = smem + PT * LD;      // [PTH+2][PTW+2][16]   halo of this workgroup's 16 input channels
+    float* dyT = smem;              // [PT][LD]
+    float* xh = smem + PT * LD;     // [HPIX][LD]
 
-    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6;      // wave index = filter row
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int c0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int chunk = blockIdx.x / a.nnb, nb = blockIdx.x % a.nnb;
+    const int c0 = chunk * a.cw;
+    const int CW = (a.Cin - c0) < a.cw ? (a.Cin - c0) : a.cw;     // channels of this chunk
+    const int NTOT = 9 * CW;                                        // real columns
     const int split = blockIdx.y;
     const int tile_begin = split * a.tiles_per_block;
     int tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
-    const int KT = (a.Cout + 15) >> 4;                       // <= 7
 
-    f32x4 acc[7][3];
+    // per-lane operand bases (floats): column n -> (tap row r, tap column s, channel c).  The halo tile is a RING of three
+    // image rows (row iy lives in slot (iy + 3) % 3): pixel tiles walk DOWN a 32-pixel column strip, so a new tile only
+    // fetches the one input row it does not share with its predecessor; the slot of tap row r changes per tile.
+    int bfix[NTW], brow[NTW];
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NTW; ++q) {
+        const int n = ((nb * 4 + wave) * NTW + q) * 16 + l15;
+        const int nn = n < NTOT ? n : 0;          // columns beyond 9*CW compute garbage that is never stored
+        const int t = nn / CW, c = nn - t * CW;
+        const int r = t / 3, s_ = t - 3 * r;
+        bfix[q] = (s_ + kk) * LD + c;
+        brow[q] = r;
+    }
+    const int abase = kk * LD + l15;
 
-    auto stage_tile = [&](int tile) {
+    f32x4 acc[KT][NTW];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Stage one pixel tile (global -> registers -> LDS, batches of 4 float4 per thread); pixels outside the image are zero,
+    // channels beyond the chunk are never read back.  tile = (img * tiles_x + tx) * OH + oy.
+    auto stage_tile = [&](int tile, bool first) {
         int b = tile;
-        const int tx = b % a.tiles_x; b /= a.tiles_x;
-        const int ty = b % a.tiles_y;
-        const int img = b / a.tiles_y;
-        const int oy0 = ty * PTH, ox0 = tx * PTW;
-        const float* dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
-        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
-        constexpr int DB = 5;
+        const int oy = b % a.OH; b /= a.OH;
+        const int tx = b % a.tiles_x;
+        const int img = b / a.tiles_x;
+        const int ox0 = tx * PT;
+        const float* dyb = a.dy + ((size_t)img * a.OH + oy) * a.OW * a.dy_cs + a.dy_co;
+        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs + a.x_co + c0;
+        {
+            float4 r[DIT];
 #pragma unroll
-        for (int base = 0; base < DIT; base += DB) {
-            float4 rd[DB];
-#pragma unroll
-            for (int j = 0; j < DB; ++j) {
-                const int e = tid + (base + j) * NT;
-                const int p = e / 28, q = e - p * 28;
-                const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
-                const bool ok = (e < PT * 28) && oy < a.OH && ox < a.OW && 4 * q < a.Cout4;
-                rd[j] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + 4 * q)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                const int p = e / Q, q = e - p * Q;
+                const bool ok = (e < PT * Q) && (ox0 + p) < a.OW && 4 * q < a.Cout4;
+                r[it] = ok ? *reinterpret_cast<const float4*>(dyb + (size_t)(ox0 + p) * a.dy_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int j = 0; j < DB; ++j) {
-                const int e = tid + (base + j) * NT;
-                if (e < PT * 28) *reinterpret_cast<float4*>(dyT + e * 4) = rd[j];
+            for (int it = 0; it < DIT; ++it) {
+                const int e = tid + it * 256;
+                if (e < PT * Q) *reinterpret_cast<float4*>(dyT + e * 4) = r[it];
             }
         }
-        float4 rx[XIT];
-        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+        const int cw4 = (CW + 3) & ~3;
+        // input rows to fetch: all three at the top of a column strip / at the start of this workgroup's range, else oy + 1 only
+        const int hy0 = (first || oy == 0) ? 0 : 2;
+        constexpr int RIT = (HW * Q + 255) / 256;     // float4 items per thread per input row
+        for (int hy = hy0; hy < 3; ++hy) {
+            const int iy = oy - 1 + hy;
+            float* dst = xh + ((iy + 3) % 3) * (HW * LD);
+            float4 r[RIT];
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = tid + it * NT;
-            const int p = e >> 2, q = e & 3;
-            const int iy = iy0 + p / HWW, ix = ix0 + p % HWW;
-            const bool ok = (e < HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
-            rx[it] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int j = 0; j < RIT; ++j) {
+                const int e = tid + j * 256;
+                const int hx = e / Q, q = e - hx * Q;
+                const int ix = ox0 - 1 + hx;
+                const bool ok = (e < HW * Q) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && 4 * q < cw4;
+                r[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = tid + it * NT;
-            if (e < HPIX * 4) *reinterpret_cast<float4*>(xh + e * 4) = rx[it];
+            for (int j = 0; j < RIT; ++j) {
+                const int e = tid + j * 256;
+                if (e < HW * Q) *reinterpret_cast<float4*>(dst + e * 4) = r[j];
+            }
         }
+        return oy;
     };
 
-    const float* abase = dyT + kq * LD + l15;                         // + (4*step)*LD + 16*kt
-    const float* bbase = xh + (r * HWW + kq) * 16 + l15;              // + (py*HWW + px + s)*16
-    const bool do_bias = a.bpart != nullptr && blockIdx.x == 0 && tid < LD;
+    // bias gradient: the first workgroup column sums the staged dy tile (one thread per output channel)
+    const bool do_bias = a.bpart != nullptr && blockIdx.x == 0 && tid < a.Cout;
     float bsum = 0.f;
-
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        stage_tile(tile);
+        const int oy = stage_tile(tile, tile == tile_begin);
         __syncthreads();
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
         }
+        int bq[NTW];
 #pragma unroll
-        for (int step = 0; step < PT / 4; ++step) {
-            const int py = (4 * step) / PTW, px = (4 * step) % PTW;
-            float av[7], bv[3];
+        for (int q = 0; q < NTW; ++q) bq[q] = bfix[q] + ((oy + 2 + brow[q]) % 3) * (HW * LD);   // tap row r reads input row oy - 1 + r
+        // (a full unroll hoists all 96 operand loads and spills; the 42-accumulator form only has room for one step's operands)
+        auto mma_step = [&](int step) {
+            float av[KT], bv[NTW];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) av[k] = (k < KT) ? abase[(4 * step) * LD + 16 * k] : 0.f;
+            for (int m = 0; m < KT; ++m) av[m] = dyT[abase + step * 4 * LD + m * 16];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bv[t] = bbase[(py * HWW + px + t) * 16];
+            for (int q = 0; q < NTW; ++q) bv[q] = xh[bq[q] + step * 4 * LD];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                if (k < KT) {
+            for (int m = 0; m < KT; ++m)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[t], acc[k][t], 0, 0, 0);
-                }
-            }
-            if ((step & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // bound the operand prefetch depth (register pressure)
+                for (int q = 0; q < NTW; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+        };
+        if constexpr (KT * NTW > 36) {
+#pragma unroll 1
+            for (int step = 0; step < PT / 4; ++step) mma_step(step);
+        } else {
+#pragma unroll 2
+            for (int step = 0; step < PT / 4; ++step) mma_step(step);
         }
         __syncthreads();
     }
 
-    if (do_bias && tid < a.Cout) a.bpart[(size_t)split * a.Cout + tid] = bsum;
+    if (do_bias) a.bpart[(size_t)split * a.Cout + tid] = bsum;
+    // ---- write partials: part[split][tap][k][c] ----
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * 9 * KC_;
-    const int c = c0 + l15;
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int q = 0; q < NTW; ++q) {
+        const int n = ((nb * 4 + wave) * NTW + q) * 16 + l15;
+        if (n >= NTOT) continue;
+        const int t = n / CW, c = n - t * CW;
+        float* pt = pb + (size_t)t * KC_ + c0 + c;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int m = 0; m < KT; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ko = 16 * k + 4 * kq + q;
-                if (ko < a.Cout && c < a.Cin) pb[(size_t)(r * 3 + t) * KC_ + (size_t)ko * a.Cin + c] = acc[k][t][q];
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * m + 4 * kk + r;
+                if (k < a.Cout) pt[(size_t)k * a.Cin] = acc[m][q][r];
             }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -577,10 +612,8 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float*
     dbias[c] = (float)s;
 }
 
-// wgrad_narrow_kernel is OPT-IN (unet_set_wgrad_narrow(1)): it removes the channel padding of the 96/100-wide layers and wins
-// 5-25 % in isolation, but inside the full step it measured 25-40 % slower than the 64x64-tiled kernel on the same launches
-// (run-to-run 9.0 .. 13.8 ms on the 100->100 layer): left for a later round, see DESIGN.md.
-static int g_wgrad_narrow = 0;
+// narrow-output kernel (wgrad_flat_kernel) for 80 < Cout <= 112; unet_set_wgrad_narrow(0) falls back to the 64x64-tiled kernel
+static int g_wgrad_narrow = 1;
 static int g_wgrad_1x1 = 1;           // 128x128-tiled GEMM kernel for 1x1 weight gradients
 
 struct WPlan {
@@ -617,16 +650,19 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.total_tiles = d->N * k.tiles_y * k.tiles_x;
     k.kt = unet::cdiv(d->Cout, BK);
     k.ct = unet::cdiv(d->Cin, BC);
-    // narrow-output specialisation: all output-channel tiles per wave, 7 input-channel tiles x 1 filter row per workgroup
-    // (only where the 64x64-tiled kernel would pad: 64 < Cout <= 112; exact multiples of 64 stay on the 32x32x2 form)
-    p->narrow = (g_wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 64 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
+    // narrow-output specialisation (taps flattened into the column dimension): only where the 64x64-tiled kernel pads
+    p->narrow = (g_wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 80 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
     int cols = k.kt * k.ct;
     if (p->narrow) {
         p->ptw = 32;
-        k.tiles_y = unet::cdiv(d->OH, 2);
+        k.tiles_y = d->OH;
         k.tiles_x = unet::cdiv(d->OW, 32);
         k.total_tiles = d->N * k.tiles_y * k.tiles_x;
-        cols = unet::cdiv(d->Cin, 16);
+        const int nch = unet::cdiv(d->Cin, 112);
+        k.cw = unet::roundup(unet::cdiv(d->Cin, nch), 4);
+        const int ntw = d->Cout > 96 ? 5 : 7;                     // column tiles per wave (KT = 7 / 6 output-channel tiles)
+        k.nnb = unet::cdiv(unet::cdiv(9 * k.cw, 16), 4 * ntw);
+        cols = nch * k.nnb;
     }
     p->gemm1x1 = (d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
     if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
@@ -732,14 +768,16 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
         UNET_CHECK_LAUNCH();
         rc = UNET_OK;
     } else if (p.narrow) {
-        auto kern = wgrad_narrow_kernel<32>;
+        const size_t lds = (size_t)(32 + 3 * 34) * 112 * sizeof(float);
+        const dim3 grid(unet::cdiv(d->Cin, p.k.cw) * p.k.nnb, p.splits);
         static bool configured = false;
         if (!configured) {
-            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<6, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             configured = true;
         }
-        const size_t lds = (size_t)(64 * 112 + 4 * 34 * 16) * sizeof(float);
-        hipLaunchKernelGGL(kern, dim3(unet::cdiv(d->Cin, 16), p.splits), dim3(192), lds, st, p.k);
+        if (d->Cout > 96) hipLaunchKernelGGL((wgrad_flat_kernel<7, 5>), grid, dim3(256), lds, st, p.k);
+        else hipLaunchKernelGGL((wgrad_flat_kernel<6, 7>), grid, dim3(256), lds, st, p.k);
         UNET_CHECK_LAUNCH();
         rc = UNET_OK;
     } else
