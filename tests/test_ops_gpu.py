@@ -499,18 +499,21 @@ def test_row_softmax_and_strided_pack(ops):
     assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv")
 
 
-def test_wgrad_narrow_kernel(ops):
-    """narrow-output weight gradient (64 < Cout <= 112, 3x3 s1, W >= 32; opt-in) against torch, incl. bias gradient and ragged tiles"""
+@pytest.mark.parametrize("narrow", [1, 0])
+def test_wgrad_narrow_kernel(ops, narrow):
+    """narrow-output weight gradient (80 < Cout <= 112, 3x3 s1, W >= 32; default on) and its 64x64-tiled fallback on the same
+    cases against torch, incl. bias gradient, ragged tiles and input-channel chunking"""
     from unet_amd._lib import lib
-    lib.unet_set_wgrad_narrow(1)
+    lib.unet_set_wgrad_narrow(narrow)
     try:
         _narrow_cases(ops)
     finally:
-        lib.unet_set_wgrad_narrow(0)
+        lib.unet_set_wgrad_narrow(1)
 
 
 def _narrow_cases(ops):
-    for case in [(2, 40, 48, 100, 100), (1, 34, 64, 192, 96), (2, 32, 32, 96, 96), (1, 37, 45, 36, 100), (1, 32, 40, 250, 80)]:
+    for case in [(2, 40, 48, 100, 100), (1, 34, 64, 192, 96), (2, 32, 32, 96, 96), (1, 37, 45, 36, 100), (1, 32, 40, 250, 81),
+                 (3, 5, 33, 100, 100)]:
         N, H, W, Cin, Cout = case
         g = torch.Generator().manual_seed(sum(case))
         x = torch.randn(N, Cin, H, W, generator=g)

@@ -7,11 +7,9 @@
 // BM(=128 pixel) x BN(32/64/128 channel) output tile:
 //   * the input HALO tile of the spatial tile is staged ONCE per 16-channel
 //     chunk into LDS and re-used by all 9 taps (no im2col, 9x less L2->LDS traffic);
-//   * the filter slab of one (tap, chunk) is staged per stage from a pre-packed
-//     [tap][chunk][cout][16] image (fully coalesced 16-B loads);
-//   * both are double buffered: global loads for stage s+1 are issued before the
-//     MFMAs of stage s and written to the other LDS buffer after them, one
-//     barrier per stage;
+//   * the filter slab of one (tap, chunk) comes from a pre-packed [tap][chunk][cout][16] image (fully coalesced 16-B
+//     loads): the 32x32x2 kernel stages it through LDS (double buffered, one barrier per stage), the default 16x16x4
+//     kernel loads it straight into MFMA operand registers one stage ahead (one barrier per chunk);
 //   * LDS rows are 20 floats (16 + 4 pad) so that the ds_read_b128 operand
 //     fetches (4 k-values per lane) are bank-conflict free;
 //   * v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];

@@ -376,62 +376,83 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
 #pragma unroll
         for (int q = 0; q < NTW; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Stage one pixel tile (global -> registers -> LDS, batches of 4 float4 per thread); pixels outside the image are zero,
-    // channels beyond the chunk are never read back.  tile = (img * tiles_x + tx) * OH + oy.
-    auto stage_tile = [&](int tile, bool first) {
+    // Staging (global -> registers -> LDS); pixels outside the image are zero, channels beyond the chunk are never read
+    // back.  tile = (img * tiles_x + tx) * OH + oy.  The 35-accumulator form has 32 registers to spare: it fetches the next
+    // tile's dy rows and its one new input row BEFORE the MFMA loop of the current tile and stores them after it.
+    constexpr bool PF = (KT * NTW <= 36);
+    constexpr int RIT = (HW * Q + 255) / 256;     // float4 items per thread per input row
+    const int cw4 = (CW + 3) & ~3;
+    struct TilePos { int oy, ox0; const float* dyb; const float* xb; };
+    auto tile_pos = [&](int tile) {
         int b = tile;
-        const int oy = b % a.OH; b /= a.OH;
+        TilePos t;
+        t.oy = b % a.OH; b /= a.OH;
         const int tx = b % a.tiles_x;
         const int img = b / a.tiles_x;
-        const int ox0 = tx * PT;
-        const float* dyb = a.dy + ((size_t)img * a.OH + oy) * a.OW * a.dy_cs + a.dy_co;
-        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs + a.x_co + c0;
-        {
-            float4 r[DIT];
+        t.ox0 = tx * PT;
+        t.dyb = a.dy + ((size_t)img * a.OH + t.oy) * a.OW * a.dy_cs + a.dy_co;
+        t.xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs + a.x_co + c0;
+        return t;
+    };
+    auto load_dy = [&](const TilePos& t, float4 (&r)[DIT]) {
 #pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int e = tid + it * 256;
-                const int p = e / Q, q = e - p * Q;
-                const bool ok = (e < PT * Q) && (ox0 + p) < a.OW && 4 * q < a.Cout4;
-                r[it] = ok ? *reinterpret_cast<const float4*>(dyb + (size_t)(ox0 + p) * a.dy_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int e = tid + it * 256;
-                if (e < PT * Q) *reinterpret_cast<float4*>(dyT + e * 4) = r[it];
-            }
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + it * 256;
+            const int p = e / Q, q = e - p * Q;
+            const bool ok = (e < PT * Q) && (t.ox0 + p) < a.OW && 4 * q < a.Cout4;
+            r[it] = ok ? *reinterpret_cast<const float4*>(t.dyb + (size_t)(t.ox0 + p) * a.dy_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int cw4 = (CW + 3) & ~3;
-        // input rows to fetch: all three at the top of a column strip / at the start of this workgroup's range, else oy + 1 only
-        const int hy0 = (first || oy == 0) ? 0 : 2;
-        constexpr int RIT = (HW * Q + 255) / 256;     // float4 items per thread per input row
+    };
+    auto store_dy = [&](const float4 (&r)[DIT]) {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + it * 256;
+            if (e < PT * Q) *reinterpret_cast<float4*>(dyT + e * 4) = r[it];
+        }
+    };
+    auto load_row = [&](const TilePos& t, int hy, float4 (&r)[RIT]) {      // input row oy - 1 + hy
+        const int iy = t.oy - 1 + hy;
+#pragma unroll
+        for (int j = 0; j < RIT; ++j) {
+            const int e = tid + j * 256;
+            const int hx = e / Q, q = e - hx * Q;
+            const int ix = t.ox0 - 1 + hx;
+            const bool ok = (e < HW * Q) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && 4 * q < cw4;
+            r[j] = ok ? *reinterpret_cast<const float4*>(t.xb + ((size_t)iy * a.IW + ix) * a.x_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_row = [&](const TilePos& t, int hy, const float4 (&r)[RIT]) {
+        float* dst = xh + ((t.oy + 2 + hy) % 3) * (HW * LD);               // ring slot of row iy = (iy + 3) % 3
+#pragma unroll
+        for (int j = 0; j < RIT; ++j) {
+            const int e = tid + j * 256;
+            if (e < HW * Q) *reinterpret_cast<float4*>(dst + e * 4) = r[j];
+        }
+    };
+    auto stage_rows = [&](const TilePos& t, int hy0) {
+        float4 rd[DIT];
+        load_dy(t, rd);
+        store_dy(rd);
         for (int hy = hy0; hy < 3; ++hy) {
-            const int iy = oy - 1 + hy;
-            float* dst = xh + ((iy + 3) % 3) * (HW * LD);
-            float4 r[RIT];
-#pragma unroll
-            for (int j = 0; j < RIT; ++j) {
-                const int e = tid + j * 256;
-                const int hx = e / Q, q = e - hx * Q;
-                const int ix = ox0 - 1 + hx;
-                const bool ok = (e < HW * Q) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && 4 * q < cw4;
-                r[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < RIT; ++j) {
-                const int e = tid + j * 256;
-                if (e < HW * Q) *reinterpret_cast<float4*>(dst + e * 4) = r[j];
-            }
+            float4 rx[RIT];
+            load_row(t, hy, rx);
+            store_row(t, hy, rx);
         }
-        return oy;
     };
 
     // bias gradient: the first workgroup column sums the staged dy tile (one thread per output channel)
     const bool do_bias = a.bpart != nullptr && blockIdx.x == 0 && tid < a.Cout;
     float bsum = 0.f;
+    if (tile_begin < tile_end) stage_rows(tile_pos(tile_begin), 0);
+    __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int oy = stage_tile(tile, tile == tile_begin);
-        __syncthreads();
+        const int oy = tile % a.OH;
+        const bool has_next = tile + 1 < tile_end;
+        const bool rolling = has_next && oy + 1 < a.OH;      // the next tile is one row further down the same column strip
+        TilePos nx;
+        float4 pd[DIT], px[RIT];
+        if (has_next) nx = tile_pos(tile + 1);
+        if (PF && rolling) { load_dy(nx, pd); load_row(nx, 2, px); }
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
@@ -458,7 +479,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
 #pragma unroll 2
             for (int step = 0; step < PT / 4; ++step) mma_step(step);
         }
-        __syncthreads();
+        if (has_next) {
+            __syncthreads();                 // everyone is done reading this tile (the new row replaces row oy - 1)
+            if (PF && rolling) { store_dy(pd); store_row(nx, 2, px); }
+            else stage_rows(nx, rolling ? 2 : 0);
+            __syncthreads();
+        }
     }
 
     if (do_bias) a.bpart[(size_t)split * a.Cout + tid] = bsum;
