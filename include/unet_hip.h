@@ -198,6 +198,14 @@ int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const
 /* dz = gscale * w[y] * (softmax(z) - onehot(y)) / denom ; gscale multiplies (loss scaling / DDP averaging) */
 int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
                 const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream);
+/* Regression mode (enable_regression, reference train.py:137-138,189-193; utils.py:145-147): n_out = 1, the loss is the mean over all
+ * pixels of kind 0 = (z - t)^2 (MSELossFlat), 1 = |z - t| (L1LossFlat), 2 = SmoothL1(beta) (Smoothl1: beta 0.5).  z = channel z_co of
+ * the NHWC output [P,z_cs], float targets [P]; workspace = unet_ce_workspace(P) floats.
+ * dz = gscale * d loss / d z. */
+int unet_regloss_fwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta,
+                     float* loss /*[1]*/, float* workspace, void* stream);
+int unet_regloss_bwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta, float gscale,
+                     float* dz, int dz_cs, int dz_co, void* stream);
 /* probs NCHW [N,C,H,W] (what Learner.predict returns, predict.py:196-203) and argmax uint8/int64 mask */
 int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, int H, int W, int C,
                         float* probs_nchw /*or NULL*/, int64_t* argmax /*or NULL*/, void* stream);

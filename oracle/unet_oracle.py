@@ -363,6 +363,51 @@ class CrossEntropyLossFlat:
         return x.argmax(dim=self.axis)
 
 
+class _FlatRegLoss:
+    """fastai ``BaseLoss(loss_cls, axis=1, floatify=True, is_2d=False)`` as used by the regression branch
+    (train.py:189-193 ``MSELossFlat(axis=1)``; utils.py:145-147 ``Smoothl1``): both tensors are transposed
+    (axis <-> last), the target is cast to float, both are flattened with ``view(-1)``; 'mean' reduction."""
+    loss_cls, kwargs = nn.MSELoss, {}
+
+    def __init__(self, axis: int = 1):
+        self.func = self.loss_cls(**self.kwargs)
+        self.axis = axis
+
+    def __call__(self, inp: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        inp = inp.transpose(self.axis, -1).contiguous()
+        targ = targ.transpose(self.axis, -1).contiguous().float()
+        return self.func(inp.view(-1), targ.view(-1))
+
+    def activation(self, x):
+        return x
+
+    def decodes(self, x):
+        return x
+
+
+class MSELossFlat(_FlatRegLoss):
+    loss_cls = nn.MSELoss
+
+
+class L1LossFlat(_FlatRegLoss):
+    loss_cls = nn.L1Loss
+
+
+class Smoothl1(_FlatRegLoss):
+    loss_cls, kwargs = nn.SmoothL1Loss, {"beta": 0.5}
+
+
+def rmse(pred: torch.Tensor, targ: torch.Tensor) -> float:
+    """fastai ``rmse`` (AccumMetric over the whole validation set): sqrt(mse(flatten(pred), flatten(targ)))."""
+    return float(torch.sqrt(F.mse_loss(pred.reshape(-1).double(), targ.reshape(-1).double())))
+
+
+def r2_score(pred: torch.Tensor, targ: torch.Tensor) -> float:
+    """fastai ``R2Score()`` = sklearn.metrics.r2_score(targ, pred): 1 - SS_res / SS_tot."""
+    p, t = pred.reshape(-1).double(), targ.reshape(-1).double()
+    return float(1.0 - ((t - p) ** 2).sum() / ((t - t.mean()) ** 2).sum())
+
+
 class DiceMulti:
     """fastai ``DiceMulti(axis=1)``: per class inter/union accumulated over the
     whole validation set, value = nanmean_c(2 inter / union)."""

@@ -3,7 +3,8 @@
 Mirrors ``save_predictions`` (reference ``predict.py:146-147``).  Differences that keep results identical but not the
 schedule: tiles are predicted in BATCHES (the reference loops ``learn.predict`` one tile at a time, ``predict.py:191-193``) and the
 overlap merge -- sum of softmax probabilities + hit counter -> divide -> argmax (``predict.py:284-334``) -- runs on the GPU
-(``unet_mosaic_accumulate`` / ``unet_mosaic_finalize``).  ``regression`` and the confusion-matrix plots are out of scope.
+(``unet_mosaic_accumulate`` / ``unet_mosaic_finalize``).  ``regression`` predicts the raw single-band output (float32 tiles; merged
+mosaic = mean of the overlapping tiles, nodata -9999 where no tile was placed).  The confusion-matrix plots are out of scope.
 """
 from __future__ import annotations
 
@@ -37,8 +38,6 @@ def _geo(path):
 
 def save_predictions(predict_model, predict_path, regression, merge=False, all_classes=False, specific_class=None, large_file=False,
                      AOI=None, year=None, validation_vision=True, class_zero=False, batch_size=16):
-    if regression:
-        raise NotImplementedError("regression mode is out of scope of the MI355X hot path")
     # cfg5: one process per GPU (torch.distributed.run); tile i goes to rank i mod world, the merge mosaic is summed with RCCL
     from unet_amd.distributed import init_from_env
     import torch.distributed as dist
@@ -62,7 +61,10 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
         ids = mine[b0:b0 + batch_size]
         chunk = [tiles[i] for i in ids]
         x = torch.from_numpy(np.stack([scale_input(open_tile(t), dtype) for t in chunk]))
-        probs, amax = model.predict_probs(x.to(model._device))
+        if regression:       # predict.py:195-197: tile_preds[1] = raw outputs [1,H,W]
+            probs, amax = model.predict_values(x.to(model._device)), None
+        else:
+            probs, amax = model.predict_probs(x.to(model._device))
         for j, t in enumerate(chunk):
             i = ids[j]
             gt, tags = geos[i]
@@ -70,7 +72,7 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
                 results.append((i, probs[j]))
                 gts[i, 1], gts[i, 4] = probs.shape[3], probs.shape[2]
                 continue
-            if all_classes:
+            if regression or all_classes:
                 out = probs[j].cpu().numpy()
             elif specific_class is None:
                 out = amax[j].cpu().numpy().astype(np.uint8)
@@ -102,7 +104,7 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
     MW, MH = round((lrx_full - ulx_full) / xres), round((lry_full - uly_full) / yres)
     C = model.n_out
     print(f"True merged raster size: {C * MH * MW * 4 / (1024 ** 2): .1f}MB.")
-    if large_file:
+    if large_file and not regression:
         # int8 path of the reference: probabilities * 31 rounded to int8, integer division by the hit counter (host)
         merged = np.zeros((C, MH, MW), dtype=np.int8)
         counter = np.zeros((C, MH, MW), dtype=np.int8)
@@ -130,6 +132,13 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
         am = torch.empty((MH, MW), dtype=torch.uint8, device=model._device)
         ops.mosaic_finalize(mosaic, count, am)
         merged, amax_full = mosaic.cpu().numpy(), am.cpu().numpy()
+        if regression:       # predict.py:306-315: mean of the overlapping tiles, -9999 where no prediction was placed
+            out = merged[0]
+            out[count.cpu().numpy() == 0] = -9999
+            name = "_".join(filter(None, [AOI, year, model_name, "prediction"])) + ".tif"
+            store_tif(output_folder / name, out, [ulx_full, xres, 0.0, uly_full, 0.0, yres], geos[0][1], -9999, class_zero)
+            print(f"Prediction stored in {output_folder}.")
+            return output_folder
     if all_classes:
         out = merged
     elif specific_class is None:

@@ -97,3 +97,56 @@ def test_dataloaders_batches(tmp_path):
     assert len(xs) == 2 and xs[0][0].shape == (2, 4, 8, 8) and xs[0][0].dtype == torch.float32 and xs[0][1].dtype == torch.int64
     assert float(xs[0][0].max()) <= 1.0
     assert len(list(dls.valid)) == 1
+
+
+# ------------------------------------------------------------------ regression mode / lr_find host logic
+
+@pytest.mark.parametrize("cls", ["MSELossFlat", "L1LossFlat", "Smoothl1"])
+def test_regression_losses_match_oracle(cls):
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(3, 1, 6, 7, generator=g)
+    targ = torch.randn(3, 6, 7, generator=g) * 2
+    mine, ref = getattr(L, cls)(axis=1), getattr(O, cls)(axis=1)
+    mine.func.weight = torch.ones(1)                  # train.py:211 assigns it even in regression mode; it must be accepted and ignored
+    assert abs(float(mine(pred, targ)) - float(ref(pred, targ))) < 1e-6
+    assert mine.decodes(pred) is pred and mine.activation(pred) is pred
+    assert mine.kind in ("mse", "l1", "smoothl1")
+
+
+def test_rmse_r2_accumulate_over_batches():
+    g = torch.Generator().manual_seed(6)
+    a, b = L.Rmse(), L.R2Score()
+    a.reset(); b.reset()
+    ps, ts = [], []
+    for _ in range(4):
+        p, t = torch.randn(2, 5, 5, generator=g), torch.randn(2, 5, 5, generator=g) + 0.3
+        a.accumulate_values(p, t); b.accumulate_values(p, t)
+        ps.append(p); ts.append(t)
+    P, T = torch.cat(ps), torch.cat(ts)
+    assert abs(a.value - O.rmse(P, T)) < 1e-9 and abs(b.value - O.r2_score(P, T)) < 1e-9
+    assert (a.name, b.name) == ("_rmse", "r2_score")          # fastai metric names (monitor 'r2_score', train.py:199)
+    from sklearn.metrics import r2_score
+    assert abs(b.value - r2_score(T.reshape(-1).numpy(), P.reshape(-1).numpy())) < 1e-6
+
+
+def test_lr_suggestions_on_a_synthetic_sweep():
+    lrs = np.logspace(-7, 1, 100)
+    x = np.log10(lrs)
+    losses = 2.0 - 1.5 / (1 + np.exp(-(x + 4) * 2)) + np.where(x > -1.5, (x + 1.5) ** 2 * 2, 0)     # plateau, descent, blow-up
+    v, st, mn, sl = (L.lr_valley(lrs, losses, 100), L.lr_steep(lrs, losses, 100), L.lr_minimum(lrs, losses, 100),
+                     L.lr_slide(lrs, losses, 100))
+    lo = float(lrs[np.argmin(losses)])
+    assert 1e-6 < v < lo                       # valley: inside the descending stretch, left of the minimum
+    assert abs(np.log10(st) + 4) < 0.3         # steepest descent of the sigmoid at 1e-4
+    assert abs(mn - lo / 10) < 1e-12
+    assert 1e-7 <= sl <= 10
+
+
+def test_tile_dataset_float_targets_for_regression():
+    x = np.zeros((2, 4, 4), dtype=np.uint8)
+    m = np.arange(16, dtype=np.float32).reshape(4, 4) / 3
+    ds = L.TileDataset([x], [m], "int8", regression=True)
+    _, y = ds[0]
+    assert y.dtype == torch.float32 and torch.allclose(y, torch.from_numpy(m))
+    _, y2 = L.TileDataset([x], [m], "int8")[0]
+    assert y2.dtype == torch.int64

@@ -353,3 +353,37 @@ def test_odd_geometry_train_step_smooth():
     l2r = O.CrossEntropyLossFlat()(ref(x2), y2)
     l2 = model.forward_loss_backward(x2.cuda(), y2.cuda(), None)
     assert abs(l2.item() - l2r.item()) < 1e-4 * max(1.0, abs(l2r.item()))
+
+
+@pytest.mark.parametrize("loss_name,kind", [("MSELossFlat", "mse"), ("Smoothl1", "smoothl1")])
+def test_regression_train_step_matches_oracle(loss_name, kind):
+    """enable_regression branch (train.py:137-138,189-193): n_out = 1, float targets; fused HIP step vs the oracle on the
+    smooth (ReLU-flip-free) network, every parameter gradient element-wise"""
+    from unet_amd.model import HipDynamicUnet
+    arch, n_in, size, bs = "xresnet18", 4, (64, 64), 2
+    torch.manual_seed(8)
+    ref = O.DynamicUnet(arch, n_in, 1, size)
+    O.randomize_bn_and_zero_gammas(ref, seed=9)
+    _make_all_active(ref)
+    model = HipDynamicUnet(arch, n_in, 1, size)
+    model.load_state_dict(ref.state_dict())
+    x, _ = O.synthetic_batch(bs, n_in, size[0], size[1], 2)
+    y = torch.rand(bs, size[0], size[1], generator=torch.Generator().manual_seed(10)) * 3
+    ref.train(); model.train()
+    out = ref(x)
+    loss_ref = getattr(O, loss_name)(axis=1)(out, y)
+    loss_ref.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), reg_kind=kind, reg_beta=0.5)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    worst = ("", 0.0)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        e = (p.grad.cpu() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < 2e-3, worst
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        vals = model.predict_values(x.cuda()).cpu()
+        assert vals.shape == (bs, 1, size[0], size[1])
+        assert (vals - ref(x)).abs().max().item() < 1e-3 * max(1.0, ref(x).abs().max().item())

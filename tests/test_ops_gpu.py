@@ -527,3 +527,26 @@ def _narrow_cases(ops):
         torch.cuda.synchronize()
         assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"narrow wgrad {case}")
         assert_close(db.cpu(), dy.sum((0, 2, 3)), rtol=3e-4, atol=1e-4, what=f"narrow dbias {case}")
+
+
+@pytest.mark.parametrize("kind", ["mse", "l1", "smoothl1"])
+def test_regression_loss_kernels(ops, kind):
+    """unet_regloss_fwd / _bwd against torch (MSELoss / L1Loss / SmoothL1Loss(beta=0.5), mean reduction) on a channel slice"""
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 13, 17
+    z = torch.randn(N, 1, H, W, generator=g, requires_grad=True)
+    t = torch.randn(N, H, W, generator=g)
+    t.view(-1)[:5] = z.detach().view(-1)[:5]                      # exact zeros of the residual (sign(0) = 0)
+    fn = {"mse": F.mse_loss, "l1": F.l1_loss, "smoothl1": lambda a, b: F.smooth_l1_loss(a, b, beta=0.5)}[kind]
+    ref = fn(z.reshape(-1), t.reshape(-1))
+    ref.backward()
+    zt = to_ts(z.detach(), cs=8, co=4)
+    dz = empty_ts(N, H, W, 1, cs=12, co=8)
+    loss = torch.zeros(1, device="cuda")
+    ws = torch.empty(ops.ce_workspace(zt.P), device="cuda")
+    ops.regloss_fwd(zt, t.cuda().contiguous(), kind, 0.5, loss, ws)
+    ops.regloss_bwd(zt, t.cuda().contiguous(), kind, 0.5, 0.5, dz)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert_close(from_ts(dz), 0.5 * z.grad, rtol=1e-5, atol=1e-8, what=f"regloss bwd {kind}")
+    assert outside_untouched(dz)

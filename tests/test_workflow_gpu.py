@@ -62,3 +62,56 @@ def test_train_export_predict_merge(tmp_path):
     assert np.array_equal((acc / cnt).argmax(0).astype(np.uint8), mm)
     # non-overlapped columns of the merge equal the per-tile masks
     assert np.array_equal(mm[:, :32], m0[:, :32])
+
+
+def _make_regression_dataset(root, n_train=6, n_val=2, size=64, seed=0):
+    from unet_amd.tiffio import write_tiff
+    g = np.random.default_rng(seed)
+    for split, n in (("trai", n_train), ("vali", n_val)):
+        (root / split / "img_tiles").mkdir(parents=True)
+        (root / split / "mask_tiles").mkdir(parents=True)
+        for i in range(n):
+            img = g.integers(0, 255, (4, size, size)).astype(np.uint8)
+            target = (img[0].astype(np.float32) + img[1]) / 100.0          # a smooth function of the inputs
+            gt = (500000.0 + i * size * 0.2, 0.2, 0.0, 5800000.0, 0.0, -0.2)
+            write_tiff(root / split / "img_tiles" / f"t{i}.tif", img, geotransform=gt)
+            write_tiff(root / split / "mask_tiles" / f"t{i}.tif", target, geotransform=gt)
+
+
+def test_regression_workflow_with_lr_finder(tmp_path):
+    """enable_regression = True and LR_FINDER = 'valley' through train_func -> export -> load_learner -> predict (2-tuple)
+    -> save_predictions with overlap merge (mean of overlapping tiles, nodata -9999)"""
+    import train as T
+    import predict as P
+    from unet_amd import xresnet18
+    from unet_amd.learner import Learner_adjust
+    from unet_amd.tiffio import read_tiff, write_tiff
+    data = tmp_path / "data"
+    _make_regression_dataset(data)
+    learn = T.train_func(data, None, tmp_path / "models", "reg", 2, False, True, "even", xresnet18, 2, 1e-3, 10, "valley", None,
+                         None, False, ["vali"], ["value"], False, None, True, None, 1, "", False)
+    assert isinstance(learn, Learner_adjust) and learn.model.n_out == 1
+    hist = (tmp_path / "models" / "reg" / "reg_history.csv").read_text().strip().splitlines()
+    assert hist[0] == "epoch,train_loss,valid_loss,_rmse,r2_score,time" and len(hist) == 3
+    row = [float(v) for v in hist[-1].split(",")[1:5]]
+    assert all(np.isfinite(row)) and abs(row[2] - np.sqrt(row[1])) < 1e-3 * max(1.0, row[2])      # rmse = sqrt(valid MSE)
+    # the LR finder restored the weights it started from (fit_one_cycle then trained from the initial state) and left a curve
+    assert len(learn.lr_find_curve[0]) >= 6
+    pkl = tmp_path / "models" / "reg" / "reg.pkl"
+    lr = T.load_learner(pkl)
+    assert isinstance(lr, Learner_adjust)
+    pred = tmp_path / "pred" / "tiles"
+    pred.mkdir(parents=True)
+    g = np.random.default_rng(1)
+    for i in range(2):
+        write_tiff(pred / f"p{i}.tif", g.integers(0, 255, (4, 64, 64)).astype(np.uint8),
+                   geotransform=(1000.0 + i * 96 * 0.5, 0.5, 0.0, 2000.0, 0.0, -0.5))       # a 32-pixel gap between the tiles
+    dec, pr = lr.predict(pred / "p0.tif")
+    assert dec.shape == (1, 64, 64) and torch.equal(dec, pr)
+    out_dir = P.save_predictions(pkl, pred, True, merge=False, validation_vision=False)
+    t0, _ = read_tiff(out_dir / "p0.tif")
+    assert t0.dtype == np.float32 and np.allclose(t0.reshape(64, 64), pr[0].numpy(), atol=1e-6)
+    merged = P.save_predictions(pkl, pred, True, merge=True, AOI="aoi", validation_vision=False)
+    mm, meta = read_tiff(merged / "aoi_reg_prediction.tif")
+    assert mm.shape == (64, 160) and meta.get("nodata") == -9999.0
+    assert np.all(mm[:, 64:96] == -9999) and np.allclose(mm[:, :64], t0.reshape(64, 64), atol=1e-6)

@@ -2,8 +2,10 @@
 
 Mirrors the reference's ``train.py`` surface: ``unet_learner_MS`` (``train.py:98-160``), ``train_unet`` (``:163-283``) and
 ``train_func`` with its 25 positional arguments (``:287-292``).  Data layout: ``<data_path>/{trai,vali}/{img_tiles,mask_tiles}``
-with ``.tif`` (uncompressed GeoTIFF) or ``.npy`` tiles.  Out of scope here: plots, LR finder,
-regression mode, albumentations pipelines (only the built-in flips), run-parameter JSON beyond a compact dump.
+with ``.tif`` (uncompressed GeoTIFF) or ``.npy`` tiles.  Regression mode (``enable_regression``: n_out = 1, MSELossFlat /
+L1LossFlat / Smoothl1, rmse + R2Score, ``Learner_adjust``) and the learning-rate finder (``LR_FINDER`` = valley / slide /
+steep / minimum, utils.py:150-167) are available.  Out of scope here: plots, albumentations pipelines
+(only the built-in flips), run-parameter JSON beyond a compact dump.
 """
 from __future__ import annotations
 
@@ -16,8 +18,9 @@ import numpy as np
 import torch
 
 from unet_amd import xresnet34  # noqa: F401  (architecture tokens, like `from fastai.vision.all import xresnet34`)
-from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, FlipAugment, Learner,
-                              SaveModelCallback, TileDataset, load_learner, open_tile)
+from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, FlipAugment, L1LossFlat, Learner,
+                              Learner_adjust, MSELossFlat, R2Score, Rmse, SaveModelCallback, Smoothl1, TileDataset, load_learner,
+                              open_tile)
 from unet_amd.model import HipDynamicUnet
 
 
@@ -43,39 +46,52 @@ def get_class_weights(ds: TileDataset, n_cls: int, max_tiles: int = 1200) -> np.
     return cnt.sum() / np.maximum(cnt, 1)
 
 
-def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda", train_tfm=None) -> DataLoaders:
+def make_dataloaders(data_path, bs, codes, dtype=None, device="cuda", train_tfm=None, regression=False) -> DataLoaders:
     data_path = Path(data_path)
     dtype = dtype or get_datatype(data_path)
     sets = {}
     for split in ("trai", "vali"):
         imgs = _tiles(data_path / split / "img_tiles")
         masks = [data_path / split / "mask_tiles" / p.name for p in imgs]
-        sets[split] = TileDataset(imgs, masks, dtype)
+        sets[split] = TileDataset(imgs, masks, dtype, regression=regression)
     return DataLoaders(sets["trai"], sets["vali"], bs, device=device, vocab=list(codes), train_tfm=train_tfm)
 
 
 def unet_learner_MS(dls, arch, pretrained=True, loss_func=None, norm_type=None, opt_func=Adam, lr=1e-3, splitter=None, cbs=None,
                     metrics=None, path=None, model_dir="models", wd=None, wd_bn_bias=False, train_bn=True,
                     moms=(0.95, 0.85, 0.95), regression=False, self_attention=False) -> Learner:
-    if regression:
-        raise NotImplementedError("regression mode is out of scope of the MI355X hot path (SURVEY.md section 2)")
     x0, _ = dls.train_ds[0]
     n_in, size = x0.shape[0], tuple(x0.shape[-2:])
-    n_out = len(dls.vocab)
+    n_out = 1 if regression else len(dls.vocab)                      # train.py:137-140
     model = HipDynamicUnet(_arch_name(arch), n_in, n_out, size, self_attention=self_attention, device=dls.device)
-    return Learner(dls=dls, model=model, loss_func=loss_func, opt_func=opt_func, lr=lr, splitter=splitter, cbs=cbs, metrics=metrics,
+    cls = Learner_adjust if regression else Learner                   # train.py:148
+    return cls(dls=dls, model=model, loss_func=loss_func, opt_func=opt_func, lr=lr, splitter=splitter, cbs=cbs, metrics=metrics,
                    path=path, model_dir=model_dir, wd=wd, wd_bn_bias=wd_bn_bias, train_bn=train_bn, moms=moms)
+
+
+def find_lr(learn, finder):
+    """utils.py:150-167: suggested maximum learning rate from the LR finder."""
+    lrs = learn.lr_find(suggest_funcs=("minimum", "steep", "valley", "slide"), show_plot=False)
+    if finder not in ("valley", "slide", "steep", "minimum"):
+        warnings.warn("Learning rate finder parameter not recognised (minimum, steep, valley, slide, None). Using valley.")
+        finder = "valley"
+    return getattr(lrs, finder)
 
 
 def train_unet(class_weights, dls, architecture, epochs, path, lr, encoder_factor, lr_finder=None, regression=False,
                loss_func=None, monitor=None, existing_model=None, self_attention=False, export_model_summary=False) -> Learner:
     weights = torch.tensor(np.asarray(class_weights, dtype=np.float32), device=dls.device)
-    if loss_func is None:
-        loss_func = CrossEntropyLossFlat(axis=1, weight=weights)
-    metrics = [DiceMulti()]
-    monitor = monitor or "dice_multi"
+    if regression:                                                    # train.py:189-193
+        if loss_func is None:
+            loss_func = MSELossFlat(axis=1)
+        metrics = [Rmse(), R2Score()]
+    else:
+        if loss_func is None:
+            loss_func = CrossEntropyLossFlat(axis=1, weight=weights)
+        metrics = [DiceMulti()]
+    monitor = monitor or ("r2_score" if regression else "dice_multi")
     comp = np.less if monitor in ("train_loss", "valid_loss") else np.greater
-    if monitor not in ("train_loss", "valid_loss", "dice_multi"):
+    if monitor not in ("train_loss", "valid_loss", "r2_score", "dice_multi"):
         warnings.warn("Monitor not recognised. Assuming maximization.")
     path = Path(path)
     cbs = [SaveModelCallback(monitor=monitor, comp=comp, fname="best-model"), CSVLogger()]
@@ -91,7 +107,8 @@ def train_unet(class_weights, dls, architecture, epochs, path, lr, encoder_facto
         Path(str(path).rsplit(".", 1)[0] + "_model_summary.txt").write_text(
             f"Class_weights: {class_weights}\n{learn.summary()}\n{learn.model}\n")
     if lr_finder is not None:
-        warnings.warn("lr_finder is not available on this path; using LEARNING_RATE as given")
+        lr = find_lr(learn, lr_finder)
+        print(f"Optimized learning rate: {lr}")
     learn.unfreeze()
     learn.fit_one_cycle(epochs, lr_max=slice(lr / encoder_factor, lr))
     hist = Path(str(path).rsplit(".", 1)[0] + "_history.csv")
@@ -120,10 +137,10 @@ def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, v
         if aug_pipe is not None and not isinstance(aug_pipe, FlipAugment):
             warnings.warn("only the built-in flip augmentation is available on this path; using it instead of aug_pipe")
         tfm = aug_pipe if isinstance(aug_pipe, FlipAugment) else FlipAugment(n_transform_imgs=n_transform_imgs)
-    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, train_tfm=tfm)
+    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, train_tfm=tfm, regression=bool(enable_regression))
     if enable_regression:
-        raise NotImplementedError("regression mode is out of scope of the MI355X hot path")
-    if isinstance(CLASS_WEIGHTS, str):
+        CLASS_WEIGHTS = [1]                                           # train.py:334-335
+    elif isinstance(CLASS_WEIGHTS, str):
         if CLASS_WEIGHTS == "even":
             CLASS_WEIGHTS = np.ones(len(CODES)) / len(CODES)
         elif CLASS_WEIGHTS == "weighted":

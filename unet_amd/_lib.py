@@ -118,6 +118,8 @@ _sig = {
     "unet_ce_workspace": (sz, [ll]),
     "unet_ce_fwd": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp, vp]),
     "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),
+    "unet_regloss_fwd": (i, [vp, i, i, vp, ll, i, f, vp, vp, vp]),
+    "unet_regloss_bwd": (i, [vp, i, i, vp, ll, i, f, f, vp, i, i, vp]),
     "unet_softmax_argmax": (i, [vp, i, i, i, i, i, i, vp, vp, vp]),
     "unet_adam_step": (i, [vp, vp, vp, vp, vp, ll, c_float_p, f, f, f, f, i, f, vp]),
     "unet_adam_hyper_floats": (i, []),

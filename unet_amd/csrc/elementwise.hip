@@ -613,6 +613,50 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
     }
 }
 
+// Regression losses of the enable_regression branch (reference train.py:189-193: MSELossFlat(axis=1); utils.py:145-147:
+// Smoothl1 = SmoothL1Loss(beta=0.5); fastai L1LossFlat): prediction = channel 0 of the [P,1] output slice, float targets,
+// 'mean' reduction over all P pixels.  kind 0: d^2   1: |d|   2: |d| < beta ? d^2 / (2 beta) : |d| - beta / 2
+__device__ __forceinline__ float regloss_val(float d, int kind, float beta) {
+    const float ad = fabsf(d);
+    if (kind == 0) return d * d;
+    if (kind == 1) return ad;
+    return ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
+}
+__device__ __forceinline__ float regloss_grad(float d, int kind, float beta) {
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (kind == 0) return 2.f * d;
+    if (kind == 1) return sg;
+    return fabsf(d) < beta ? d / beta : sg;
+}
+
+__global__ __launch_bounds__(256) void regloss_fwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const float* __restrict__ target,
+                                                          long long P, int kind, float beta, float* __restrict__ part) {
+    float num = 0.f;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x)
+        num += regloss_val(z[(size_t)p * z_cs + z_co] - target[p], kind, beta);
+    __shared__ float sn[4];
+    for (int o = 32; o > 0; o >>= 1) num += __shfl_down(num, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sn[wv] = num;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sn[0] + sn[1] + sn[2] + sn[3];
+}
+
+__global__ void regloss_finalize_kernel(const float* __restrict__ part, int rows, long long P, float* loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double n = 0.0;
+    for (int r = 0; r < rows; ++r) n += (double)part[r];
+    *loss = (float)(n / (double)P);
+}
+
+__global__ __launch_bounds__(256) void regloss_bwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const float* __restrict__ target,
+                                                          long long P, int kind, float beta, float gscale, float* __restrict__ dz, int dz_cs,
+                                                          int dz_co) {
+    const float inv = gscale / (float)P;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x)
+        dz[(size_t)p * dz_cs + dz_co] = inv * regloss_grad(z[(size_t)p * z_cs + z_co] - target[p], kind, beta);
+}
+
 __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __restrict__ z, int z_cs, int z_co, int N, long long HW, int C,
                                                              float* __restrict__ probs, int64_t* __restrict__ amax) {
     const long long total = (long long)N * HW;
@@ -1003,6 +1047,28 @@ extern "C" int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* ta
     UNET_CHECK_ARG(z && target && denom && dz && P > 0 && C > 0 && C <= CE_MAXC, "ce_bwd: bad args");
     UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs && dz_co >= 0 && dz_co + C <= dz_cs, "ce_bwd: bad slice");
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs,
+                       dz_co);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_regloss_fwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta, float* loss,
+                                float* workspace, void* stream) {
+    UNET_CHECK_ARG(z && target && loss && workspace && P > 0 && kind >= 0 && kind <= 2 && (kind != 2 || beta > 0.f), "regloss_fwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co < z_cs, "regloss_fwd: bad slice");
+    const int rows = ce_rows(P);
+    hipLaunchKernelGGL(regloss_fwd_kernel, dim3(rows), dim3(256), 0, ST, z, z_cs, z_co, target, P, kind, beta, workspace);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(regloss_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, P, loss);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_regloss_bwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta, float gscale,
+                                float* dz, int dz_cs, int dz_co, void* stream) {
+    UNET_CHECK_ARG(z && target && dz && P > 0 && kind >= 0 && kind <= 2 && (kind != 2 || beta > 0.f), "regloss_bwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co < z_cs && dz_co >= 0 && dz_co < dz_cs, "regloss_bwd: bad slice");
+    hipLaunchKernelGGL(regloss_bwd_kernel, dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, P, kind, beta, gscale, dz, dz_cs,
                        dz_co);
     UNET_CHECK_LAUNCH();
     return UNET_OK;

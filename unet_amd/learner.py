@@ -78,6 +78,88 @@ class CrossEntropyLossFlat:
         return x.argmax(dim=self.axis)
 
 
+class _RegLoss:
+    """fastai ``BaseLoss(nn.<X>Loss, axis=1, floatify=True, is_2d=False)``: prediction [B,1,H,W] and target [B,H,W] are flattened,
+    'mean' reduction.  ``kind`` selects the HIP kernel of the fused training step (unet_regloss_fwd / _bwd)."""
+    kind, beta = "mse", 0.5
+
+    def __init__(self, axis: int = 1, floatify: bool = True):
+        self.axis = axis
+        self.func = _Func(None)       # train.py:211 assigns loss_func.func.weight for every loss; regression losses ignore it
+
+    def __call__(self, pred: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        """Generic path (torch autograd)."""
+        d = pred.reshape(-1) - targ.float().reshape(-1)
+        if self.kind == "mse":
+            return (d * d).mean()
+        if self.kind == "l1":
+            return d.abs().mean()
+        return torch.nn.functional.smooth_l1_loss(pred.reshape(-1), targ.float().reshape(-1), beta=self.beta)
+
+    def activation(self, x):
+        return x
+
+    def decodes(self, x):
+        return x
+
+
+class MSELossFlat(_RegLoss):
+    """train.py:191 ``MSELossFlat(axis=1)``"""
+    kind = "mse"
+
+
+class L1LossFlat(_RegLoss):
+    kind = "l1"
+
+
+class Smoothl1(_RegLoss):
+    """utils.py:145-147: ``BaseLoss(nn.SmoothL1Loss, axis=1, floatify=True, is_2d=False, beta=0.5)``"""
+    kind = "smoothl1"
+
+
+class Rmse:
+    """fastai ``rmse`` = AccumMetric(sqrt(mse), flatten=True): root of the mean squared error over the WHOLE validation set."""
+    name = "_rmse"
+
+    def reset(self):
+        self.se, self.n = 0.0, 0
+
+    def accumulate_values(self, pred: torch.Tensor, targ: torch.Tensor):
+        d = (pred.reshape(-1).double() - targ.reshape(-1).double())
+        self.se += float((d * d).sum().item())
+        self.n += d.numel()
+
+    def all_reduce(self):
+        pass
+
+    @property
+    def value(self) -> float:
+        return float(np.sqrt(self.se / max(1, self.n)))
+
+
+class R2Score:
+    """fastai ``R2Score()`` = sklearn ``r2_score`` over the whole validation set: 1 - SS_res / SS_tot."""
+    name = "r2_score"
+
+    def reset(self):
+        self.n, self.st, self.stt, self.res = 0, 0.0, 0.0, 0.0
+
+    def accumulate_values(self, pred: torch.Tensor, targ: torch.Tensor):
+        p, t = pred.reshape(-1).double(), targ.reshape(-1).double()
+        self.n += t.numel()
+        self.st += float(t.sum().item())
+        self.stt += float((t * t).sum().item())
+        self.res += float(((t - p) ** 2).sum().item())
+
+    def all_reduce(self):
+        pass
+
+    @property
+    def value(self) -> float:
+        tot = self.stt - self.st * self.st / max(1, self.n)
+        return float("nan") if tot <= 0 else float(1.0 - self.res / tot)
+
+
 class DiceMulti:
     """fastai ``DiceMulti(axis=1)``: inter/union per class accumulated over the validation set; nanmean of 2I/U."""
     name = "dice_multi"
@@ -133,8 +215,9 @@ def scale_input(a: np.ndarray, dtype: str = "int8") -> np.ndarray:
 
 
 class TileDataset:
-    def __init__(self, imgs: Sequence, masks: Optional[Sequence] = None, dtype: str = "int8"):
+    def __init__(self, imgs: Sequence, masks: Optional[Sequence] = None, dtype: str = "int8", regression: bool = False):
         self.imgs, self.masks, self.dtype = list(imgs), None if masks is None else list(masks), dtype
+        self.regression = regression      # RegressionBlock (data.py:98-99): the mask tile is a float target
 
     def __len__(self):
         return len(self.imgs)
@@ -146,7 +229,7 @@ class TileDataset:
             return torch.from_numpy(x), None
         mk = self.masks[i]
         y = open_tile(mk)[0] if not isinstance(mk, np.ndarray) else mk
-        return torch.from_numpy(x), torch.from_numpy(np.asarray(y).astype(np.int64))
+        return torch.from_numpy(x), torch.from_numpy(np.asarray(y).astype(np.float32 if self.regression else np.int64))
 
 
 class DataLoader:
@@ -285,6 +368,46 @@ def Adam(model, lr, mom=0.9, sqr_mom=0.99, eps=1e-5, wd=0.01, wd_bn_bias=False, 
     return FlatAdam(model, lr, mom, sqr_mom, eps, wd, wd_bn_bias, splitter)
 
 
+# --------------------------------------------------------------------------- lr_find suggestions (fastai callback/schedule.py)
+
+def lr_valley(lrs, losses, num_it):
+    """longest strictly decreasing sub-sequence of the loss curve; suggestion = 2/3 into it"""
+    n = len(losses)
+    max_start = max_end = 0
+    lds = [1] * n
+    for i in range(1, n):
+        for j in range(0, i):
+            if losses[i] < losses[j] and lds[i] < lds[j] + 1:
+                lds[i] = lds[j] + 1
+            if lds[max_end] < lds[i]:
+                max_end = i
+                max_start = max_end - lds[max_end]
+    sections = (max_end - max_start) / 3
+    idx = max_start + int(sections) + int(sections / 2)
+    return lrs[idx]
+
+
+def lr_slide(lrs, losses, num_it, lr_diff=15, thresh=.005, adjust_value=1.):
+    g = np.gradient(losses)
+    r_idx = -1
+    l_idx = r_idx - lr_diff
+    local_min_lr = lrs[l_idx] if -l_idx <= len(lrs) else lrs[0]
+    while l_idx >= -len(losses) and abs(g[r_idx] - g[l_idx]) > thresh:
+        local_min_lr = lrs[l_idx]
+        r_idx -= 1
+        l_idx -= 1
+    return float(local_min_lr) * adjust_value
+
+
+def lr_minimum(lrs, losses, num_it):
+    return lrs[int(np.argmin(losses))] / 10
+
+
+def lr_steep(lrs, losses, num_it):
+    grads = (losses[1:] - losses[:-1]) / (np.log(lrs[1:]) - np.log(lrs[:-1]))
+    return lrs[int(np.argmin(grads))]
+
+
 # --------------------------------------------------------------------------- Learner
 
 class Learner:
@@ -332,6 +455,10 @@ class Learner:
     def _weights(self):
         return self.loss_func._w(self.dls.device) if isinstance(self.loss_func, CrossEntropyLossFlat) else None
 
+    @property
+    def regression(self) -> bool:
+        return isinstance(self.loss_func, _RegLoss)
+
     # -- training
     def fit_one_cycle(self, n_epoch, lr_max=None, div=25.0, div_final=1e5, pct_start=0.25, wd=None, moms=None):
         if self.opt is None:
@@ -355,10 +482,13 @@ class Learner:
         lrs = np.array([self.lr if lr is None else lr] * len(self.opt.groups), dtype=np.float64)
         self._fit(n_epoch, lambda p: lrs, lambda p: self.opt.mom)
 
-    def _fit(self, n_epoch, lr_f, mom_f):
+    def _fit(self, n_epoch, lr_f, mom_f, batch_cb=None):
+        """batch_cb(it, loss_tensor, lr) -> True stops the fit after that batch (lr_find)."""
         model, opt = self.model, self.opt
-        fused = isinstance(self.loss_func, CrossEntropyLossFlat)
+        fused = isinstance(self.loss_func, (CrossEntropyLossFlat, _RegLoss))
         step = TrainStep(model, opt, self._weights(), self.world) if fused else None
+        if fused and self.regression:
+            step.reg_kind, step.reg_beta = self.loss_func.kind, self.loss_func.beta
         n_iter = len(self.dls.train)
         total = max(1, n_epoch * n_iter)
         for cb in self.cbs:
@@ -381,6 +511,8 @@ class Learner:
                     opt.step()
                 pending.append((loss.detach().reshape(1).clone(), opt.lrs[-1]))
                 it += 1
+                if batch_cb is not None and batch_cb(it, pending[-1][0], opt.lrs[-1]):
+                    return
             for l, lr in pending:                       # one host sync per epoch, not per batch
                 self.recorder.add_batch(float(l.item()), lr)
             train_loss = self.recorder.losses[-1] if self.recorder.losses else float("nan")
@@ -390,7 +522,8 @@ class Learner:
             self.recorder.values.append(row[1:-1])
             self.recorder.log_row = row
             self.recorder.last = dict(zip(self.recorder.metric_names[1:-1], row[1:-1]))
-            print(dict(zip(self.recorder.metric_names, row)))
+            if not getattr(self, "_no_logging", False):
+                print(dict(zip(self.recorder.metric_names, row)))
             for cb in self.cbs:
                 cb.after_epoch(self)
         for cb in self.cbs:
@@ -410,6 +543,17 @@ class Learner:
         w = self._weights()
         for xb, yb in dl:
             z = model._hip_forward(xb.to(model._device, torch.float32), False)
+            if self.regression:
+                yb = yb.to(model._device, torch.float32).contiguous()
+                loss = ctx.vec(self, "vloss", 1)
+                ops.regloss_fwd(z, yb, self.loss_func.kind, self.loss_func.beta, loss, ctx.workspace(ops.ce_workspace(z.P)))
+                vals = torch.empty((z.N, z.C, z.H, z.W), dtype=torch.float32, device=model._device)
+                ops.nhwc_to_nchw(z, vals)
+                num += float(loss.item()) * z.P
+                den += z.P
+                for m in self.metrics:
+                    m.accumulate_values(vals[:, 0], yb)
+                continue
             loss, denom = ctx.vec(self, "vloss", 1), ctx.vec(self, "vden", 1)
             ops.ce_fwd(z, yb.contiguous(), w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
             amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=model._device)
@@ -431,8 +575,12 @@ class Learner:
         self.model.eval()
         xs, ps, ys, ds = [], [], [], []
         for xb, yb in dl:
-            probs, amax = self.model.predict_probs(xb)
-            ps.append(probs.cpu()); ds.append(amax.cpu())
+            if self.regression:
+                vals = self.model.predict_values(xb)      # decoded == preds: no activation (train.py:90-95)
+                ps.append(vals.cpu()); ds.append(vals.cpu())
+            else:
+                probs, amax = self.model.predict_probs(xb)
+                ps.append(probs.cpu()); ds.append(amax.cpu())
             if with_input:
                 xs.append(xb.cpu())
             if yb is not None:
@@ -445,11 +593,67 @@ class Learner:
         return res
 
     def predict(self, item, rm_type_tfms=None, with_input=False):
-        """(decoded mask, argmax [H,W], per-class probabilities [C,H,W]) for one tile (path or [C,H,W] array)."""
+        """(decoded mask, argmax [H,W], per-class probabilities [C,H,W]) for one tile (path or [C,H,W] array); in regression
+        mode the 2-tuple (decoded, preds) of ``Learner_adjust.predict`` (train.py:87-95), both [1,H,W]."""
         dl = self.dls.test_dl([item])
         _, preds, _, dec = self.get_preds(dl=dl, with_input=True, with_decoded=True)
+        if self.regression:
+            return dec[0], preds[0]
         res = dec[0], dec[0], preds[0]
         return res
+
+    # -- learning-rate finder (fastai callback/schedule.py LRFinder + Learner.lr_find; reference utils.py:150-167)
+    def lr_find(self, start_lr=1e-7, end_lr=10, num_it=100, stop_div=True, show_plot=False, suggest_funcs=("valley",)):
+        """Exponential LR sweep over ``num_it`` training batches (all parameter groups at the same rate), stopped early when
+        the smoothed loss exceeds 4x its best; model and optimizer state are restored afterwards.  Returns an object with one
+        attribute per suggestion function (``.valley``, ``.slide``, ``.steep``, ``.minimum``)."""
+        from types import SimpleNamespace
+        if self.opt is None:
+            self.create_opt()
+        num_it = max(6, int(num_it))
+        self.save("_tmp_lr_find", with_opt=True)
+        rec, self.recorder = self.recorder, Recorder([])
+        self._no_logging = True
+        cbs, self.cbs = self.cbs, []
+        valid, self.dls.valid = self.dls.valid, None          # before_validate: CancelValidException
+        k = len(self.opt.groups)
+        best = [float("inf")]
+        smooth = Recorder([])
+
+        def lr_f(_pct, it=[0]):
+            lr = start_lr * (end_lr / start_lr) ** (it[0] / num_it)       # SchedExp at pos = train_iter / num_it
+            it[0] += 1
+            return np.array([lr] * k)
+
+        def batch_cb(it, loss, lr):
+            smooth.add_batch(float(loss.item()), lr)
+            sl = smooth.losses[-1]
+            best[0] = min(best[0], sl)
+            return (stop_div and (sl > 4 * best[0] or not np.isfinite(sl))) or it >= num_it
+        n_epoch = num_it // max(1, len(self.dls.train)) + 1
+        try:
+            self._fit(n_epoch, lr_f, lambda p: self.opt.mom, batch_cb=batch_cb)
+        finally:
+            self.recorder, self.cbs, self.dls.valid = rec, cbs, valid
+            self._no_logging = False
+            self.model.flat_grad.zero_()
+            self.load("_tmp_lr_find", with_opt=True)
+            self.model.mark_weights_dirty()
+            try:
+                self._model_path("_tmp_lr_find").unlink()
+            except OSError:
+                pass
+        lrs = np.array(smooth.lrs[num_it // 10:-5], dtype=np.float64)
+        losses = np.array(smooth.losses[num_it // 10:-5], dtype=np.float64)
+        ok = np.isfinite(losses)
+        lrs, losses = lrs[ok], losses[ok]
+        self.lr_find_curve = (smooth.lrs, smooth.losses)
+        fns = {"valley": lr_valley, "slide": lr_slide, "steep": lr_steep, "minimum": lr_minimum}
+        out = {}
+        for f in suggest_funcs:
+            name = f if isinstance(f, str) else f.__name__.replace("lr_", "")
+            out[name] = float(fns[name](lrs, losses, num_it)) if len(lrs) > 1 else float("nan")
+        return SimpleNamespace(**out)
 
     # -- persistence
     def _model_path(self, name):
@@ -476,7 +680,8 @@ class Learner:
         w = self.loss_func.func.weight if isinstance(self.loss_func, CrossEntropyLossFlat) else None
         meta = {"arch": m.arch, "n_in": m.n_in, "n_out": m.n_out, "img_size": list(m.img_size), "vocab": self.dls.vocab,
                 "dtype": self.dls.train_ds.dtype if self.dls is not None else "int8",
-                "class_weights": None if w is None else [float(v) for v in torch.as_tensor(w).cpu()]}
+                "class_weights": None if w is None else [float(v) for v in torch.as_tensor(w).cpu()],
+                "regression": self.loss_func.kind if self.regression else None}
         p = Path(fname)
         p = p if p.is_absolute() else self.path / p
         p.parent.mkdir(parents=True, exist_ok=True)
@@ -491,6 +696,10 @@ class Learner:
         return "\n".join(lines)
 
 
+class Learner_adjust(Learner):
+    """train.py:87-95: the regression Learner (predict returns the 2-tuple); the behaviour lives in Learner.predict."""
+
+
 def load_learner(fname, device="cuda") -> Learner:
     d = torch.load(fname, map_location="cpu")
     meta = d["meta"]
@@ -499,5 +708,8 @@ def load_learner(fname, device="cuda") -> Learner:
     empty = TileDataset([], None, meta.get("dtype", "int8"))
     dls = DataLoaders(empty, None, 1, device=device, vocab=meta.get("vocab"))
     w = meta.get("class_weights")
+    if meta.get("regression"):
+        loss = {"mse": MSELossFlat, "l1": L1LossFlat, "smoothl1": Smoothl1}[meta["regression"]](axis=1)
+        return Learner_adjust(dls, model, loss_func=loss, metrics=[Rmse(), R2Score()])
     loss = CrossEntropyLossFlat(axis=1, weight=None if w is None else torch.tensor(w))
     return Learner(dls, model, loss_func=loss, metrics=[DiceMulti()])

@@ -304,22 +304,40 @@ class HipDynamicUnet(nn.Module):
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
 
     def forward_loss_backward(self, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                              grad_scale: float = 1.0) -> torch.Tensor:
-        """One fused training pass: logits -> weighted per-pixel cross-entropy (CrossEntropyLossFlat(axis=1, weight),
-        train.py:195,211) -> backward into the flat gradient buffer.  Returns the loss as a 1-element device tensor
-        (no host sync).  grad_scale multiplies the gradient (1/world for tile-DDP averaging)."""
+                              grad_scale: float = 1.0, reg_kind: Optional[str] = None, reg_beta: float = 0.5) -> torch.Tensor:
+        """One fused training pass: logits -> loss -> backward into the flat gradient buffer.  Returns the loss as a 1-element
+        device tensor (no host sync).  grad_scale multiplies the gradient (1/world for tile-DDP averaging).
+        Classification (default): weighted per-pixel cross-entropy, CrossEntropyLossFlat(axis=1, weight) (train.py:195,211).
+        Regression (reg_kind = "mse" | "l1" | "smoothl1", n_out = 1, float targets [B,H,W]): train.py:189-193."""
         x = x.to(self._device, torch.float32)
         z = self._hip_forward(x, True)
         ctx = self.ctx
-        y = y.to(self._device, torch.int64).contiguous()
         P = z.P
-        loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
-        ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
         dz = ctx.act(self, "dlogits", z.N, z.H, z.W, z.C, zero=True)
-        ops.ce_bwd(z, y, weight, denom, grad_scale, dz)
+        if reg_kind is None:
+            y = y.to(self._device, torch.int64).contiguous()
+            loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
+            ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
+            ops.ce_bwd(z, y, weight, denom, grad_scale, dz)
+        else:
+            if self.n_out != 1:
+                raise ValueError("regression losses need a model with n_out = 1")
+            y = y.to(self._device, torch.float32).contiguous()
+            loss = ctx.vec(self, "loss", 1)
+            ops.regloss_fwd(z, y, reg_kind, reg_beta, loss, ctx.workspace(ops.ce_workspace(P)))
+            ops.regloss_bwd(z, y, reg_kind, reg_beta, grad_scale, dz)
         self._ensure_grad_views()
         self._hip_backward(dz)
         return loss
+
+    @torch.no_grad()
+    def predict_values(self, x: torch.Tensor) -> torch.Tensor:
+        """eval-mode forward, raw outputs [B,n_out,H,W] (regression: no activation, train.py:90-95)."""
+        x = x.to(self._device, torch.float32)
+        z = self._hip_forward(x, False)
+        out = torch.empty((z.N, z.C, z.H, z.W), dtype=torch.float32, device=self._device)
+        ops.nhwc_to_nchw(z, out)
+        return out
 
     @torch.no_grad()
     def predict_probs(self, x: torch.Tensor, want_probs=True, want_argmax=True):

@@ -330,6 +330,20 @@ def ce_bwd(z: TS, target, weight, denom, gscale: float, dz: TS):
                           dz.co, _stream()), "ce_bwd")
 
 
+REG_KINDS = {"mse": 0, "l1": 1, "smoothl1": 2}
+
+
+def regloss_fwd(z: TS, target: torch.Tensor, kind: str, beta: float, loss, ws):
+    assert target.dtype == torch.float32 and target.is_contiguous() and target.numel() == z.P and z.C == 1
+    check(lib.unet_regloss_fwd(z.ptr, z.cs, z.co, target.data_ptr(), z.P, REG_KINDS[kind], float(beta), loss.data_ptr(), ws.data_ptr(),
+                               _stream()), "regloss_fwd")
+
+
+def regloss_bwd(z: TS, target: torch.Tensor, kind: str, beta: float, gscale: float, dz: TS):
+    check(lib.unet_regloss_bwd(z.ptr, z.cs, z.co, target.data_ptr(), z.P, REG_KINDS[kind], float(beta), float(gscale), dz.ptr, dz.cs,
+                               dz.co, _stream()), "regloss_bwd")
+
+
 def softmax_argmax(z: TS, probs: Optional[torch.Tensor], amax: Optional[torch.Tensor]):
     check(lib.unet_softmax_argmax(z.ptr, z.cs, z.co, z.N, z.H, z.W, z.C, _p(probs), _p(amax), _stream()), "softmax_argmax")
 

@@ -24,6 +24,8 @@ class TrainStep:
                  max_bucket_elems: int = 16 << 20, use_graph: bool = False):
         self.model, self.opt, self.world = model, opt, world
         self.weights = class_weights
+        self.reg_kind: Optional[str] = None     # "mse" | "l1" | "smoothl1": regression mode (float targets, n_out = 1)
+        self.reg_beta = 0.5
         self.use_graph = use_graph and world == 1
         self._graph = None
         self._calls = 0
@@ -42,16 +44,17 @@ class TrainStep:
         if self._graph is None:
             if self._calls < 2:                     # eager warm-up: allocates every persistent buffer / workspace
                 self._calls += 1
-                loss = m.forward_loss_backward(x, y, self.weights, grad_scale=1.0)
+                loss = m.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta)
                 opt.step()
                 return loss
             self._xs = x.to(m._device, torch.float32).clone()
-            self._ys = y.to(m._device, torch.int64).clone()
+            self._ys = y.to(m._device, torch.int64 if self.reg_kind is None else torch.float32).clone()
             opt.upload_hyper(opt.step_count + 1)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._loss = m.forward_loss_backward(self._xs, self._ys, self.weights, grad_scale=1.0)
+                self._loss = m.forward_loss_backward(self._xs, self._ys, self.weights, grad_scale=1.0, reg_kind=self.reg_kind,
+                                                     reg_beta=self.reg_beta)
                 opt.step_from_device_hyper()
             # (the capture itself does not execute the step)
         self._xs.copy_(x, non_blocking=True)
@@ -67,7 +70,8 @@ class TrainStep:
             return self._graphed(x, y)
         if self.reducer is not None:
             self.reducer.reset()
-        loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0 / self.world)
+        loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0 / self.world, reg_kind=self.reg_kind,
+                                                reg_beta=self.reg_beta)
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
