@@ -120,11 +120,11 @@ int unet_bn_stats_rows(long long P);
 int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream);
 /* train-mode finalize: from partial sums psum[rows][C], psumsq[rows][C] (unet_bn_stats planes or the
  * colsum/colsumsq of a conv epilogue) compute mean / invstd, scale = gamma*invstd, shift = beta - mean*scale,
- * and update running stats (unbiased var, momentum). */
+ * and update running stats (unbiased var, momentum); batches_tracked (BatchNorm2d.num_batches_tracked, int64, or NULL) += 1. */
 int unet_bn_finalize(const float* psum, const float* psumsq, int rows, long long count, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps,
-                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+                     float* scale, float* shift, float* save_mean, float* save_invstd, long long* batches_tracked, void* stream);
 /* eval-mode: scale/shift from running stats */
 int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, int C, float* scale, float* shift, void* stream);

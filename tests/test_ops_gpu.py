@@ -181,13 +181,15 @@ def test_batchnorm_train_fwd_bwd(ops, shape):
     dev = lambda t: t.detach().clone().cuda()
     scale, shift, smean, sinv = (torch.empty(Cc, device="cuda") for _ in range(4))
     rmd, rvd = dev(rm0), dev(rv0)
-    ops.bn_finalize(part, part[rows * Cc:], rows, P, Cc, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, scale, shift, smean, sinv)
+    tracked = torch.full((), 7, dtype=torch.int64, device="cuda")
+    ops.bn_finalize(part, part[rows * Cc:], rows, P, Cc, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, scale, shift, smean, sinv, tracked)
     yt = empty_ts(N, H, W, Cc)
     ops.affine_act(xt, yt, scale, shift, x2=to_ts(res), relu=True)
     torch.cuda.synchronize()
     assert_close(from_ts(yt), out.detach(), rtol=1e-5, atol=1e-5, what="bn fwd")
     assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6, what="running_mean")
     assert_close(rvd.cpu(), rv, rtol=1e-5, atol=1e-6, what="running_var")
+    assert int(tracked.item()) == 8          # BatchNorm2d.num_batches_tracked += 1 inside the finalize kernel
 
     # backward: g = dout * (out > 0); dx, dgamma, dbeta; residual branch gets g.  The reference uses the
     # ReLU mask of the HIP forward output so that a sign flip of a ~1e-8 pre-activation cannot fail the test.

@@ -95,7 +95,7 @@ _sig = {
     "unet_conv2d_wgrad": (i, [C.POINTER(WgradDesc), vp]),
     "unet_bn_stats_rows": (i, [ll]),
     "unet_bn_stats": (i, [vp, i, i, ll, i, vp, vp]),
-    "unet_bn_finalize": (i, [vp, vp, i, ll, i, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp]),
+    "unet_bn_finalize": (i, [vp, vp, i, ll, i, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp, vp]),
     "unet_bn_eval_coeffs": (i, [vp, vp, vp, vp, f, i, vp, vp, vp]),
     "unet_affine_act": (i, [vp, i, i, vp, vp, vp, i, i, vp, vp, vp, i, i, ll, i, i, vp]),
     "unet_bn_bwd_reduce": (i, [vp, i, i, vp, i, i, vp, i, i, vp, vp, ll, i, vp, vp]),

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           int rstride, double count, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* running_mean, float* running_var,
                                                           float momentum, float eps, float* scale, float* shift, float* save_mean,
-                                                          float* save_invstd) {
+                                                          float* save_invstd, long long* batches_tracked) {
+    if (batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;   // BatchNorm2d.num_batches_tracked
     double s, q; int c;
     rows_reduce2(psum, psumsq, rows, rstride, C, s, q, c);
     if (c < 0) return;
@@ -816,10 +817,10 @@ extern "C" int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, in
 
 extern "C" int unet_bn_finalize(const float* psum, const float* psumsq, int rows, long long count, int C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                                float* shift, float* save_mean, float* save_invstd, void* stream) {
+                                float* shift, float* save_mean, float* save_invstd, long long* batches_tracked, void* stream) {
     UNET_CHECK_ARG(psum && psumsq && scale && shift && rows > 0 && count > 0 && C > 0, "bn_finalize: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, ST, psum, psumsq, rows, C, (double)count, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, batches_tracked);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

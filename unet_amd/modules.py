@@ -144,8 +144,7 @@ class _BNExec:
             ops.bn_stats(x, part)
             mean, invstd = ctx.vec(self, "mean", C_), ctx.vec(self, "invstd", C_)
             ops.bn_finalize(part, part[rows * C_:], rows, P, C_, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
-                            BN_MOM, BN_EPS, scale, shift, mean, invstd)
-            bn.num_batches_tracked += 1
+                            BN_MOM, BN_EPS, scale, shift, mean, invstd, bn.num_batches_tracked)
         else:
             ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, BN_EPS, scale, shift)
         return scale, shift

@@ -209,9 +209,10 @@ def bn_stats(x: TS, partial: torch.Tensor):
     check(lib.unet_bn_stats(x.ptr, x.cs, x.co, x.P, x.C, partial.data_ptr(), _stream()), "bn_stats")
 
 
-def bn_finalize(psum, psumsq, rows, count, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinvstd):
+def bn_finalize(psum, psumsq, rows, count, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinvstd, tracked=None):
+    assert tracked is None or tracked.dtype == torch.int64
     check(lib.unet_bn_finalize(_p(psum), _p(psumsq), rows, count, C_, _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
-                               _p(scale), _p(shift), _p(smean), _p(sinvstd), _stream()), "bn_finalize")
+                               _p(scale), _p(shift), _p(smean), _p(sinvstd), _p(tracked), _stream()), "bn_finalize")
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
