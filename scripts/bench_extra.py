@@ -52,3 +52,39 @@ if "graph" in which:
     predict_rate("xresnet34", 4, 5, 512, 1, steps=20); predict_rate("xresnet34", 4, 5, 512, 1, steps=20, graph=True)
     train_rate("xresnet34", 4, 5, 512, 16, graph=True)
 if "cfg4" in which: train_rate("xresnet50", 8, 10, 1024, 2, steps=2)
+
+
+def cfg5_rate(side=20000, size=512, overlap=0.2, b=16):
+    """BASELINE configs[4] on ONE GPU: sliding-window inference over a side x side 4-band raster resident in HBM as uint8
+    (window rule of create_tiles_unet.split_raster: step = size - floor(size * overlap), last window flush with the border),
+    batched eval forward + softmax, overlap merge (sum of probabilities + hit counter) and argmax on the device."""
+    from unet_amd import ops
+    torch.manual_seed(0)
+    m = HipDynamicUnet("xresnet34", 4, 5, (size, size)); m.eval()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    raster = torch.randint(0, 256, (4, side, side), dtype=torch.uint8, device="cuda", generator=g)
+    step = size - int(size * overlap)
+    offs = list(range(0, side - size + 1, step))
+    if offs[-1] != side - size:
+        offs.append(side - size)
+    wins = [(y, x) for y in offs for x in offs]
+    mosaic = torch.zeros((5, side, side), dtype=torch.float32, device="cuda")
+    count = torch.zeros((side, side), dtype=torch.int32, device="cuda")
+    am = torch.empty((side, side), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        m.predict_probs(torch.zeros(b, 4, size, size, device="cuda"))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(0, len(wins), b):
+        ws = wins[i:i + b]
+        x = torch.stack([raster[:, y:y + size, x0:x0 + size] for y, x0 in ws]).float() / 255.0
+        probs, _ = m.predict_probs(x, want_argmax=False)
+        for j, (y, x0) in enumerate(ws):
+            ops.mosaic_accumulate(probs[j], mosaic, count, y, x0)
+    ops.mosaic_finalize(mosaic, count, am)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"what": f"cfg5 sliding-window predict {side}x{side}, {len(wins)} windows of {size}, overlap {overlap}, batch {b}, "
+                              "forward + softmax + device merge + argmax", "seconds": round(dt, 2), "tiles_per_s": round(len(wins) / dt, 1),
+                      "covered": bool((count > 0).all().item()), "max_overlap": int(count.max().item())}), flush=True)
+
+
+if "cfg5" in which: cfg5_rate()
