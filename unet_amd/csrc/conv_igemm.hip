@@ -413,7 +413,12 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
 
     // block coordinates (the divisions run on the VALU: readfirstlane returns the results to SGPRs, so that all the
     // pointer arithmetic derived from them is scalar)
-    int bid = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in launch order; give every XCD ONE contiguous range
+    // of tiles, so that the workgroups resident on an XCD at the same time are spatial neighbours (shared halo columns / rows)
+    // and the N-tiles of one pixel tile -- their input reads hit that XCD's L2.  The grid is padded to a multiple of 8.
+    const int per_xcd = (int)(gridDim.x >> 3);
+    int bid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (bid >= a.mtiles * a.ntn) return;
     const int nt = __builtin_amdgcn_readfirstlane(bid % a.ntn); bid /= a.ntn;
     const int mtile = __builtin_amdgcn_readfirstlane(bid);
     const int tx_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_x); bid /= a.tiles_x;
@@ -840,7 +845,8 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     UNET_CHECK_ARG(max_hpix * 4 <= p->hit * 256, "conv: halo tile too large (%d pixels)", max_hpix);
     // the 16x16x4 kernel keeps no filter slab in LDS (operand B goes global -> VGPR)
     p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + (p->mf == 16 ? 0 : 2 * p->bn * LDK)) * sizeof(float);
-    p->grid = dim3((unsigned)((long long)k.mtiles * k.ntn), 1, (unsigned)p->nparity);
+    // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
+    p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), 1, (unsigned)p->nparity);
     UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");
     return UNET_OK;
 }

@@ -346,14 +346,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kk = lane >> 4;
-    const int chunk = blockIdx.x / a.nnb, nb = blockIdx.x % a.nnb;
+    // XCD-aware block mapping: workgroups are dealt round-robin to the 8 XCDs in launch order, and the column blocks / channel
+    // chunks of ONE pixel split stream the same x and dy rows -- put them on the same XCD (ids 8 apart) so that all but the
+    // first read hit that XCD's L2.  grid = (cols, splits rounded up to 8).
+    const int cols = gridDim.x;
+    const int lin = blockIdx.x + cols * blockIdx.y;
+    const int xcd = lin & 7, qq = lin >> 3;
+    const int bx = qq % cols, split = xcd + 8 * (qq / cols);
+    const int chunk = bx / a.nnb, nb = bx % a.nnb;
     const int c0 = chunk * a.cw;
     const int CW = (a.Cin - c0) < a.cw ? (a.Cin - c0) : a.cw;     // channels of this chunk
     const int NTOT = 9 * CW;                                        // real columns
-    const int split = blockIdx.y;
     const int tile_begin = split * a.tiles_per_block;
     int tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    if (tile_begin >= a.total_tiles) return;      // padding of the split count to a multiple of 8 (uniform per workgroup)
 
     // per-lane operand bases (floats): column n -> (tap row r, tap column s, channel c).  The halo tile is a RING of three
     // image rows (row iy lives in slot (iy + 3) % 3): pixel tiles walk DOWN a 32-pixel column strip, so a new tile only
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
     };
 
     // bias gradient: the first workgroup column sums the staged dy tile (one thread per output channel)
-    const bool do_bias = a.bpart != nullptr && blockIdx.x == 0 && tid < a.Cout;
+    const bool do_bias = a.bpart != nullptr && bx == 0 && tid < a.Cout;
     float bsum = 0.f;
     if (tile_begin < tile_end) stage_rows(tile_pos(tile_begin), 0);
     __syncthreads();
@@ -700,6 +707,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     }
     // aim for ~512 workgroups (256 CUs x 2 resident; 1024 for the 3-wave narrow kernel); at least 4 tiles per block
     int want = 512 / cols;
+    if (p->narrow && want >= 8) want &= ~7;      // the XCD-aware mapping pads the split count to a multiple of 8: stay within 512
     if (want < 1) want = 1;
     int tpb = unet::cdiv(k.total_tiles, want);
     if (tpb < 4) tpb = 4;
@@ -795,7 +803,7 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
         rc = UNET_OK;
     } else if (p.narrow) {
         const size_t lds = (size_t)(32 + 3 * 34) * 112 * sizeof(float);
-        const dim3 grid(unet::cdiv(d->Cin, p.k.cw) * p.k.nnb, p.splits);
+        const dim3 grid(unet::cdiv(d->Cin, p.k.cw) * p.k.nnb, unet::roundup(p.splits, 8));
         static bool configured = false;
         if (!configured) {
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
