@@ -70,6 +70,9 @@ typedef struct {
     int kind, flags;
     float* colsum;                       /* optional [rows][Cout] per-wave partial column sums of y (bias-grad / BN stats), or NULL */
     float* colsumsq;                     /* optional same shape, sums of y*y */
+    int cout_begin, cout_count;          /* produce only channels [cout_begin, cout_begin + cout_count) of the Cout-wide problem
+                                            (cout_begin % 16 == 0); 0, 0 = all.  Lets a caller issue e.g. 192 channels as 128 + 64
+                                            with a channel-block width that fits each part. */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */

@@ -36,6 +36,9 @@ CONV_CASES = [
     (2, 32, 32, 100, 5, 1, 1),        # head
     (1, 32, 32, 99, 2, 1, 1),         # 3-channel config head (99 = 96 + 3)
     (1, 16, 16, 64, 128, 1, 1),       # identity-path 1x1
+    (1, 24, 40, 96, 192, 3, 1),       # 192 = 128 + 64 produced channels: issued as two channel-range launches
+    (2, 16, 16, 32, 136, 3, 1),       # 128 + 8
+    (1, 32, 32, 64, 392, 1, 1),       # 3 * 128 + 8 (xresnet50-width decoder)
 ]
 
 
@@ -58,6 +61,38 @@ def test_conv_fwd(ops, case):
     ops.conv2d(xt, wp, yt, ks, stride, bias=b.cuda())
     torch.cuda.synchronize()
     assert_close(from_ts(yt), ref, rtol=2e-4, what=f"conv fwd {case}")
+
+
+def test_conv_channel_range_launch(ops):
+    """unet_conv_desc.cout_begin / cout_count: three launches over disjoint channel ranges of one 176-wide conv (with bias,
+    residual and ReLU) reproduce the single launch bit for bit and touch nothing outside their range"""
+    from unet_amd import _lib as L
+    N, H, W, Cin, Cout = 2, 20, 36, 48, 176
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xt, rt = to_ts(x), to_ts(r)
+    wp = ops.pack_weights(w.cuda(), 0)
+    full = empty_ts(N, H, W, Cout)
+    d = ops._conv_desc(xt, wp, full, 3, 1, L.CONV_FWD, b.cuda(), rt, None, True, None, None)
+    L.check(L.lib.unet_conv2d(L.C.byref(d), ops._stream()), "full")
+    parts = empty_ts(N, H, W, Cout)
+    for beg, cnt in ((0, 64), (64, 96), (160, 16)):
+        d2 = ops._conv_desc(xt, wp, parts, 3, 1, L.CONV_FWD, b.cuda(), rt, None, True, None, None)
+        d2.cout_begin, d2.cout_count = beg, cnt
+        L.check(L.lib.unet_conv2d(L.C.byref(d2), ops._stream()), "part")
+        torch.cuda.synchronize()
+        got = from_ts(parts)
+        assert torch.equal(got[:, beg:beg + cnt], from_ts(full)[:, beg:beg + cnt])
+        assert bool((got[:, beg + cnt:] == 7.25).all())          # channels of later ranges still hold the fill value
+    assert torch.equal(from_ts(parts), from_ts(full))
+    ref = F.relu(F.conv2d(x, w, b, padding=1) + r)
+    assert_close(from_ts(full), ref, rtol=2e-4, what="conv 176")
+    d3 = ops._conv_desc(xt, wp, parts, 3, 1, L.CONV_FWD, None, None, None, False, None, None)
+    d3.cout_begin, d3.cout_count = 8, 16                      # not a multiple of 16
+    assert L.lib.unet_conv2d(L.C.byref(d3), ops._stream()) != 0
 
 
 def test_conv_fwd_slices_relu_res_colsum(ops):

@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("kind", C.c_int), ("flags", C.c_int),
         ("colsum", vp),
         ("colsumsq", vp),
+        ("cout_begin", C.c_int), ("cout_count", C.c_int),
     ]
 
 

@@ -50,6 +50,7 @@ struct KArgs {
     int OH, OW, Cout;
     int S, OS, TSH, TSW, tiles_y, tiles_x, ntn;
     int nchunks, coutPad, flags, mtiles;
+    int n_base, n_end;   // produced-channel range of this launch (unet_conv_desc.cout_begin / cout_count); n_end <= Cout
     TapSet taps[4];
 };
 
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
     const int ty_t = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
     const int oy0 = ty_t * TH, ox0 = tx_t * TW;
-    const int n0 = nt * BN;
+    const int n0 = a.n_base + nt * BN;
 
     const int S = a.S;
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int cout = n0 + (wn * NT + n) * 32 + l31;
-        const bool cvalid = cout < a.Cout;
+        const bool cvalid = cout < a.n_end;
         const float bv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
         float csum = 0.f, csq = 0.f;
 #pragma unroll
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     const int ty_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_y);
     const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
     const int oy0 = ty_t * TH, ox0 = tx_t * TW;
-    const int n0 = nt * BN;
+    const int n0 = a.n_base + nt * BN;
 
     const int S = a.S;
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
@@ -484,8 +485,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     // 16-wide output-channel tiles are dealt round-robin to the WN waves (tile n of this wave = block tile n*WN + wn), so the
     // tiles that survive the Cout cut-off are balanced between the waves' MFMA pipes
     // number of this wave's tiles that contain a real channel: tiles n with (n*WN + wn)*16 < Cout - n0
-    int nvalid = ((a.Cout - n0 + 15) / 16 - wn + WN - 1) / WN;
-    nvalid = (a.Cout - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
+    nvalid = (a.n_end - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
     // operand B: uniform slab pointer + one 32-bit per-lane byte offset (tile n is n * WN * 16 columns = n * WN KiB further),
     // loaded unconditionally (the packed image is padded to the block's 128 columns) so every stage issues exactly N16 loads
     const unsigned lane_b = (unsigned)(((wn * 16 + l15) * KC + 4 * kq) * sizeof(float));
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     for (int n = 0; n < N16; ++n) {
         if (n >= nvalid) continue;
         const int cout = n0 + (n * WN + wn) * 16 + l15;
-        const bool cvalid = cout < a.Cout;
+        const bool cvalid = cout < a.n_end;
         const int cc = cvalid ? cout : 0;
         const float bvv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
         float csum = 0.f, csq = 0.f;
@@ -762,6 +763,11 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     k.mask_cs = d->mask_cs; k.mask_co = d->mask_co; k.y_cs = d->y_cs; k.y_co = d->y_co;
     k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, 4);
     k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
+    // optional produced-channel range (a wide layer can be issued as several launches with different channel-block widths)
+    const int cols = d->cout_count > 0 ? d->cout_count : d->Cout;
+    UNET_CHECK_ARG(d->cout_begin >= 0 && (d->cout_begin & 15) == 0 && d->cout_begin + cols <= d->Cout, "conv: bad cout range [%d,+%d) of %d",
+                   d->cout_begin, cols, d->Cout);
+    k.n_base = d->cout_begin; k.n_end = d->cout_begin + cols;
     k.flags = d->flags;
     k.nchunks = unet::cdiv(d->Cin, KC);
     k.coutPad = unet::roundup(d->Cout, 128);
@@ -819,14 +825,14 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     }
 
     p->tw = k.TSW >= 32 ? 32 : (k.TSW >= 16 ? 16 : 8);
-    p->bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+    p->bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
     p->bm = 128;
     p->hit = (k.S == 2) ? 10 : 4;
     p->mf = g_mfma_shape;
     // small problems (deep 16x16 / 32x32 stages): shrink the tile until the grid can fill 256 CUs x 2
     auto blocks = [&](int bm, int bn) {
         const int th_ = bm / p->tw;
-        return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(d->Cout, bn) * p->nparity;
+        return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(cols, bn) * p->nparity;
     };
     if (p->bn >= 64 && blocks(128, p->bn) < 400) {
         p->bm = 64;
@@ -835,7 +841,8 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     const int th = p->bm / p->tw;
     k.tiles_y = unet::cdiv(k.TSH, th);
     k.tiles_x = unet::cdiv(k.TSW, p->tw);
-    k.ntn = unet::cdiv(d->Cout, p->bn);
+    k.ntn = unet::cdiv(cols, p->bn);
+    UNET_CHECK_ARG(k.n_base + k.ntn * p->bn <= k.coutPad, "conv: cout range leaves the packed filter image");
     k.mtiles = d->N * k.tiles_y * k.tiles_x;
     int max_hpix = 0;
     for (int z = 0; z < p->nparity; ++z) {

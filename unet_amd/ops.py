@@ -132,6 +132,7 @@ class ConvProbe:
         self.variant = variant
         self.events = []
         self.flops = 0.0
+        self.detail = []          # (what, N, H, W, Cin, Cout, ks, stride, flops) per probed launch
 
     def summary(self):
         ms = [a.elapsed_time(b) for a, b in self.events]
@@ -141,7 +142,7 @@ class ConvProbe:
 CONV_PROBE: Optional[ConvProbe] = None
 
 
-def _launch_conv(d: ConvDesc, what: str, alg_flops: float):
+def _launch_conv_part(d: ConvDesc, what: str, alg_flops: float):
     pr = CONV_PROBE
     if pr is not None and lib.unet_conv2d_variant(C.byref(d)) == pr.variant:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -150,8 +151,24 @@ def _launch_conv(d: ConvDesc, what: str, alg_flops: float):
         e1.record()
         pr.events.append((e0, e1))
         pr.flops += alg_flops
+        pr.detail.append((what, d.N, d.OH, d.OW, d.Cin, d.cout_count or d.Cout, d.ks, d.stride, alg_flops))
         return
     check(lib.unet_conv2d(C.byref(d), _stream()), what)
+
+
+def _launch_conv(d: ConvDesc, what: str, alg_flops: float):
+    """A produced-channel count of k*128 + r with 0 < r <= 64 would run its last 128-wide channel block at most half full
+    (and re-stage the input tile for it): issue the k*128 part and the r-wide part as two launches, the second with a 64- or
+    32-wide channel block.  Column sums (rows depend on the tile geometry of ONE launch) keep the single launch."""
+    Co = d.Cout
+    r = Co % 128
+    if Co > 128 and 0 < r <= 64 and not d.colsum:
+        for b, n in ((0, Co - r), (Co - r, r)):
+            d.cout_begin, d.cout_count = b, n
+            _launch_conv_part(d, what, alg_flops * n / Co)
+        d.cout_begin = d.cout_count = 0
+        return
+    _launch_conv_part(d, what, alg_flops)
 
 
 def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, res=None, mask=None, relu=False,
