@@ -117,3 +117,39 @@ def test_gradient_reducer_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_degenerate_and_oversized_problems_are_rejected_before_any_launch():
+    """empty batch, zero-sized tiles, channel slices that leave their buffer, a grid beyond 2^31 tiles, an unsupported loss kind
+    and a too-small split-K workspace: every entry point validates on the host and returns UNET_E_BADARG with a message"""
+    import ctypes as C
+    import unet_amd._lib as L
+    fake = 0x100000            # never dereferenced: validation precedes every launch
+
+    def conv(**kw):
+        d = L.ConvDesc()
+        base = dict(x=fake, x_cs=16, x_co=0, wp=fake, y=fake, y_cs=16, y_co=0, N=1, IH=8, IW=8, Cin=16, OH=8, OW=8, Cout=16, ks=3,
+                    stride=1, kind=0, flags=0)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        return L.lib.unet_conv2d(C.byref(d), None), L.lib.unet_last_error().decode()
+
+    for kw in (dict(N=0), dict(IH=0, OH=0), dict(Cin=0), dict(x_co=8), dict(y_cs=12), dict(ks=5), dict(stride=3),
+               dict(OH=9), dict(cout_begin=8, cout_count=8), dict(cout_begin=16, cout_count=16),
+               dict(N=1 << 20, IH=4096, IW=4096, OH=4096, OW=4096)):
+        rc, msg = conv(**kw)
+        assert rc == -1 and msg, (kw, rc, msg)
+
+    w = L.WgradDesc()
+    for k, v in dict(x=fake, x_cs=16, x_co=0, dy=fake, dy_cs=16, dy_co=0, dw=fake, N=1, IH=8, IW=8, Cin=16, OH=8, OW=8, Cout=16, ks=3,
+                     stride=1, workspace=fake, workspace_floats=1).items():
+        setattr(w, k, v)
+    assert L.lib.unet_conv2d_wgrad(C.byref(w), None) == -1 and b"workspace" in L.lib.unet_last_error()
+    w.N = 0
+    assert L.lib.unet_conv2d_wgrad(C.byref(w), None) == -1
+    assert L.lib.unet_conv2d_wgrad_workspace(C.byref(w)) == 0
+    assert L.lib.unet_regloss_fwd(fake, 4, 0, fake, 10, 7, 0.5, fake, fake, None) == -1      # unknown loss kind
+    assert L.lib.unet_regloss_fwd(fake, 4, 0, fake, 0, 0, 0.5, fake, fake, None) == -1       # no pixels
+    assert L.lib.unet_ce_fwd(fake, 8, 0, fake, None, 10, 65, fake, fake, fake, None) == -1   # more classes than the kernel supports
+    assert L.lib.unet_adam_hyper_floats() > 0

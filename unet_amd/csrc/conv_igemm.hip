@@ -843,7 +843,14 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     k.tiles_x = unet::cdiv(k.TSW, p->tw);
     k.ntn = unet::cdiv(cols, p->bn);
     UNET_CHECK_ARG(k.n_base + k.ntn * p->bn <= k.coutPad, "conv: cout range leaves the packed filter image");
-    k.mtiles = d->N * k.tiles_y * k.tiles_x;
+    // in-image element offsets are 32-bit inside the kernels (the image index is applied in 64 bits)
+    UNET_CHECK_ARG((long long)d->IH * d->IW * d->x_cs < (1ll << 31) && (long long)d->OH * d->OW * d->y_cs < (1ll << 31) &&
+                   (d->res == nullptr || (long long)d->OH * d->OW * d->res_cs < (1ll << 31)) &&
+                   (d->mask == nullptr || (long long)d->OH * d->OW * d->mask_cs < (1ll << 31)),
+                   "conv: one image of a tensor exceeds 2^31 elements");
+    const long long mtiles_ll = (long long)d->N * k.tiles_y * k.tiles_x;
+    UNET_CHECK_ARG(mtiles_ll * k.ntn < (1ll << 31) - 8, "conv: grid too large (%lld pixel tiles x %d channel blocks)", mtiles_ll, k.ntn);
+    k.mtiles = (int)mtiles_ll;
     int max_hpix = 0;
     for (int z = 0; z < p->nparity; ++z) {
         const int hh = (th - 1) * k.S + k.taps[z].ext_y, hw = (p->tw - 1) * k.S + k.taps[z].ext_x;

@@ -662,6 +662,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     UNET_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride must be 1 or 2");
     UNET_CHECK_ARG(!(d->ks == 1 && d->stride != 1), "wgrad: 1x1 stride 2 unsupported");
     UNET_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0, "wgrad: bad dims");
+    UNET_CHECK_ARG((long long)d->N * d->OH * d->OW < (1ll << 31), "wgrad: more than 2^31 output pixels");
     const int pad = (d->ks - 1) / 2;
     UNET_CHECK_ARG(d->OH == (d->IH + 2 * pad - d->ks) / d->stride + 1 && d->OW == (d->IW + 2 * pad - d->ks) / d->stride + 1,
                    "wgrad: output dims inconsistent");
