@@ -387,3 +387,66 @@ def test_regression_train_step_matches_oracle(loss_name, kind):
         vals = model.predict_values(x.cuda()).cpu()
         assert vals.shape == (bs, 1, size[0], size[1])
         assert (vals - ref(x)).abs().max().item() < 1e-3 * max(1.0, ref(x).abs().max().item())
+
+
+def test_fit_one_cycle_trajectory_matches_oracle_training_loop():
+    """Six optimizer steps of ``Learner.fit_one_cycle`` (2 epochs x 3 batches: schedule, weighted CE, backward, fastai Adam with
+    three parameter groups and no weight decay on norm/bias parameters) against the same loop written with the oracle's
+    modules: per-batch losses and the final parameters.  Smooth (ReLU-flip-free) network, so that six steps of error
+    propagation stay at rounding level."""
+    import numpy as np
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, DiceMulti, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    arch, n_in, n_out, size, bs, n_items, n_epoch = "xresnet18", 4, 3, (64, 64), 2, 6, 2
+    torch.manual_seed(21)
+    ref = O.DynamicUnet(arch, n_in, n_out, size)
+    O.randomize_bn_and_zero_gammas(ref, seed=22)
+    _make_all_active(ref)
+    model = HipDynamicUnet(arch, n_in, n_out, size)
+    model.load_state_dict(ref.state_dict())
+    g = np.random.default_rng(23)
+    imgs = [g.integers(0, 256, (n_in, *size)).astype(np.uint8) for _ in range(n_items)]
+    masks = [g.integers(0, n_out, size).astype(np.uint8) for _ in range(n_items)]
+    w = torch.tensor([0.2, 0.3, 0.5])
+    dls = DataLoaders(TileDataset(imgs, masks, "int8"), None, bs, device="cuda", vocab=["a", "b", "c"], seed=5)
+    dls.train.shuffle = False                                       # same batch order on both sides
+    learn = Learner(dls, model, loss_func=CrossEntropyLossFlat(axis=1, weight=w), metrics=[DiceMulti()])
+    lr, factor = 2e-3, 10.0
+    learn.fit_one_cycle(n_epoch, lr_max=slice(lr / factor, lr))
+    torch.cuda.synchronize()
+
+    groups = O.xresnet_split(ref)
+    opt = O.FastaiAdam(groups, lr, no_wd=O.bn_bias_params(ref))
+    lr_f, mom_f = O.one_cycle_scheds(O.even_mults(lr / factor, lr, 3))
+    loss_fn = O.CrossEntropyLossFlat(weight=w)
+    ref.train()
+    n_iter = n_items // bs
+    losses, it = [], 0
+    for _ in range(n_epoch):
+        for b in range(n_iter):
+            x = torch.from_numpy(np.stack(imgs[b * bs:(b + 1) * bs]).astype(np.float32) / 255.0)
+            y = torch.from_numpy(np.stack(masks[b * bs:(b + 1) * bs]).astype(np.int64))
+            pct = it / (n_epoch * n_iter)
+            opt.lrs, opt.mom = list(lr_f(pct)), float(mom_f(pct))
+            opt.zero_grad()
+            loss = loss_fn(ref(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            it += 1
+    # Recorder keeps the AvgSmoothLoss values; undo the smoothing to get the raw per-batch losses back
+    sm, raw, val = learn.recorder.losses, [], 0.0
+    for i, s_ in enumerate(sm, 1):
+        v = s_ * (1 - 0.98 ** i)
+        raw.append((v - 0.98 * val) / 0.02)
+        val = v
+    assert len(raw) == len(losses) == 6
+    for a, b_ in zip(raw, losses):
+        assert abs(a - b_) < 2e-4 * max(1.0, abs(b_)), (raw, losses)
+    worst = ("", 0.0)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        e = (p.detach().cpu() - q.detach()).abs().max().item() / (q.detach().abs().max().item() + 1e-12)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < 2e-3, worst
+    assert np.allclose(learn.recorder.lrs, [lr_f(i / 6)[-1] for i in range(6)], rtol=1e-6)
