@@ -161,7 +161,10 @@ WGRAD_CASES = [
     (2, 26, 26, 64, 128, 3, 2),
     (1, 25, 25, 32, 64, 3, 2),
     (2, 16, 16, 128, 256, 1, 1),
-    (2, 32, 32, 100, 5, 1, 1),
+    (2, 32, 32, 100, 5, 1, 1),        # head: FMA kernel for <= 16 output channels
+    (1, 17, 19, 8, 16, 1, 1),
+    (3, 9, 7, 36, 3, 1, 1),
+    (8, 128, 128, 100, 10, 1, 1),     # many workgroups, 10 classes
     (4, 64, 64, 64, 64, 3, 1),        # several split-K partials
     # narrow-output kernel (taps flattened into the column dimension): 80 < Cout <= 112, width >= 32
     (1, 33, 64, 192, 96, 3, 1),       # two input-channel chunks of 96, 6 output tiles x 7 column tiles per wave

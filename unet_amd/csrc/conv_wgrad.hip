@@ -614,6 +614,100 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const WArgs a, long lo
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 weight gradient with a handful of output channels (the classification / regression head: 100 -> n_classes <= 16): a
+// 128 x 128 MFMA block would be 96 % padding and is HBM-bound anyway (x is read once, 1.7 GB at 16 x 512^2 x 100).  Plain
+// FMA: a thread owns 4 input channels (one float4 of x per pixel) x all K output channels; the PS pixel lanes of a workgroup
+// and the workgroups write separate partial rows [row][k][c] (no atomics, no LDS), summed by wgrad_reduce_kernel.
+template <int K4>   // ceil(Cout / 4): 1..4
+__global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const WArgs a, long long P, int PS, long long pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [PS][KK * Cin4 + KK]: lane partials [k][c] + bias sums [k]
+    const int C4 = a.Cin4 >> 2;
+    const int tid = threadIdx.x;
+    const int q = tid % C4, lane = tid / C4;
+    const bool active = lane < PS;
+    const long long p_begin = (long long)blockIdx.x * pix_per_block;
+    long long p_end = p_begin + pix_per_block;
+    if (p_end > P) p_end = P;
+    float acc[4 * K4][4];
+    float bsum[4 * K4];
+#pragma unroll
+    for (int k = 0; k < 4 * K4; ++k) {
+        bsum[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    }
+    if (active) {
+        for (long long p = p_begin + lane; p < p_end; p += PS) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)p * a.x_cs + a.x_co + 4 * q);
+            const float* dyp = a.dy + (size_t)p * a.dy_cs + a.dy_co;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) {
+                const float4 d = (4 * k4 < a.Cout4) ? *reinterpret_cast<const float4*>(dyp + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[4 * k4 + i][0] += dv[i] * xv.x; acc[4 * k4 + i][1] += dv[i] * xv.y;
+                    acc[4 * k4 + i][2] += dv[i] * xv.z; acc[4 * k4 + i][3] += dv[i] * xv.w;
+                    bsum[4 * k4 + i] += dv[i];
+                }
+            }
+        }
+    }
+    // sum the PS pixel lanes of this workgroup in a fixed order (deterministic) through LDS: one partial row per workgroup
+    constexpr int KK = 4 * K4;
+    const int rowlen = C4 * 4;                      // floats per k of one lane
+    const int lstride = KK * rowlen + KK;           // floats per lane
+    if (active) {
+        float* mine = smem + (size_t)lane * lstride;
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine[k * rowlen + 4 * q + j] = acc[k][j];
+        if (q == 0) {
+#pragma unroll
+            for (int k = 0; k < KK; ++k) mine[KK * rowlen + k] = bsum[k];
+        }
+    }
+    __syncthreads();
+    const size_t KCf = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)blockIdx.x * KCf;
+    for (int e = tid; e < a.Cout * a.Cin; e += 256) {
+        const int k = e / a.Cin, c = e - k * a.Cin;
+        float sum = 0.f;
+        for (int l = 0; l < PS; ++l) sum += smem[(size_t)l * lstride + k * rowlen + c];
+        pb[e] = sum;
+    }
+    if (a.bpart != nullptr && tid < a.Cout) {
+        float sum = 0.f;
+        for (int l = 0; l < PS; ++l) sum += smem[(size_t)l * lstride + KK * rowlen + tid];
+        a.bpart[(size_t)blockIdx.x * a.Cout + tid] = sum;
+    }
+}
+
+// second stage for FEW outputs and MANY partial rows (the head): 4 row lanes x 64 elements per workgroup, fixed summation order
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ dw, int rows, int T,
+                                                                size_t KC_, int accumulate) {
+    __shared__ float sm[4][64];
+    const size_t total = (size_t)T * KC_;
+    const int el = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int r = rl;
+        for (; r + 4 < rows; r += 8) { s0 += part[(size_t)r * total + e]; s1 += part[(size_t)(r + 4) * total + e]; }
+        for (; r < rows; r += 4) s0 += part[(size_t)r * total + e];
+    }
+    sm[rl][el] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && e < total) {
+        const float sum = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+        const size_t t = e / KC_, i = e - t * KC_;
+        float* o = dw + i * T + t;
+        *o = accumulate ? (*o + sum) : sum;
+    }
+}
+
 // dw[(k*Cin + c)*T + t] (=|+=) sum_split part[split][t][k][c]
 // one thread per (t, k*Cin+c): reads are coalesced along c for every split, 8 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T,
@@ -651,7 +745,8 @@ static int g_wgrad_1x1 = 1;           // 128x128-tiled GEMM kernel for 1x1 weigh
 
 struct WPlan {
     WArgs k;
-    int ptw, splits, T, narrow, gemm1x1;
+    int ptw, splits, T, narrow, gemm1x1, small1x1, ps;
+    long long pix_per_block;
     size_t lds_bytes, lds_bytes16;
 };
 
@@ -697,6 +792,27 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         const int ntw = d->Cout > 96 ? 5 : 7;                     // column tiles per wave (KT = 7 / 6 output-channel tiles)
         k.nnb = unet::cdiv(unet::cdiv(9 * k.cw, 16), 4 * ntw);
         cols = nch * k.nnb;
+    }
+    // heads: 1x1 with <= 16 output channels and <= 1024 input channels -> FMA kernel, one partial row per (workgroup, pixel lane)
+    p->small1x1 = (d->ks == 1 && d->Cout <= 16 && k.Cin4 <= 512 && g_wgrad_1x1) ? 1 : 0;
+    p->ps = 1; p->pix_per_block = 0;
+    if (p->small1x1) {
+        const long long P = (long long)d->N * d->OH * d->OW;
+        p->ps = 256 / (k.Cin4 / 4);
+        {
+            const int kk = 4 * ((d->Cout + 3) / 4);
+            const int per_lane = (kk * k.Cin4 + kk) * (int)sizeof(float);
+            if (p->ps > 65536 / per_lane) p->ps = 65536 / per_lane;
+            if (p->ps < 1) p->ps = 1;
+        }
+        long long blocks = P / ((long long)p->ps * 64);            // >= 64 pixels per thread
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        p->pix_per_block = (P + blocks - 1) / blocks;
+        p->splits = (int)((P + p->pix_per_block - 1) / p->pix_per_block);       // one partial row per workgroup
+        p->gemm1x1 = 0;
+        p->lds_bytes = p->lds_bytes16 = 0;
+        return UNET_OK;
     }
     p->gemm1x1 = (d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
     if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
@@ -792,7 +908,21 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
                    d->workspace_floats, need);
     p.k.bpart = d->dbias != nullptr ? d->workspace + npart : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (p.gemm1x1) {
+    if (p.small1x1) {
+        const long long P = (long long)d->N * d->OH * d->OW;
+        const dim3 grid((unsigned)p.splits);
+        const int k4 = (d->Cout + 3) / 4;
+        const size_t lds = (size_t)p.ps * (4 * k4 * p.k.Cin4 + 4 * k4) * sizeof(float);
+        UNET_CHECK_ARG(lds <= 64 * 1024, "wgrad: head kernel needs %zu bytes of LDS", lds);
+        switch (k4) {
+            case 1: hipLaunchKernelGGL(wgrad1x1_small_kernel<1>, grid, dim3(256), lds, st, p.k, P, p.ps, p.pix_per_block); break;
+            case 2: hipLaunchKernelGGL(wgrad1x1_small_kernel<2>, grid, dim3(256), lds, st, p.k, P, p.ps, p.pix_per_block); break;
+            case 3: hipLaunchKernelGGL(wgrad1x1_small_kernel<3>, grid, dim3(256), lds, st, p.k, P, p.ps, p.pix_per_block); break;
+            default: hipLaunchKernelGGL(wgrad1x1_small_kernel<4>, grid, dim3(256), lds, st, p.k, P, p.ps, p.pix_per_block); break;
+        }
+        UNET_CHECK_LAUNCH();
+        rc = UNET_OK;
+    } else if (p.gemm1x1) {
         static bool configured = false;
         if (!configured) {
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -823,8 +953,12 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     }
     if (rc != UNET_OK) return rc;
     const size_t KC_ = (size_t)d->Cout * d->Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_ * p.T, 256)), dim3(256), 0, st, d->workspace, d->dw,
-                       p.splits, p.T, KC_, d->accumulate);
+    if (p.small1x1)
+        hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(unet::cdiv((int)(KC_ * p.T), 64)), dim3(256), 0, st, d->workspace, d->dw,
+                           p.splits, p.T, KC_, d->accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_ * p.T, 256)), dim3(256), 0, st, d->workspace, d->dw,
+                           p.splits, p.T, KC_, d->accumulate);
     UNET_CHECK_LAUNCH();
     if (d->dbias != nullptr) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(unet::cdiv(d->Cout, 128)), dim3(128), 0, st, p.k.bpart, d->dbias, p.splits,
