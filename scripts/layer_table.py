@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(1)
 x = (torch.randint(0, 256, (16, 4, 512, 512), generator=g).float() / 255).cuda(); y = torch.randint(0, 5, (16, 512, 512), generator=g).cuda()
 for _ in range(3): st(x, y)
 torch.cuda.synchronize()
-ops.CONV_PROBE = pr = ops.ConvProbe(32 * 10000 + 128 * 10)
+ops.CONV_PROBE = pr = ops.ConvProbe(int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 10000 + 128 * 10)
 st(x, y)
 torch.cuda.synchronize()
 ops.CONV_PROBE = None

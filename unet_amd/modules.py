@@ -84,6 +84,11 @@ def _no_forward(self, *a, **k):
 # leaf helpers: one convolution / one batch norm on the device
 # --------------------------------------------------------------------------
 
+# BatchNorm batch statistics from the producing conv's epilogue instead of a separate pass over y.  Parity-tested, but OFF: the
+# per-wave partial rows (4096 for a 128x128 stage) make the finalize kernel slower than the pass it saves (step 122.5 -> 127.0 ms).
+FUSE_BN_STATS = False
+
+
 class _ConvExec:
     """Packed-weight cache + launches for one nn.Conv2d parameter holder."""
 
@@ -117,6 +122,17 @@ class _ConvExec:
         b = self.conv.bias
         ops.conv2d(x, self.packed(0), y, self.ks, self.stride, bias=None if b is None else b.data, res=res, relu=relu)
 
+    def fwd_stats(self, ctx: Ctx, x: TS, y: TS):
+        """conv whose epilogue also emits the per-wave partial column sums / sums of squares of y: the BatchNorm statistics of
+        the following layer without a second pass over y.  Returns (psum, psumsq, rows)."""
+        assert self.conv.bias is None
+        wp = self.packed(0)
+        rows = ops.conv_colsum_rows(x, wp, y, self.ks, self.stride, 0)
+        part = ctx.workspace(2 * rows * y.C)
+        cs, cq = part[:rows * y.C], part[rows * y.C:]
+        ops.conv2d(x, wp, y, self.ks, self.stride, colsum=cs, colsumsq=cq)
+        return cs, cq, rows
+
     def bwd_w(self, ctx: Ctx, x: TS, dy: TS):
         """weight (+bias) gradient into the .grad views of the flat gradient buffer"""
         w, b = self.conv.weight, self.conv.bias
@@ -134,16 +150,21 @@ class _BNExec:
         self.bn = bn
         self.C = bn.num_features
 
-    def coeffs(self, ctx: Ctx, x: TS) -> Tuple[torch.Tensor, torch.Tensor]:
+    def coeffs(self, ctx: Ctx, x: TS, partials=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """partials = (psum, psumsq, rows) from the producing conv's epilogue (train mode), else a statistics pass over x"""
         bn, C_ = self.bn, self.C
         scale, shift = ctx.vec(self, "scale", C_), ctx.vec(self, "shift", C_)
         if ctx.training:
             P = x.P
-            rows = ops.bn_stats_rows(P)
-            part = ctx.workspace(2 * rows * C_)
-            ops.bn_stats(x, part)
+            if partials is None:
+                rows = ops.bn_stats_rows(P)
+                part = ctx.workspace(2 * rows * C_)
+                ops.bn_stats(x, part)
+                ps, pq = part, part[rows * C_:]
+            else:
+                ps, pq, rows = partials
             mean, invstd = ctx.vec(self, "mean", C_), ctx.vec(self, "invstd", C_)
-            ops.bn_finalize(part, part[rows * C_:], rows, P, C_, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+            ops.bn_finalize(ps, pq, rows, P, C_, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
                             BN_MOM, BN_EPS, scale, shift, mean, invstd, bn.num_batches_tracked)
         else:
             ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, BN_EPS, scale, shift)
@@ -200,8 +221,7 @@ class ConvLayer(nn.Sequential):
         OH, OW = self.cx.out_hw(x.H, x.W)
         if self.has_bn:
             y = ctx.act(self, "y", x.N, OH, OW, self.nf)
-            self.cx.fwd(x, y)
-            scale, shift = self.bx.coeffs(ctx, y)
+            scale, shift = self._conv_bn(ctx, x, y)
             a = ctx.act(self, "a", x.N, OH, OW, self.nf)
             ops.affine_act(y, a, scale, shift, relu=self.has_act)
         else:
@@ -214,10 +234,16 @@ class ConvLayer(nn.Sequential):
         """conv + BN statistics only (the affine is applied by the caller, fused with the residual add)."""
         OH, OW = self.cx.out_hw(x.H, x.W)
         y = ctx.act(self, "y", x.N, OH, OW, self.nf)
-        self.cx.fwd(x, y)
-        scale, shift = self.bx.coeffs(ctx, y)
+        scale, shift = self._conv_bn(ctx, x, y)
         ctx.saved[(id(self), "x")] = x
         return y, scale, shift
+
+    def _conv_bn(self, ctx: Ctx, x: TS, y: TS):
+        """conv + BatchNorm coefficients; in train mode the batch statistics come out of the conv epilogue"""
+        if ctx.training and FUSE_BN_STATS and not (self.nf > 128 and 0 < self.nf % 128 <= 64):    # (not for split launches)
+            return self.bx.coeffs(ctx, y, self.cx.fwd_stats(ctx, x, y))
+        self.cx.fwd(x, y)
+        return self.bx.coeffs(ctx, y)
 
     def hip_bwd(self, ctx: Ctx, da: TS, need_dx=True, dx_res: Optional[TS] = None) -> Optional[TS]:
         """BN flavour: da = dL/d(output).  Returns dL/dx (+ dx_res fused) or None."""
