@@ -2,7 +2,7 @@
 # GPU-side evidence run for profiles/: bench line, rocprofv3 kernel stats, two separate PMC passes (HBM traffic), SQ pass.
 # usage (from the repo root, through gpurun): bash scripts/profile_round.sh <tag>
 TAG=${1:-r01_x}
-R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+R=$PWD; OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 tail -1 $OUT/bench.json | cut -c1-200
 export TMPDIR=/tmp; cd /tmp
