@@ -822,7 +822,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         k.tiles_y = k.tiles_x = 1;
         cols = k.kt * k.ct;
     }
-    // aim for ~512 workgroups (256 CUs x 2 resident; 1024 for the 3-wave narrow kernel); at least 4 tiles per block
+    // aim for ~512 workgroups (256 CUs x 2 resident); at least 4 tiles per block
     int want = 512 / cols;
     if (p->narrow && want >= 8) want &= ~7;      // the XCD-aware mapping pads the split count to a multiple of 8: stay within 512
     if (want < 1) want = 1;
