@@ -155,3 +155,25 @@ def test_input_gradient_program_is_linear_at_full_resolution():
     scale = d1.buf.abs().max().item()
     assert (d12.buf - (d1.buf + d2.buf)).abs().max().item() < 2e-5 * scale
     assert torch.equal(d3.buf, 2.0 * d1.buf)        # a power of two commutes with every fp32 rounding: bit-identical
+
+
+def test_xresnet50_wide_decoder_tile_against_the_oracle():
+    """BASELINE configs[3] family (xresnet50, 8 bands, 10 classes) on a 256x256 tile: 2048-channel bottleneck, 392-wide final
+    ResBlock (3 * 128 + 8 produced channels: channel-range launches), eval logits and mask against the oracle"""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(2)
+    ref = O.DynamicUnet("xresnet50", 8, 10, (256, 256))
+    O.randomize_bn_and_zero_gammas(ref, seed=3)
+    model = HipDynamicUnet("xresnet50", 8, 10, (256, 256))
+    model.load_state_dict(ref.state_dict())
+    x, _ = O.synthetic_batch(1, 8, 256, 256, 10)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z_ref = ref(x)
+        z = model(x.cuda()).cpu()
+        _, amax = model.predict_probs(x.cuda())
+    err, scale = (z - z_ref).abs().max().item(), z_ref.abs().max().item()
+    assert err < 1e-3 * max(1.0, scale / 8.0), f"logit err {err} at logit scale {scale}"
+    diff = amax.cpu()[0] != z_ref.argmax(dim=1)[0]
+    top2 = z_ref[0].topk(2, dim=0).values
+    assert int(diff.sum()) <= 4 and bool(((top2[0] - top2[1])[diff] <= 2 * err).all())
