@@ -10,66 +10,74 @@ import time
 from unet_amd import xresnet18, xresnet34, xresnet50  # noqa: F401
 
 # ----------------------------------------------------------------------------------- switches (params_and_main.py:22-24)
-Create_tiles = False
-Train = True
+Create_tiles = True
+Train = False
 Predict = False
 
-# ----------------------------------------------------------------------------------- tiles (params_and_main.py:27-47)
+# ----------------------------------------------------------------------------------- tiles (params_and_main.py:31-38)
 image_path = "PATH"
-mask_path = "PATH"
+mask_path = "PATH"             # None when cutting prediction tiles without a mask
 base_dir = "PATH"
 patch_size = 400
-patch_overlap = 0
+patch_overlap = 0              # 0.2 with split = [1] to cut prediction tiles of a full image
 split = [0.8, 0.2]
-class_zero = False
-max_empty = 0.9
 
-# ----------------------------------------------------------------------------------- training (params_and_main.py:49-118)
-data_path = "PATH"
+# ----------------------------------------------------------------------------------- training (params_and_main.py:45-63)
+data_path = base_dir
 model_path = "PATH"
-description = "unet_run"
-info = ""
-BATCH_SIZE = 16
-EPOCHS = 30
-LEARNING_RATE = 1e-4
+description = "Beschirmung_geo_Aug_data"
+info = "RGB images"
+existing_model = None          # or the path of an exported model: transfer learning
+BATCH_SIZE = 4                 # the reference's value for a 16 GB P100; 16 fits an MI355X many times over
+EPOCHS = 15
+LEARNING_RATE = 0.0001
 enable_regression = False
-visualize_data_example = False
+visualize_data_example = True  # plots are out of scope on this path (ignored)
 export_model_summary = True
-enable_extra_parameters = False
-self_attention = False
-ENCODER_FACTOR = 10
-LR_FINDER = None
-VALID_SCENES = ["vali"]
-loss_func = None
-monitor = "dice_multi"
-CLASS_WEIGHTS = "even"
-ARCHITECTURE = xresnet34
-existing_model = None
-CODES = ["background", "class1", "class2", "class3", "class4"]
-transforms = False
-n_transform_imgs = 1
-aug_pipe = None
-split_idx = None
+CODES = ["NO_Data", "Background", "Beschirmung"]
+CLASS_WEIGHTS = "even"         # list, "even" or "weighted"
 
-# ----------------------------------------------------------------------------------- prediction
+# ----------------------------------------------------------------------------------- prediction (params_and_main.py:68-76)
 predict_path = "PATH"
-predict_model = "PATH"
-AOI = None
-year = None
+predict_model = "PATH"         # model_path/description/description.pkl
+AOI = "str"
+year = "str"
 merge = False
+regression = False
+validation_vision = True       # confusion-matrix figures: out of scope on this path (ignored)
+
+# ----------------------------------------------------------------------------------- extra parameters (params_and_main.py:84-118)
+enable_extra_parameters = True
+self_attention = True
+ENCODER_FACTOR = 10
+LR_FINDER = None               # None, "minimum", "steep", "valley", "slide"
+VALID_SCENES = ["vali"]
+loss_func = None               # None = CrossEntropyLossFlat(axis=1) (the reference's default object); regression: MSELossFlat(axis=1), L1LossFlat
+monitor = "valid_loss"         # 'dice_multi', 'r2_score', 'train_loss', 'valid_loss'
 all_classes = False
 specific_class = None
 large_file = False
-validation_vision = False
-regression = False
+max_empty = 0.2
+class_zero = False
+ARCHITECTURE = xresnet34
+transforms = True
+split_idx = 0
+n_transform_imgs = 1
+aug_pipe = None                # None = the reference's default pipeline: HorizontalFlip(p=0.5) + VerticalFlip(p=0.5) (unet_amd.learner.FlipAugment)
 
 
 def main():
-    global self_attention, ENCODER_FACTOR, LR_FINDER, loss_func, monitor, ARCHITECTURE, transforms
+    global large_file, specific_class, all_classes, transforms, VALID_SCENES, self_attention, monitor, loss_func, LR_FINDER
+    global ENCODER_FACTOR, ARCHITECTURE, enable_regression, max_empty
     t0 = time.time()
-    if not enable_extra_parameters:      # params_and_main.py:130-146: reset the "expert" knobs
-        self_attention, ENCODER_FACTOR, LR_FINDER, loss_func, monitor = False, 10, None, None, "dice_multi"
-        ARCHITECTURE, transforms = xresnet34, False
+    if enable_extra_parameters:          # params_and_main.py:129-145
+        import warnings
+        warnings.warn("Extra parameters are enabled. Code may behave in unexpected ways. "
+                      "Please disable unless experienced with the code.")
+    else:
+        ENCODER_FACTOR, LR_FINDER, VALID_SCENES, loss_func, monitor = 10, None, ["vali"], None, None
+        all_classes, specific_class, enable_regression, large_file, max_empty = False, None, False, False, 0.9
+        ARCHITECTURE, self_attention = xresnet34, False
     if Create_tiles:
         from create_tiles_unet import split_raster
         split_raster(path_to_raster=image_path, path_to_mask=mask_path, base_dir=base_dir, patch_size=patch_size,

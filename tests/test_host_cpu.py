@@ -153,3 +153,27 @@ def test_degenerate_and_oversized_problems_are_rejected_before_any_launch():
     assert L.lib.unet_regloss_fwd(fake, 4, 0, fake, 0, 0, 0.5, fake, fake, None) == -1       # no pixels
     assert L.lib.unet_ce_fwd(fake, 8, 0, fake, None, 10, 65, fake, fake, fake, None) == -1   # more classes than the kernel supports
     assert L.lib.unet_adam_hyper_floats() > 0
+
+
+def test_params_and_main_surface(monkeypatch):
+    """the configuration module keeps the reference's global names (params_and_main.py:21-118) and its main() dispatches to the
+    three stages with the reference's argument lists"""
+    import params_and_main as P
+    for name in ("Create_tiles Train Predict image_path mask_path base_dir patch_size patch_overlap split data_path model_path "
+                 "description info existing_model BATCH_SIZE EPOCHS LEARNING_RATE enable_regression visualize_data_example "
+                 "export_model_summary CODES CLASS_WEIGHTS predict_path predict_model AOI year merge regression validation_vision "
+                 "enable_extra_parameters self_attention ENCODER_FACTOR LR_FINDER VALID_SCENES loss_func monitor all_classes "
+                 "specific_class large_file max_empty class_zero ARCHITECTURE transforms split_idx n_transform_imgs aug_pipe").split():
+        assert hasattr(P, name), name
+    calls = {}
+    import create_tiles_unet, predict, train
+    monkeypatch.setattr(create_tiles_unet, "split_raster", lambda **kw: calls.setdefault("tiles", kw))
+    monkeypatch.setattr(train, "train_func", lambda *a: calls.setdefault("train", a))
+    monkeypatch.setattr(predict, "save_predictions", lambda *a, **k: calls.setdefault("predict", a))
+    monkeypatch.setattr(P, "Create_tiles", True); monkeypatch.setattr(P, "Train", True); monkeypatch.setattr(P, "Predict", True)
+    monkeypatch.setattr(P, "enable_extra_parameters", False)
+    P.main()
+    assert set(calls) == {"tiles", "train", "predict"}
+    assert len(calls["train"]) == 25 and calls["train"][15] is False          # self_attention reset without the extra parameters
+    assert calls["tiles"]["max_empty"] == 0.9 and calls["train"][14] is None   # monitor reset to None -> train_unet's default
+    assert len(calls["predict"]) == 11                                        # predict.py:146-147 argument list
