@@ -73,6 +73,9 @@ typedef struct {
     int cout_begin, cout_count;          /* produce only channels [cout_begin, cout_begin + cout_count) of the Cout-wide problem
                                             (cout_begin % 16 == 0); 0, 0 = all.  Lets a caller issue e.g. 192 channels as 128 + 64
                                             with a channel-block width that fits each part. */
+    long long wp_img_stride;             /* floats between the packed filter images of consecutive batch images; 0 = one image for all.
+                                            Per-image "filters" are activations: the attention products of SelfAttention run as ONE
+                                            launch over the batch (unet_pack_weights_strided once per image into one buffer). */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */

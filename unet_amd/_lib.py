@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("colsum", vp),
         ("colsumsq", vp),
         ("cout_begin", C.c_int), ("cout_count", C.c_int),
+        ("wp_img_stride", C.c_longlong),
     ]
 
 

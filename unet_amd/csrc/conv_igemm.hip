@@ -51,6 +51,7 @@ struct KArgs {
     int S, OS, TSH, TSW, tiles_y, tiles_x, ntn;
     int nchunks, coutPad, flags, mtiles;
     int n_base, n_end;   // produced-channel range of this launch (unet_conv_desc.cout_begin / cout_count); n_end <= Cout
+    long long wp_stride; // floats between the packed filter images of consecutive batch images (0: one image for all)
     TapSet taps[4];
 };
 
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
 #define LOAD_HALO(chunk_) ld_halo<HIT, NTH>(hreg, goff, xb, (chunk_) * KC, a.Cin4, tid)
 #define STORE_HALO(dst_, chunk_) do { if (has_tail && (chunk_) == a.nchunks - 1) st_halo_tail<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); \
                                        else st_halo<HIT, NTH>(hreg, (dst_), HPIX * 4, tid); } while (0)
-#define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
+#define LOAD_W(widx_, chunk_) ld_w<WIT, NTH, BN>(wreg0, wreg1, a.wp + (size_t)img * a.wp_stride + ((size_t)((widx_) * a.nchunks + (chunk_)) * a.coutPad + n0) * KC, tid)
 #define STORE_W(dst_) st_w<WIT, NTH, BN>(wreg0, wreg1, (dst_), tid)
 
     // ---- MFMA operand addressing ----
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     // operand B: uniform slab pointer + one 32-bit per-lane byte offset (tile n is n * WN * 16 columns = n * WN KiB further),
     // loaded unconditionally (the packed image is padded to the block's 128 columns) so every stage issues exactly N16 loads
     const unsigned lane_b = (unsigned)(((wn * 16 + l15) * KC + 4 * kq) * sizeof(float));
-    const char* wbase = reinterpret_cast<const char*>(a.wp + (size_t)n0 * KC);
+    const char* wbase = reinterpret_cast<const char*>(a.wp + (size_t)img * a.wp_stride + (size_t)n0 * KC);
     const size_t slab_b = (size_t)a.coutPad * KC * sizeof(float);
     constexpr int TSTR = WN * 16 * KC * 4;    // bytes between two of this wave's tiles (<= 2 KiB: fits the immediate offset)
     v4f b0[N16], b1[N16];
@@ -768,6 +769,8 @@ int make_plan(const unet_conv_desc* d, Plan* p) {
     UNET_CHECK_ARG(d->cout_begin >= 0 && (d->cout_begin & 15) == 0 && d->cout_begin + cols <= d->Cout, "conv: bad cout range [%d,+%d) of %d",
                    d->cout_begin, cols, d->Cout);
     k.n_base = d->cout_begin; k.n_end = d->cout_begin + cols;
+    UNET_CHECK_ARG(d->wp_img_stride >= 0 && (d->wp_img_stride & 3) == 0, "conv: bad wp_img_stride");
+    k.wp_stride = d->wp_img_stride;
     k.flags = d->flags;
     k.nchunks = unet::cdiv(d->Cin, KC);
     k.coutPad = unet::roundup(d->Cout, 128);

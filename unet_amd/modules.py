@@ -473,17 +473,21 @@ class SelfAttention(nn.Module):
         qkv = ctx.act(self, "qkv", B, H, W, CQ)
         ops.conv2d(x, wp, qkv, 1)
         T = ctx.act(self, "T", B, H, W, N)
-        wpa = ctx.vec(self, "wp_a", max(ops.lib.unet_pack_weights_size(N, max(c8, C_), 1, 0), ops.lib.unet_pack_weights_size(C_, N, 1, 0)))
+        # per-image operand matrices are packed once per image into one buffer; every product is ONE launch over the batch
+        # (unet_conv_desc.wp_img_stride): O_b = P_b H_b alone would be 96 workgroups per image
+        szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
+               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
+        wpa = ctx.vec(self, "wp_a", B * max(szs))
         img = N * CQ * 4      # bytes per image of qkv
         for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img, CQ, 1, N, c8, wpa)                       # (o=i, r=c) = F_b[i][c]
-            ops.conv2d(TS(qkv.buf[b:b + 1], c8, c8), wpa, TS(T.buf[b:b + 1], 0, N), 1)           # T_b = G_b F_b^T
+            ops.pack_weights_strided(qkv.ptr + b * img, CQ, 1, N, c8, wpa[b * szs[0]:])         # (o=i, r=c) = F_b[i][c]
+        ops.conv2d(TS(qkv.buf, c8, c8), wpa, T, 1, wp_img_stride=szs[0])                         # T_b = G_b F_b^T
         P = ctx.act(self, "P", B, H, W, N)
         ops.row_softmax(T, P)
         O = ctx.act(self, "O", B, H, W, C_)
         for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, 1, CQ, C_, N, wpa)              # (o=c, r=i) = H_b[i][c]
-            ops.conv2d(TS(P.buf[b:b + 1], 0, N), wpa, TS(O.buf[b:b + 1], 0, C_), 1)              # O_b = P_b H_b
+            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, 1, CQ, C_, N, wpa[b * szs[1]:])  # (o=c, r=i) = H_b[i][c]
+        ops.conv2d(P, wpa, O, 1, wp_img_stride=szs[1])                                           # O_b = P_b H_b
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         gvec.copy_(self.gamma.data.expand(C_))
         out = ctx.act(self, "out", B, H, W, C_)
@@ -503,21 +507,25 @@ class SelfAttention(nn.Module):
         ops.affine_act(dout, dO, gvec, zvec)
         dqkv = ctx.act(self, "dqkv", B, H, W, CQ)
         dP = ctx.act(self, "dP", B, H, W, N)
-        wpa = ctx.vec(self, "wp_a", max(ops.lib.unet_pack_weights_size(N, max(c8, C_), 1, 0), ops.lib.unet_pack_weights_size(C_, N, 1, 0)))
+        szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
+               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
+        wpa = ctx.vec(self, "wp_a", B * max(szs))
         tmp = ctx.vec(self, "tmp", N * C_)
         img = N * CQ * 4
         for b in range(B):
+            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, CQ, 1, N, C_, wpa[b * szs[2]:])  # (o=i, r=c) = H_b[i][c]
+        ops.conv2d(dO, wpa, dP, 1, wp_img_stride=szs[2])                                          # dP_b = dO_b H_b^T
+        for b in range(B):
             dO_b, P_b = TS(dO.buf[b:b + 1], 0, C_), TS(P.buf[b:b + 1], 0, N)
-            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, CQ, 1, N, C_, wpa)              # (o=i, r=c) = H_b[i][c]
-            ops.conv2d(dO_b, wpa, TS(dP.buf[b:b + 1], 0, N), 1)                                   # dP_b = dO_b H_b^T
             n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
             ops.conv2d_wgrad(dO_b, P_b, tmp, 1, 1, ctx.workspace(n))                              # dH_b = P_b^T dO_b  -> [N][C]
             ops.copy_slice(TS(tmp[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8, C_))
         ops.row_softmax_bwd(P, dP, dP)                                                            # dT in place
         for b in range(B):
+            ops.pack_weights_strided(qkv.ptr + b * img, 1, CQ, c8, N, wpa[b * szs[3]:])           # (o=c, r=i) = F_b[i][c]
+        ops.conv2d(dP, wpa, TS(dqkv.buf, c8, c8), 1, wp_img_stride=szs[3])                        # dG_b = dT_b F_b
+        for b in range(B):
             dT_b, G_b = TS(dP.buf[b:b + 1], 0, N), TS(qkv.buf[b:b + 1], c8, c8)
-            ops.pack_weights_strided(qkv.ptr + b * img, 1, CQ, c8, N, wpa)                       # (o=c, r=i) = F_b[i][c]
-            ops.conv2d(dT_b, wpa, TS(dqkv.buf[b:b + 1], c8, c8), 1)                               # dG_b = dT_b F_b
             n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
             ops.conv2d_wgrad(G_b, dT_b, tmp, 1, 1, ctx.workspace(n))                              # dF_b = dT_b^T G_b -> [N][c8]
             ops.copy_slice(TS(tmp[:N * c8].view(1, H, W, c8), 0, c8), TS(dqkv.buf[b:b + 1], 0, c8))

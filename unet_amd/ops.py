@@ -172,8 +172,10 @@ def _launch_conv(d: ConvDesc, what: str, alg_flops: float):
 
 
 def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, res=None, mask=None, relu=False,
-           colsum=None, colsumsq=None):
+           colsum=None, colsumsq=None, wp_img_stride: int = 0):
+    """wp_img_stride > 0: image n of the batch uses the packed filter image at wp + n * wp_img_stride floats"""
     d = _conv_desc(x, wp, y, ks, stride, L.CONV_FWD, bias, res, mask, relu, colsum, colsumsq)
+    d.wp_img_stride = wp_img_stride
     _launch_conv(d, "conv2d", 2.0 * y.P * x.C * y.C * ks * ks)
 
 
