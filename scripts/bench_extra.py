@@ -88,3 +88,7 @@ def cfg5_rate(side=20000, size=512, overlap=0.2, b=16):
 
 
 if "cfg5" in which: cfg5_rate()
+
+if "default" in which:     # the reference's shipped configuration (params_and_main.py): 3-band 400x400 tiles, 3 classes, batch 4, SA on
+    train_rate("xresnet34", 3, 3, 400, 4, sa=True, steps=10)
+    train_rate("xresnet34", 3, 3, 400, 16, sa=True, steps=5)
