@@ -70,3 +70,50 @@ def test_two_ranks_one_gpu_gloo():
     for p in procs:
         p.join(timeout=120)
     assert [r[:3] for r in res] == [(0, True, True), (1, True, True)], res
+
+
+def _predict_worker(rank, world, port, pkl, tiles_dir, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      UNET_DIST_BACKEND="gloo", UNET_FORCE_DEVICE="0")
+    import torch.distributed as dist
+    import predict as P
+    out = P.save_predictions(pkl, tiles_dir, False, merge=True, AOI="ddp", year=None, validation_vision=False, batch_size=2)
+    q.put((rank, None if out is None else str(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharded_prediction_two_ranks(tmp_path):
+    """BASELINE configs[4] partitioning (tile i -> rank i mod world, partial sum-of-probabilities mosaics all-reduced): the merged
+    mask written by rank 0 of a 2-rank run equals the single-process result bit for bit"""
+    import numpy as np
+    import predict as P
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, DiceMulti, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.tiffio import read_tiff, write_tiff
+    torch.manual_seed(3)
+    model = HipDynamicUnet("xresnet18", 4, 3, (64, 64), device="cuda:0")
+    dls = DataLoaders(TileDataset([np.zeros((4, 64, 64), np.uint8)], None, "int8"), None, 1, device="cuda:0", vocab=["a", "b", "c"])
+    learn = Learner(dls, model, loss_func=CrossEntropyLossFlat(axis=1), metrics=[DiceMulti()], path=tmp_path)
+    pkl = tmp_path / "m.pkl"
+    learn.export(pkl)
+    tiles = tmp_path / "set" / "tiles"
+    tiles.mkdir(parents=True)
+    g = np.random.default_rng(4)
+    for i in range(5):                                   # 5 tiles, 50 % overlap along x: ranks get 3 + 2 tiles
+        write_tiff(tiles / f"p{i}.tif", g.integers(0, 255, (4, 64, 64)).astype(np.uint8),
+                   geotransform=(100.0 + i * 32 * 0.5, 0.5, 0.0, 900.0, 0.0, -0.5))
+    single = P.save_predictions(pkl, tiles, False, merge=True, AOI="single", year=None, validation_vision=False, batch_size=2)
+    ref, _ = read_tiff(single)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, 2, port, str(pkl), str(tiles), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[1] is None and res[0] is not None
+    got, meta = read_tiff(res[0])
+    assert got.shape == ref.shape == (64, 192) and np.array_equal(got, ref)
