@@ -44,10 +44,10 @@ shutil.copy(src / "bench.json", dst / f"{tag}_bench.json")
 stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))[0]
 shutil.copy(stats, dst / f"{tag}_bench_kernel_stats.csv")
 
-fetch, write, sq, sqdur = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), durations("pmc_sq")
+fetch, write, sq, sqdur, lds = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), durations("pmc_sq"), pmc("pmc_lds")
 traffic = {}
 rows = []
-for k in sorted(set(fetch) | set(write) | set(sq)):
+for k in sorted(set(fetch) | set(write) | set(sq) | set(lds)):
     fa = fetch[k].get("FETCH_SIZE", [])
     wa = write[k].get("WRITE_SIZE", [])
     row = {"kernel": k, "launches": len(fa) or len(wa)}
@@ -64,8 +64,14 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         d = sqdur.get(k)
         if d:
             row["eff_clock_ghz"] = round(sum(sq[k]["GRBM_GUI_ACTIVE"]) / 8 / sum(d), 3)
+    if k in lds and lds[k].get("SQ_BUSY_CU_CYCLES"):
+        act = sum(lds[k]["SQ_LDS_IDX_ACTIVE"])
+        row["lds_conflict_frac"] = round(sum(lds[k]["SQ_LDS_BANK_CONFLICT"]) / act, 4) if act else 0.0
+        # SQ_WAVE_CYCLES counts in units of 4 cycles: wave-quad-cycles / CU-busy cycles = resident waves per SIMD
+        row["waves_per_simd"] = round(sum(lds[k]["SQ_WAVE_CYCLES"]) / sum(lds[k]["SQ_BUSY_CU_CYCLES"]), 2)
     rows.append(row)
-cols = ["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch", "mfma_busy_frac", "eff_clock_ghz"]
+cols = ["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch", "mfma_busy_frac", "eff_clock_ghz",
+        "lds_conflict_frac", "waves_per_simd"]
 with open(dst / f"{tag}_pmc_summary.csv", "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=cols)
     w.writeheader()
