@@ -36,8 +36,34 @@ def synth(batch, seed, device):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(sample_tiles: int = 1, iters: int = 2):
-    """The reference's path restated on PyTorch-CPU (oracle/unet_oracle.py), same step, bounded sample."""
+def _cpu_step_rate(O, arch, n_in, n_cls, size, tiles, iters, cores):
+    torch.manual_seed(0)
+    m = O.DynamicUnet(arch, n_in, n_cls, (size, size))
+    m.train()
+    opt = O.FastaiAdam(O.xresnet_split(m), list(O.even_mults(1e-5, 1e-4, 3)), no_wd=O.bn_bias_params(m))
+    loss_fn = O.CrossEntropyLossFlat(weight=torch.full((n_cls,), 1.0 / n_cls))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randint(0, 256, (tiles, n_in, size, size), generator=g).float() / 255
+    y = torch.randint(0, n_cls, (tiles, size, size), generator=g)
+
+    def step():
+        opt.zero_grad()
+        loss_fn(m(x), y).backward()
+        opt.step()
+
+    t0 = time.perf_counter(); step()  # warm-up
+    print(f"[bench] cpu_baseline {arch} {n_in}x{size}x{size} B={tiles}: warm-up {time.perf_counter() - t0:.1f}s on {cores} threads",
+          file=sys.stderr, flush=True)
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline iter {ts[-1]:.1f}s", file=sys.stderr, flush=True)
+    return tiles / sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline(sample_tiles: int = 2, iters: int = 3):
+    """The reference's path restated on PyTorch-CPU (oracle/unet_oracle.py), same step, bounded sample (1 warm-up
+    + 3 timed iterations; cfg2 geometry for the like-for-like tiles/s, plus BASELINE configs[0] = cfg1 at its batch 2)."""
     from oracle import unet_oracle as O
     # the GPU box gives one GPU's job a 16-core share; os.cpu_count() reports the whole host and would
     # oversubscribe oneDNN by an order of magnitude
@@ -47,29 +73,42 @@ def cpu_baseline(sample_tiles: int = 1, iters: int = 2):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("UNET_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    m = O.DynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE))
-    m.train()
-    opt = O.FastaiAdam(O.xresnet_split(m), list(O.even_mults(1e-5, 1e-4, 3)), no_wd=O.bn_bias_params(m))
-    loss_fn = O.CrossEntropyLossFlat(weight=torch.full((N_CLS,), 1.0 / N_CLS))
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randint(0, 256, (sample_tiles, N_IN, SIZE, SIZE), generator=g).float() / 255
-    y = torch.randint(0, N_CLS, (sample_tiles, SIZE, SIZE), generator=g)
+    rate = _cpu_step_rate(O, ARCH, N_IN, N_CLS, SIZE, sample_tiles, iters, cores)
+    cfg1 = _cpu_step_rate(O, "xresnet18", 3, 2, 256, 2, iters, cores)
+    return {"value": round(rate, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_tiles} tile(s) of the same 4x512x512 xresnet34 step (fwd + weighted CE + bwd + fastai-Adam), fp32, "
+                      f"1 warm-up + {iters} timed, median",
+            "cfg1_value": round(cfg1, 4),
+            "cfg1_sample": f"BASELINE configs[0]: xresnet18 3->2, 256x256, batch 2, same step, 1 warm-up + {iters} timed, median (256x256 tiles/s)"}
 
-    def step():
-        opt.zero_grad()
-        loss_fn(m(x), y).backward()
-        opt.step()
 
-    t0 = time.perf_counter(); step()  # warm-up
-    print(f"[bench] cpu_baseline warm-up {time.perf_counter() - t0:.1f}s on {cores} threads", file=sys.stderr, flush=True)
-    ts = []
-    for _ in range(iters):
-        t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
-        print(f"[bench] cpu_baseline iter {ts[-1]:.1f}s", file=sys.stderr, flush=True)
-    t = sorted(ts)[len(ts) // 2]
-    return {"value": round(sample_tiles / t, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample_tiles} tile(s) of the same 4x512x512 xresnet34 step, fp32, 1 warm-up + {iters} timed, median"}
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (the contract's env: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*) BEFORE this process has touched the GPU, wait for them, return the worst exit code.  No exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    rc, live = 0, list(procs)
+    while live:                                   # a rank that dies must not leave its peers waiting in a collective forever
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for q in live:
+                    q.terminate()                 # exactly the children started above
+    return rc
 
 
 def main():
@@ -81,9 +120,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # this process never initialises the GPU
+    if int(os.environ["WORLD_SIZE"] if "WORLD_SIZE" in os.environ else 1) != args.gpus:
+        world = int(os.environ["WORLD_SIZE"])
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or run "
+                         f"`python bench.py --gpus {args.gpus}` without WORLD_SIZE set and let it start the ranks itself")
     from unet_amd.distributed import broadcast_parameters, init_from_env
     rank, local_rank, world = init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}: launch with torch.distributed.run"
     if os.environ.get("UNET_FORCE_DEVICE") is not None:      # rehearsal of the N>1 path on a single GPU (with UNET_DIST_BACKEND=gloo)
         local_rank = int(os.environ["UNET_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
@@ -136,6 +181,13 @@ def main():
         dt = float(t.item())
     _ops.CONV_PROBE = None
     ps = probe.summary()
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": f"cuda:{local_rank}", "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    devices = [me]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
 
     if rank == 0:
         tiles = args.batch * world * args.steps
@@ -164,6 +216,10 @@ def main():
                          "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
                          "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)},
             "hbm_bytes_allocated": model.memory_bytes(),
+            # world size the collective library itself reports (1 = no process group) and the device every rank ran on
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "devices": devices,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -41,8 +41,9 @@ int unet_abi_version(void);
 const char* unet_last_error(void);
 
 /* ------------------------------------------------------------------ conv --
- * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC,
- * LDS-staged input halo tile + filter slab, no im2col.
+ * Implicit-GEMM convolution on fp32 MFMA, NHWC, no im2col.  Default instruction v_mfma_f32_16x16x4_f32: LDS-staged input halo
+ * tile, packed filter tiles global -> VGPR (MFMA operand order); v_mfma_f32_32x32x2_f32 with an LDS filter slab is kept
+ * behind unet_set_mfma_shape(32).
  * Replaces: every nn.Conv2d of fastai ConvLayer (layers.py) in XResNet
  * (vision/models/xresnet.py), DynamicUnet.middle_conv / UnetBlock.conv1,conv2 /
  * PixelShuffle_ICNR 1x1 / final ResBlock / head (vision/models/unet.py), as

@@ -11,6 +11,13 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on the CPU: use this job's core share, not the host's core count (a GPU box reports the whole host)
+    try:
+        import torch
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(n, int(os.environ.get("UNET_TEST_THREADS", "16")))))
+    except Exception:  # pragma: no cover
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

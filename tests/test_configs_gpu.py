@@ -1,0 +1,354 @@
+"""Every BASELINE.json configuration at ITS OWN size against the CPU oracle, with north_star's literal bar
+("per-pixel class logits within 1e-3 fp32, argmax masks bit-exact").
+
+Truth for everything that two correct fp32 evaluations can disagree on (ReLU / max-pool sign flips of ~0 pre-activations in a
+gradient, numerical ties of the two best logits in a mask) is an fp64 run of the SAME oracle: the HIP path must be as close
+to fp64 as the fp32 CPU oracle is (or within the stated absolute bar), tensor by tensor / pixel by pixel.
+
+  cfg2 (configs[1]): xresnet34 4->5, 512x512 -- full training step, EVERY parameter gradient per tensor (the narrow weight-gradient
+        kernels wgrad_flat<7,5>/<6,7> and every conv launch at their real shapes); default-init tile with logits O(1):
+        |dlogit| < 1e-3 absolute and identical masks;
+  cfg1 (configs[0]): xresnet18 3->2, 256x256, batch 2 training step;
+  cfg4 (configs[3]): xresnet50 8->10, ONE 1024x1024 tile, eval logits + mask; training step properties at that size;
+  shipped default (reference params_and_main.py:36,83): 3-band 400x400 tiles, 3 classes, self-attention ON;
+  SelfAttention at cfg2 size (4096 positions).
+Reference call sites: train.py:247-250 (fit_one_cycle step), predict.py:193-203,232 (probabilities -> argmax).
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as O  # noqa: E402  (checker)
+
+
+def _rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-300)).item()
+
+
+def _hip_from(ref, arch, n_in, n_out, size, sa=False):
+    from unet_amd.model import HipDynamicUnet
+    model = HipDynamicUnet(arch, n_in, n_out, size, self_attention=sa)
+    r = model.load_state_dict(ref.state_dict())
+    assert not r.missing_keys and not r.unexpected_keys
+    return model
+
+
+def _normalise_head(ref, x, target=4.0):
+    """scale the 1x1 head so that the eval logits are O(1) (max |z| = target): north_star's 1e-3 is an absolute bar on O(1) logits"""
+    ref.eval()
+    with torch.no_grad():
+        s = ref(x).abs().max().item() / target
+        head = ref.layers[-1][0]
+        head.weight.div_(s)
+        head.bias.div_(s)
+
+
+def _assert_masks(am_hip, z_ref32, z_ref64, err_hip, err_cpu, what):
+    """masks must be identical; a pixel may differ only where the fp64 decision margin is below the fp32 evaluation error of
+    either implementation (undecidable in fp32), and the HIP mask must then not be further from fp64 than the fp32 oracle's"""
+    am32, am64 = z_ref32.argmax(1), z_ref64.argmax(1)
+    diff = am_hip != am32
+    n = int(diff.sum())
+    if n == 0:
+        return 0
+    top2 = z_ref64.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])
+    assert bool((gap[diff] <= 2.0 * max(err_hip, err_cpu)).all()), f"{what}: a mask pixel differs where fp64 is decided (gap {gap[diff].max():.2e})"
+    wrong_hip, wrong_cpu = int((am_hip != am64).sum()), int((am32 != am64).sum())
+    assert wrong_hip <= wrong_cpu + n, (what, wrong_hip, wrong_cpu)
+    assert n <= 4, f"{what}: {n} tie pixels differ"
+    return n
+
+
+def _grad_table(model, ref, ref64):
+    rows = []
+    for (n, p), (n2, q), (_, r) in zip(model.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        assert n == n2
+        rows.append((n, _rel_l2(p.grad.cpu(), r.grad), _rel_l2(q.grad, r.grad), float(r.grad.abs().max())))
+    return rows
+
+
+def _check_grads(rows, tail_from, tail_bar, what):
+    """rows: (name, e_hip, e_cpu32, scale) against fp64.  Decoder tail (top-level child >= tail_from: hundreds of thousands of
+    pixels average out single ReLU flips): e_hip <= tail_bar.  Everywhere: e_hip <= max(tail_bar, 4 x e_cpu32) -- the HIP path may
+    not be further from fp64 than a small multiple of what the fp32 CPU oracle itself manages on that tensor."""
+    worst_tail, worst_rel = ("", 0.0), ("", 0.0, 0.0)
+    for n, eh, ec, sc in rows:
+        if sc == 0.0:
+            continue
+        top = int(n.split(".")[1])
+        if top >= tail_from and eh > worst_tail[1]:
+            worst_tail = (n, eh)
+        if eh > max(tail_bar, 4.0 * ec) and eh / max(ec, 1e-30) > worst_rel[1] / max(worst_rel[2], 1e-30):
+            worst_rel = (n, eh, ec)
+    print(f"{what}: worst tail {worst_tail}; median e_hip {sorted(r[1] for r in rows)[len(rows) // 2]:.2e} "
+          f"median e_cpu32 {sorted(r[2] for r in rows)[len(rows) // 2]:.2e}; max e_hip {max(r[1] for r in rows):.2e}")
+    assert worst_tail[1] <= tail_bar, (what, worst_tail)
+    assert worst_rel[0] == "", (what, worst_rel)
+
+
+# ------------------------------------------------------------------------------------------------ cfg2
+
+def test_cfg2_training_step_every_gradient_against_the_oracle():
+    """2 x (4 x 512 x 512), xresnet34, 5 classes, weighted CE, train mode (batch statistics), BatchNorm parameters randomised
+    so that no path is trivially zero.  Every one of the 218 parameter gradients per tensor against fp64."""
+    torch.manual_seed(0)
+    ref = O.DynamicUnet("xresnet34", 4, 5, (512, 512))
+    O.randomize_bn_and_zero_gammas(ref, seed=1)
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512))
+    ref64 = copy.deepcopy(ref).double()
+    x, y = O.synthetic_batch(2, 4, 512, 512, 5)
+    w = torch.tensor([0.1, 0.3, 0.2, 0.25, 0.15])
+    ref.train(); ref64.train(); model.train()
+    z32 = ref(x)
+    l32 = O.CrossEntropyLossFlat(weight=w)(z32, y)
+    l32.backward()
+    z64 = ref64(x.double())
+    l64 = O.CrossEntropyLossFlat(weight=w.double())(z64, y)
+    l64.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    z = model.logits_ts().view().permute(0, 3, 1, 2).cpu()
+    scale = z64.abs().max().item()
+    eh, ec = (z.double() - z64.detach()).abs().max().item(), (z32.detach().double() - z64.detach()).abs().max().item()
+    print(f"train-mode logits: scale {scale:.2f} err hip {eh:.2e} cpu32 {ec:.2e}; loss hip {loss.item():.7f} f64 {l64.item():.7f}")
+    assert eh <= max(2e-6 * scale, 3.0 * ec)
+    assert abs(loss.item() - l64.item()) <= 2e-6 * abs(l64.item())
+    rows = _grad_table(model, ref, ref64)
+    assert len(rows) == 218
+    _check_grads(rows, tail_from=7, tail_bar=1e-3, what="cfg2 B=2")
+    # the layers served by the narrow weight-gradient kernels, by name: final ResBlock 100->100 pair, last UnetBlock 192->96 / 96->96
+    named = {n: (eh, ec) for n, eh, ec, _ in rows}
+    for n in ("layers.11.convpath.0.0.weight", "layers.11.convpath.1.0.weight", "layers.7.conv1.0.weight", "layers.7.conv2.0.weight"):
+        assert named[n][0] <= 1e-3, (n, named[n])
+    # BatchNorm running statistics moved by the batch statistics
+    for (n, b), (_, b2) in zip(model.named_buffers(), ref64.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert (b.cpu().double() - b2).abs().max().item() <= 1e-5 * (1.0 + b2.abs().max().item()), n
+
+
+def test_cfg2_default_init_tile_literal_bar():
+    """The state bench.py trains from: fastai's default initialisation (BatchZero gammas, ICNR shuffle convs, kaiming decoder).
+    One train-mode forward on a batch of 2 (moves the running statistics exactly as the first training step does), then the eval
+    forward of one 512 x 512 tile: |dlogit| < 1e-3 ABSOLUTE on O(1) logits, probabilities within 1e-3, identical masks."""
+    torch.manual_seed(11)
+    ref = O.DynamicUnet("xresnet34", 4, 5, (512, 512))
+    x, _ = O.synthetic_batch(2, 4, 512, 512, 5, seed=77)
+    _normalise_head(ref, x[:1])
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512))
+    ref64 = copy.deepcopy(ref).double()
+    ref.train(); ref64.train(); model.train()
+    with torch.no_grad():
+        zt32, zt64 = ref(x), ref64(x.double())
+        zt = model(x.cuda()).cpu()
+    assert (zt - zt32).abs().max().item() < 1e-3 and (zt.double() - zt64).abs().max().item() < 1e-3
+    ref.eval(); ref64.eval(); model.eval()
+    with torch.no_grad():
+        z32, z64 = ref(x[:1]), ref64(x[:1].double())
+        probs, amax = model.predict_probs(x[:1].cuda())
+        z = model(x[:1].cuda()).cpu()
+    scale = z64.abs().max().item()
+    err_hip, err_cpu = (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
+    print(f"default init eval: logit scale {scale:.3f}, |hip-cpu32| {(z - z32).abs().max().item():.2e}, |hip-f64| {err_hip:.2e}, |cpu32-f64| {err_cpu:.2e}")
+    assert 0.5 < scale < 50.0
+    assert (z - z32).abs().max().item() < 1e-3 and err_hip < 1e-3
+    assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() < 1e-3
+    n = _assert_masks(amax.cpu(), z32, z64, err_hip, err_cpu, "default init")
+    print("default init: differing (fp64-adjudicated tie) pixels:", n)
+
+
+def test_cfg2_randomised_bn_tile_literal_bar():
+    """the BatchNorm-randomised fixture of test_fullsize_gpu with the head normalised to O(1) logits: absolute 1e-3, masks
+    adjudicated by fp64"""
+    torch.manual_seed(0)
+    ref = O.DynamicUnet("xresnet34", 4, 5, (512, 512))
+    O.randomize_bn_and_zero_gammas(ref, seed=1)
+    x, _ = O.synthetic_batch(4, 4, 512, 512, 5)
+    x = x[3:4]
+    _normalise_head(ref, x)
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512))
+    ref64 = copy.deepcopy(ref).double()
+    ref.eval(); ref64.eval(); model.eval()
+    with torch.no_grad():
+        z32, z64 = ref(x), ref64(x.double())
+        probs, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err_hip, err_cpu = (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
+    print(f"randomised BN eval: |hip-cpu32| {(z - z32).abs().max().item():.2e}, |hip-f64| {err_hip:.2e}, |cpu32-f64| {err_cpu:.2e}")
+    assert (z - z32).abs().max().item() < 1e-3 and err_hip < 1e-3
+    assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() < 1e-3
+    _assert_masks(amax.cpu(), z32, z64, err_hip, err_cpu, "randomised BN")
+
+
+# ------------------------------------------------------------------------------------------------ cfg1
+
+def test_cfg1_xresnet18_rgb_256_batch2_training_step():
+    """configs[0]: 3-channel 256 x 256 tiles, xresnet18, 2 classes, batch 2 (the reference's own CPU-runnable case)"""
+    torch.manual_seed(5)
+    ref = O.DynamicUnet("xresnet18", 3, 2, (256, 256))
+    O.randomize_bn_and_zero_gammas(ref, seed=6)
+    model = _hip_from(ref, "xresnet18", 3, 2, (256, 256))
+    ref64 = copy.deepcopy(ref).double()
+    x, y = O.synthetic_batch(2, 3, 256, 256, 2)
+    w = torch.tensor([0.5, 0.5])
+    ref.train(); ref64.train(); model.train()
+    O.CrossEntropyLossFlat(weight=w)(ref(x), y).backward()
+    z64 = ref64(x.double())
+    l64 = O.CrossEntropyLossFlat(weight=w.double())(z64, y)
+    l64.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    z = model.logits_ts().view().permute(0, 3, 1, 2).cpu()
+    assert (z.double() - z64.detach()).abs().max().item() < 1e-3 * max(1.0, z64.abs().max().item() / 8)
+    assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item())
+    _check_grads(_grad_table(model, ref, ref64), tail_from=7, tail_bar=2e-3, what="cfg1 B=2")
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = model.predict_probs(x.cuda())
+        ze = model(x.cuda()).cpu()
+    assert (ze - z32).abs().max().item() < 1e-3 * max(1.0, z32.abs().max().item() / 8)
+    diff = amax.cpu() != z32.argmax(1)
+    top2 = z32.topk(2, dim=1).values
+    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 1e-4).all())
+
+
+# ------------------------------------------------------------------------------------------------ cfg4
+
+@pytest.fixture(scope="module")
+def cfg4():
+    torch.manual_seed(2)
+    ref = O.DynamicUnet("xresnet50", 8, 10, (1024, 1024))
+    O.randomize_bn_and_zero_gammas(ref, seed=3)
+    x, y = O.synthetic_batch(1, 8, 1024, 1024, 10)
+    _normalise_head(ref, x[:, :, :256, :256])
+    model = _hip_from(ref, "xresnet50", 8, 10, (1024, 1024))
+    return ref, model, x, y
+
+
+def test_cfg4_one_1024_tile_eval_against_the_oracle(cfg4):
+    """configs[3]: 8-band 1024 x 1024 tile, xresnet50, 10 classes, fp32: 2048-channel bottleneck at 32 x 32, 392-wide final
+    ResBlock at 1024 x 1024 (3.3 TFLOP), 10.15 TFLOP forward"""
+    ref, model, x, _ = cfg4
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        probs, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err, scale = (z - z32).abs().max().item(), z32.abs().max().item()
+    print(f"cfg4 eval: logit scale {scale:.2f}, |hip-cpu32| {err:.2e}")
+    assert err < 1e-3 * max(1.0, scale / 8.0)
+    assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() < 1e-3
+    diff = amax.cpu() != z32.argmax(1)
+    top2 = z32.topk(2, dim=1).values
+    assert int(diff.sum()) <= 8 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all()), int(diff.sum())
+
+
+def test_cfg4_training_step_properties_at_full_size(cfg4):
+    """one training step of the 1024 x 1024 xresnet50 tile: reproducible bit for bit, the two conv kernel families and the two
+    3x3 weight-gradient families agree on the flat gradient, and the loss equals the oracle's train-mode loss"""
+    from unet_amd._lib import lib
+    ref, model, x, y = cfg4
+    w = torch.full((10,), 0.1)
+    xc, yc, wc = x.cuda(), y.cuda(), w.cuda()
+
+    def step():
+        model.train()
+        model.flat_grad.zero_()
+        l = model.forward_loss_backward(xc, yc, wc)
+        torch.cuda.synchronize()
+        return float(l.item()), model.flat_grad.clone()
+
+    l0, g0 = step()
+    l0b, g0b = step()
+    assert l0 == l0b and torch.equal(g0, g0b)
+    try:
+        lib.unet_set_mfma_shape(32)
+        l1, g1 = step()
+    finally:
+        lib.unet_set_mfma_shape(16)
+    n0 = g0.double().norm().item()
+    assert torch.isfinite(g0).all() and n0 > 0
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and (g1 - g0).double().norm().item() / n0 < 5e-3
+    ref.train()
+    with torch.no_grad():
+        l_ref = O.CrossEntropyLossFlat(weight=w)(ref(x), y).item()
+    assert abs(l0 - l_ref) <= 2e-5 * abs(l_ref), (l0, l_ref)
+
+
+# ------------------------------------------------------------------------------------------------ shipped default / SA
+
+def _sa_pair(arch, n_in, n_out, size, seed):
+    torch.manual_seed(seed)
+    ref = O.DynamicUnet(arch, n_in, n_out, size, self_attention=True)
+    O.randomize_bn_and_zero_gammas(ref, seed=seed + 1)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, O.SelfAttention):
+                m.gamma.fill_(0.7)          # gamma is 0 at init: the attention branch would not reach the logits
+    return ref
+
+
+def test_shipped_default_400px_rgb_3class_self_attention_on():
+    """reference params_and_main.py:36,49,83,101: patch_size 400, 3 bands, 3 classes, xresnet34, self_attention = True, batch 4
+    (here 2): SelfAttention(384) on the 50 x 50 stage (2500 positions), nearest-resize paths (400 is not divisible by 32)"""
+    ref = _sa_pair("xresnet34", 3, 3, (400, 400), 21)
+    x, y = O.synthetic_batch(2, 3, 400, 400, 3)
+    _normalise_head(ref, x[:1])
+    model = _hip_from(ref, "xresnet34", 3, 3, (400, 400), sa=True)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err = (z - z32).abs().max().item()
+    print(f"shipped default eval: |hip-cpu32| {err:.2e} at scale {z32.abs().max().item():.2f}")
+    assert err < 1e-3
+    diff = amax.cpu() != z32.argmax(1)
+    top2 = z32.topk(2, dim=1).values
+    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
+    # training step: loss + every gradient against fp64 (incl. gamma and the spectral-normed projections)
+    ref64 = copy.deepcopy(ref).double()
+    ref.train(); ref64.train(); model.train()
+    w = torch.tensor([0.2, 0.5, 0.3])
+    O.CrossEntropyLossFlat(weight=w)(ref(x), y).backward()
+    l64 = O.CrossEntropyLossFlat(weight=w.double())(ref64(x.double()), y)
+    l64.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item())
+    rows = _grad_table(model, ref, ref64)
+    _check_grads(rows, tail_from=7, tail_bar=2e-3, what="shipped default")
+    sa_rows = [r for r in rows if ".conv2.2." in r[0]]
+    assert len(sa_rows) == 4 and all(r[1] <= max(2e-3, 4 * r[2]) for r in sa_rows), sa_rows
+
+
+def test_self_attention_at_cfg2_size_4096_positions():
+    """cfg2 geometry with self_attention = True: SelfAttention(384) on the 64 x 64 stage = 4096 positions (64 MiB of attention
+    weights per tile in the oracle)"""
+    ref = _sa_pair("xresnet34", 4, 5, (512, 512), 31)
+    x, y = O.synthetic_batch(1, 4, 512, 512, 5)
+    _normalise_head(ref, x)
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512), sa=True)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err = (z - z32).abs().max().item()
+    print(f"SA 4096 eval: |hip-cpu32| {err:.2e}")
+    assert err < 1e-3
+    diff = amax.cpu() != z32.argmax(1)
+    top2 = z32.topk(2, dim=1).values
+    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
+    ref.train(); model.train()
+    O.CrossEntropyLossFlat()(ref(x), y).backward()
+    model.forward_loss_backward(x.cuda(), y.cuda(), None)
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if ".conv2.2." in n:           # gamma, query / key / value weight_orig
+            e = _rel_l2(p.grad.cpu(), q.grad)
+            assert e < 2e-3, (n, e)

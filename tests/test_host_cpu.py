@@ -177,3 +177,31 @@ def test_params_and_main_surface(monkeypatch):
     assert len(calls["train"]) == 25 and calls["train"][15] is False          # self_attention reset without the extra parameters
     assert calls["tiles"]["max_empty"] == 0.9 and calls["train"][14] is None   # monitor reset to None -> train_unet's default
     assert len(calls["predict"]) == 11                                        # predict.py:146-147 argument list
+
+
+def test_bench_starts_its_own_ranks_and_rejects_a_mismatched_world(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N fresh rank processes with the contract's environment before touching
+    the GPU; a WORLD_SIZE that contradicts --gpus is an error, not a silent 1-GPU run (VERDICT r1 / ADVICE r1)"""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_mod", root / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    stub = tmp_path / "rank.py"
+    stub.write_text("import os, sys\n"
+                    "open(os.path.join(sys.argv[-1], 'r' + os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in "
+                    "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR')) + ' ' + str('MASTER_PORT' in os.environ))\n"
+                    "sys.exit(3 if os.environ['RANK'] == '2' and os.environ.get('FAIL') else 0)\n")
+    monkeypatch.setattr(b, "__file__", str(stub))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", str(tmp_path)])
+    assert b.spawn_ranks(3) == 0
+    assert sorted(p.name for p in tmp_path.glob("r?")) == ["r0", "r1", "r2"]
+    assert (tmp_path / "r1").read_text() == "1 1 3 127.0.0.1 True"
+    monkeypatch.setenv("FAIL", "1")
+    assert b.spawn_ranks(3) == 3
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], env=dict(__import__("os").environ, WORLD_SIZE="2"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr

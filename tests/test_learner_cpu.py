@@ -150,3 +150,19 @@ def test_tile_dataset_float_targets_for_regression():
     assert y.dtype == torch.float32 and torch.allclose(y, torch.from_numpy(m))
     _, y2 = L.TileDataset([x], [m], "int8")[0]
     assert y2.dtype == torch.int64
+
+
+def test_dataloader_rank_sharding():
+    """tile-DDP: same permutation on every rank, disjoint strided shards, equal step counts for the (shuffled) training loader,
+    every item exactly once for a validation loader"""
+    imgs = [np.full((1, 4, 4), i, dtype=np.uint8) for i in range(11)]
+    masks = [np.full((4, 4), i, dtype=np.uint8) for i in range(11)]
+    ds = L.TileDataset(imgs, masks, "int8")
+    seen = []
+    for r in range(2):
+        dl = L.DataLoader(ds, 2, True, "cpu", drop_last=True, seed=5).shard(r, 2)
+        assert len(dl) == 2                       # 11 // 2 = 5 items per rank -> 2 full batches
+        seen.append([int(v) for _, yb in dl for v in yb[:, 0, 0]])
+    assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
+    val = [sorted(int(v) for _, yb in L.DataLoader(ds, 4, False, "cpu").shard(r, 3) for v in yb[:, 0, 0]) for r in range(3)]
+    assert sorted(sum(val, [])) == list(range(11)) and val[0] == [0, 3, 6, 9]

@@ -1,0 +1,207 @@
+"""Learner-surface pieces on the device: DiceMulti and the flip augmentation against the oracle / the reference's slicing rule,
+fastai-layout model files, and the tile-DDP loss exchange (two ranks sharing one GPU over gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as O  # noqa: E402  (checker)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_dice_multi_on_device_matches_oracle():
+    """fastai DiceMulti(axis=1) (reference train.py:196): counters accumulated on the GPU over several validation batches,
+    classes absent from a batch, a class absent from the whole set (nan skipped)"""
+    from unet_amd.learner import DiceMulti
+    g = torch.Generator().manual_seed(0)
+    a, b = DiceMulti(), O.DiceMulti()
+    for i in range(4):
+        logits = torch.randn(3, 6, 40, 56, generator=g)
+        logits[:, 5] = -50.0                                   # class 5 is never predicted ...
+        targ = torch.randint(0, 5 if i else 3, (3, 40, 56), generator=g)   # ... and never present
+        a.accumulate_argmax(logits.cuda().argmax(1), targ.cuda(), 6)
+        b.accumulate(logits, targ)
+    assert a.inter.is_cuda and abs(a.value - b.value) < 1e-12
+
+
+def test_flip_augment_on_device_follows_the_reference_slicing_rule():
+    """utils.py:239-295: only the first n_transform - B images of a batch are candidates (python slice semantics), each flipped
+    horizontally / vertically with p = 0.5 (params_and_main.py:105-108); image and mask move together; n_transform_imgs = 1
+    (the shipped default) touches nothing (quirk Q7)"""
+    from unet_amd.learner import FlipAugment
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(8, 4, 16, 12, generator=g).cuda()
+    y = torch.randint(0, 3, (8, 16, 12), generator=g).cuda()
+    x0, y0 = x.clone(), y.clone()
+    xa, ya = FlipAugment(n_transform_imgs=1.0)(x.clone(), y.clone())
+    assert torch.equal(xa, x0) and torch.equal(ya, y0)
+    aug = FlipAugment(n_transform_imgs=0.5, seed=3)
+    xa, ya = aug(x.clone(), y.clone())
+    assert xa.is_cuda
+    # ceil(8 * 0.5) - 8 = -4: images 0..3 are candidates, 4..7 never change
+    assert torch.equal(xa[4:], x0[4:]) and torch.equal(ya[4:], y0[4:])
+    seen = set()
+    for i in range(4):
+        for fh in (False, True):
+            for fv in (False, True):
+                xe, ye = x0[i], y0[i]
+                if fh:
+                    xe, ye = xe.flip(-1), ye.flip(-1)
+                if fv:
+                    xe, ye = xe.flip(-2), ye.flip(-2)
+                if torch.equal(xa[i], xe) and torch.equal(ya[i], ye):
+                    seen.add((i, fh, fv))
+    assert {s[0] for s in seen} == {0, 1, 2, 3}          # every candidate is one of the four flip states, image and mask alike
+    # statistics of the flip decisions over many draws: p_h = p_v = 0.5
+    aug = FlipAugment(n_transform_imgs=0.01, seed=5)     # ceil(0.08) - 8 = -7: the first image only
+    nh = nv = 0
+    for _ in range(400):
+        xa, _ = aug(x0.clone(), y0.clone())
+        nh += int(torch.equal(xa[0], x0[0].flip(-1)) or torch.equal(xa[0], x0[0].flip(-1).flip(-2)))
+        nv += int(torch.equal(xa[0], x0[0].flip(-2)) or torch.equal(xa[0], x0[0].flip(-1).flip(-2)))
+    assert 150 < nh < 250 and 150 < nv < 250
+
+
+def _tiny_learner(tmp_path, n_cls=3):
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, DiceMulti, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    g = np.random.default_rng(0)
+    imgs = [g.integers(0, 255, (4, 64, 64)).astype(np.uint8) for _ in range(4)]
+    masks = [g.integers(0, n_cls, (64, 64)).astype(np.uint8) for _ in range(4)]
+    model = HipDynamicUnet("xresnet18", 4, n_cls, (64, 64))
+    dls = DataLoaders(TileDataset(imgs, masks, "int8"), TileDataset(imgs[:2], masks[:2], "int8"), 2, vocab=list("abc"))
+    return Learner(dls, model, loss_func=CrossEntropyLossFlat(axis=1), metrics=[DiceMulti()], path=tmp_path)
+
+
+def test_model_files_use_fastai_layouts(tmp_path):
+    """fastai save_model / load_model: with_opt=False (SaveModelCallback) writes the BARE state_dict, with_opt=True writes
+    {'model','opt'}; load accepts both, and a foreign optimizer state (as written by fastai's own Adam) is skipped with a warning"""
+    learn = _tiny_learner(tmp_path)
+    learn.create_opt()
+    learn.save("bare")
+    sd = torch.load(tmp_path / "models" / "bare.pth")
+    assert "model" not in sd and "layers.0.0.0.weight" in sd
+    learn.save("full", with_opt=True)
+    sd2 = torch.load(tmp_path / "models" / "full.pth")
+    assert set(sd2) == {"model", "opt"}
+    w0 = learn.model.flat_param.clone()
+    learn.model.flat_param.add_(1.0)
+    learn.load("bare")
+    assert torch.equal(learn.model.flat_param, w0)
+    learn.model.flat_param.add_(1.0)
+    learn.load("full", with_opt=True)
+    assert torch.equal(learn.model.flat_param, w0)
+    # a fastai-written {'model','opt'} file: opt state = {'hypers': [...], 'state': [{'grad_avg':..,'sqr_avg':..,'step':..}, ...]}
+    torch.save({"model": sd, "opt": {"hypers": [{"lr": 1e-3}], "state": [{"grad_avg": torch.zeros(3), "step": 1}]}},
+               tmp_path / "models" / "fastai.pth")
+    learn.model.flat_param.add_(1.0)
+    with pytest.warns(UserWarning, match="optimizer state"):
+        learn.load("fastai", with_opt=True)
+    assert torch.equal(learn.model.flat_param, w0)
+    with pytest.warns(UserWarning, match="doesn't contain an optimizer state"):
+        learn.load("bare", with_opt=True)
+
+
+def _ce_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from unet_amd.distributed import broadcast_parameters, init_from_env
+    from unet_amd.learner import DiceMulti
+    from unet_amd.model import HipDynamicUnet
+    init_from_env(backend="gloo")
+    torch.manual_seed(50)
+    model = HipDynamicUnet("xresnet18", 4, 5, (64, 64), device="cuda:0")
+    broadcast_parameters(model.flat_param, list(model.buffers()))
+    model.mark_weights_dirty()
+    model.train()
+    g = torch.Generator().manual_seed(9 + rank)
+    x = (torch.randint(0, 256, (2, 4, 64, 64), generator=g).float() / 255).cuda()
+    # rank 0 sees mostly class 0, rank 1 mostly class 4: with non-uniform weights the ranks' denominators differ a lot
+    y = torch.where(torch.rand(2, 64, 64, generator=g) < 0.8, torch.full((2, 64, 64), 4 * rank), torch.randint(0, 5, (2, 64, 64), generator=g)).cuda()
+    w = torch.tensor([0.02, 0.1, 0.2, 0.3, 1.5], device="cuda")
+    loss = model.forward_loss_backward(x, y, w, world=world)
+    torch.cuda.synchronize()
+    z = model.logits_ts().view().permute(0, 3, 1, 2).contiguous()
+    dz = model.ctx.act(model, "dlogits", 2, 64, 64, 5, zero=True).view().permute(0, 3, 1, 2).contiguous()
+    zs, ys = [torch.empty_like(z) for _ in range(world)], [torch.empty_like(y) for _ in range(world)]
+    dist.all_gather(zs, z); dist.all_gather(ys, y)
+    # oracle: ONE weighted cross-entropy over the logits / targets of all ranks
+    zc = torch.cat(zs).cpu().double().requires_grad_(True)
+    l_ref = O.CrossEntropyLossFlat(weight=w.cpu().double())(zc, torch.cat(ys).cpu())
+    l_ref.backward()
+    dz_ref = zc.grad[2 * rank:2 * rank + 2]
+    ok_loss = abs(loss.item() - l_ref.item()) <= 2e-6 * abs(l_ref.item())
+    ok_dz = (dz.cpu().double() - dz_ref).abs().max().item() <= 2e-6 * dz_ref.abs().max().item()
+    # DiceMulti counters are summed over the ranks: every rank reports the value of the whole validation set
+    dm = DiceMulti()
+    dm.accumulate_argmax(z.argmax(1), y, 5)
+    dm.all_reduce()
+    ref = O.DiceMulti()
+    ref.accumulate(torch.cat(zs).cpu(), torch.cat(ys).cpu())
+    ok_dice = abs(dm.value - ref.value) < 1e-12
+    q.put((rank, bool(ok_loss), bool(ok_dz), bool(ok_dice)))
+    dist.destroy_process_group()
+
+
+def test_weighted_ce_numerator_denominator_and_dice_counters_are_all_reduced():
+    """with non-uniform class weights sum w[y] differs per rank; loss and logit-gradient of every rank must be those
+    of ONE cross-entropy over the global batch (numerator and denominator all-reduced between the loss kernels)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res == [(0, True, True, True), (1, True, True, True)], res
+
+
+def _learner_worker(rank, world, port, root, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from pathlib import Path
+    from unet_amd.distributed import init_from_env
+    from unet_amd.learner import CSVLogger, SaveModelCallback
+    init_from_env(backend="gloo")
+    torch.manual_seed(1000 + rank)                       # different initial weights per rank: the Learner must broadcast
+    learn = _tiny_learner(Path(root))
+    learn.cbs = [SaveModelCallback(monitor="valid_loss"), CSVLogger()]
+    assert learn.world == 2 and learn.dls.train.world == 2 and len(learn.dls.train) == 1
+    learn.fit_one_cycle(2, lr_max=slice(1e-4, 1e-3))
+    p = learn.model.flat_param.clone()
+    ref = p.clone()
+    dist.broadcast(ref, 0)
+    q.put((rank, bool(torch.equal(p, ref)), [float(v) for v in learn.recorder.values[-1][:3]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_learner_tile_ddp_two_ranks(tmp_path):
+    """the Learner under an initialised process group: rank-sharded training loader, replicas broadcast from rank 0, one
+    history.csv / best-model.pth (rank 0), validation loss and DiceMulti identical on both ranks (all-reduced)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0][1] and res[1][1], res
+    assert res[0][2][1:] == res[1][2][1:], res           # valid_loss, dice_multi: global values on every rank
+    hist = (tmp_path / "history.csv").read_text().strip().splitlines()
+    assert hist[0] == "epoch,train_loss,valid_loss,dice_multi,time" and len(hist) == 3
+    assert (tmp_path / "models" / "best-model.pth").exists()

@@ -450,3 +450,34 @@ def test_fit_one_cycle_trajectory_matches_oracle_training_loop():
             worst = (n, e)
     assert worst[1] < 2e-3, worst
     assert np.allclose(learn.recorder.lrs, [lr_f(i / 6)[-1] for i in range(6)], rtol=1e-6)
+
+
+def test_hipgraph_training_interleaved_with_eval_uses_fresh_weights():
+    """graphed steps -> eval -> graphed steps -> eval: every replay rewrites the parameters behind the packed-filter cache, so
+    the SECOND eval must not reuse the images packed by the first one (weights one Adam step stale)."""
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    torch.manual_seed(12)
+    sd = O.DynamicUnet("xresnet18", 4, 5, (64, 64)).state_dict()
+    xs = [O.synthetic_batch(2, 4, 64, 64, 5, seed=s) for s in range(8)]
+    xe = xs[0][0].cuda()
+    evals = []
+    for use_graph in (False, True):
+        model = HipDynamicUnet("xresnet18", 4, 5, (64, 64))
+        model.load_state_dict(sd)
+        opt = FlatAdam(model, [1e-3, 1e-3, 1e-2])
+        step = TrainStep(model, opt, None, 1, use_graph=use_graph)
+        out = []
+        for phase in range(2):
+            model.train()
+            for x, y in xs[4 * phase:4 * phase + 4]:
+                step(x.cuda(), y.cuda())
+            model.eval()
+            with torch.no_grad():
+                out.append(model(xe).clone().cpu())
+        assert (step._graph is not None) == use_graph
+        evals.append(out)
+    for a, b in zip(*evals):
+        assert (a - b).abs().max().item() < 1e-5 * max(1.0, a.abs().max().item())
+    assert (evals[0][0] - evals[0][1]).abs().max().item() > 1e-3        # the second phase did change the network

@@ -43,6 +43,15 @@ static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool slice_ok(int cs, int co, int C) { return cs > 0 && co >= 0 && (cs & 3) == 0 && (co & 3) == 0 && co + C <= cs; }
 
+// hipFuncSetAttribute is per device: one bit per device ordinal in a per-call-site mask (one process may drive several GPUs).
+// Returns true the first time the call site runs on the current device.
+static inline bool first_use_on_device(unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (__atomic_fetch_or(mask, bit, __ATOMIC_RELAXED) & bit) == 0;
+}
+
 // grid size for grid-stride HBM-bound kernels (256 CUs x 8 blocks)
 static inline int ew_grid(long long work_items, int block) {
     long long g = (work_items + block - 1) / block;

@@ -872,21 +872,17 @@ template <int TW, int MT, int NT, int WM, int WN, int HIT>
 int launch_cfg(const Plan& p, hipStream_t st) {
     if (p.mf == 16) {
         auto kern = conv_igemm16_kernel<TW, MT, NT, WM, WN, HIT>;
-        static size_t configured = 0;  // per instantiation
-        if (p.lds_bytes > configured) {
+        static unsigned long long configured = 0;  // per instantiation, one bit per device
+        if (unet::first_use_on_device(&configured))
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = 160 * 1024;
-        }
         hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k);
         UNET_CHECK_LAUNCH();
         return UNET_OK;
     }
     auto kern = conv_igemm_kernel<TW, MT, NT, WM, WN, HIT>;
-    static size_t configured = 0;  // per instantiation
-    if (p.lds_bytes > configured) {
+    static unsigned long long configured = 0;  // per instantiation, one bit per device
+    if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = 160 * 1024;
-    }
     hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k);
     UNET_CHECK_LAUNCH();
     return UNET_OK;

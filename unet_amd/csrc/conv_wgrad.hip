@@ -842,10 +842,9 @@ static int g_wgrad_mfma_shape = 32;   // the 16x16x4 wgrad form measured slower 
 template <int PTW, int S, int KS>
 int launch_w16(const WPlan& p, hipStream_t st) {
     auto kern = wgrad16_kernel<PTW, S, KS>;
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;   // one bit per device
+    if (unet::first_use_on_device(&configured)) {
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes16, st, p.k);
     UNET_CHECK_LAUNCH();
@@ -856,10 +855,9 @@ template <int PTW, int S, int KS>
 int launch_w(const WPlan& p, hipStream_t st) {
     if (g_wgrad_mfma_shape == 16) return launch_w16<PTW, S, KS>(p, st);
     auto kern = wgrad_kernel<PTW, S, KS>;
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;   // one bit per device
+    if (unet::first_use_on_device(&configured)) {
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes, st, p.k);
     UNET_CHECK_LAUNCH();
@@ -923,10 +921,9 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
         UNET_CHECK_LAUNCH();
         rc = UNET_OK;
     } else if (p.gemm1x1) {
-        static bool configured = false;
-        if (!configured) {
+        static unsigned long long configured = 0;   // one bit per device
+        if (unet::first_use_on_device(&configured)) {
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = true;
         }
         hipLaunchKernelGGL(wgrad1x1_kernel, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), (size_t)2 * 64 * 128 * sizeof(float), st, p.k,
                            (long long)d->N * d->OH * d->OW);
@@ -935,11 +932,10 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     } else if (p.narrow) {
         const size_t lds = (size_t)(32 + 3 * 34) * 112 * sizeof(float);
         const dim3 grid(unet::cdiv(d->Cin, p.k.cw) * p.k.nnb, unet::roundup(p.splits, 8));
-        static bool configured = false;
-        if (!configured) {
+        static unsigned long long configured = 0;   // one bit per device
+        if (unet::first_use_on_device(&configured)) {
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<6, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = true;
         }
         if (d->Cout > 96) hipLaunchKernelGGL((wgrad_flat_kernel<7, 5>), grid, dim3(256), lds, st, p.k);
         else hipLaunchKernelGGL((wgrad_flat_kernel<6, 7>), grid, dim3(256), lds, st, p.k);

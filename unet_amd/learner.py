@@ -128,9 +128,14 @@ class Rmse:
         d = (pred.reshape(-1).double() - targ.reshape(-1).double())
         self.se += float((d * d).sum().item())
         self.n += d.numel()
+        self._dev = pred.device
 
     def all_reduce(self):
-        pass
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.n:
+            t = torch.tensor([self.se, float(self.n)], dtype=torch.float64, device=self._dev)
+            dist.all_reduce(t)
+            self.se, self.n = float(t[0].item()), int(t[1].item())
 
     @property
     def value(self) -> float:
@@ -150,9 +155,14 @@ class R2Score:
         self.st += float(t.sum().item())
         self.stt += float((t * t).sum().item())
         self.res += float(((t - p) ** 2).sum().item())
+        self._dev = pred.device
 
     def all_reduce(self):
-        pass
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.n:
+            v = torch.tensor([float(self.n), self.st, self.stt, self.res], dtype=torch.float64, device=self._dev)
+            dist.all_reduce(v)
+            self.n, self.st, self.stt, self.res = int(v[0].item()), float(v[1].item()), float(v[2].item()), float(v[3].item())
 
     @property
     def value(self) -> float:
@@ -233,19 +243,39 @@ class TileDataset:
 
 
 class DataLoader:
-    def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0, batch_tfm=None):
+    """rank / world (tile-DDP, one process per GPU): every rank draws the SAME permutation (same seed) and keeps items
+    rank, rank + world, ... of it.  A shuffled (training) loader truncates to a multiple of world so that all ranks run the
+    same number of steps (the gradient all-reduce is a lock-step collective); a validation loader keeps every item."""
+
+    def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0, batch_tfm=None,
+                 rank: int = 0, world: int = 1):
         self.ds, self.bs, self.shuffle, self.device, self.drop_last = ds, bs, shuffle, device, drop_last
         self._g = np.random.default_rng(seed)
         self.batch_tfm = batch_tfm
+        self.rank, self.world = rank, world
+
+    def shard(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        return self
+
+    def _n_local(self) -> int:
+        n = len(self.ds)
+        if self.world == 1:
+            return n
+        return n // self.world if self.shuffle else len(range(self.rank, n, self.world))
 
     def __len__(self):
-        n = len(self.ds)
+        n = self._n_local()
         return n // self.bs if self.drop_last else -(-n // self.bs)
 
     def __iter__(self):
         idx = np.arange(len(self.ds))
         if self.shuffle:
             self._g.shuffle(idx)
+        if self.world > 1:
+            if self.shuffle:
+                idx = idx[:len(idx) // self.world * self.world]
+            idx = idx[self.rank::self.world]
         for b in range(len(self)):
             items = [self.ds[int(i)] for i in idx[b * self.bs:(b + 1) * self.bs]]
             xb = torch.stack([x for x, _ in items]).to(self.device)
@@ -303,17 +333,23 @@ class CSVLogger(Callback):
 
     def before_fit(self, learn):
         self.path = learn.path / self.fname
+        self.file = None
+        if learn.rank != 0:          # tile-DDP: one history file, written by rank 0
+            return
         self.path.parent.mkdir(parents=True, exist_ok=True)
         self.file = open(self.path, "a" if self.append else "w", newline="")
         self.writer = csv.writer(self.file)
         self.writer.writerow(learn.recorder.metric_names)
 
     def after_epoch(self, learn):
+        if self.file is None:
+            return
         self.writer.writerow(learn.recorder.log_row)
         self.file.flush()
 
     def after_fit(self, learn):
-        self.file.close()
+        if self.file is not None:
+            self.file.close()
 
 
 class SaveModelCallback(Callback):
@@ -327,13 +363,15 @@ class SaveModelCallback(Callback):
 
     def after_epoch(self, learn):
         val = learn.recorder.last[self.monitor]
-        if self.best is None or self.comp(val, self.best):
+        if self.best is None or self.comp(val, self.best):      # (the monitored values are all-reduced: same decision on every rank)
             self.best = val
             learn.save(self.fname)
-            print(f"Better model found at epoch {learn.epoch} with {self.monitor} value: {val}.")
+            if learn.rank == 0:
+                print(f"Better model found at epoch {learn.epoch} with {self.monitor} value: {val}.")
 
     def after_fit(self, learn):
         if self.best is not None:
+            learn._barrier()
             learn.load(self.fname)
 
 
@@ -424,13 +462,30 @@ class Learner:
         self.opt: Optional[FlatAdam] = None
         self.recorder = Recorder([getattr(m, "name", type(m).__name__.lower()) for m in self.metrics])
         self.epoch = 0
-        self.world = 1
-        try:
+        # tile-DDP (one process per GPU, torch.distributed initialised by the launcher): the training loader is sharded by rank,
+        # replicas start from rank 0's parameters, gradients / loss sums / metric counters are all-reduced, files are written
+        # by rank 0 only.  Without an initialised process group this is the plain single-GPU Learner.
+        self.rank, self.world = 0, 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+            for dl in (getattr(dls, "train", None), getattr(dls, "valid", None)):
+                if dl is not None:
+                    dl.shard(self.rank, self.world)
+        self._synced = False
+
+    def _barrier(self):
+        if self.world > 1:
             import torch.distributed as dist
-            if dist.is_initialized():
-                self.world = dist.get_world_size()
-        except Exception:
-            pass
+            dist.barrier()
+
+    def _sync_replicas(self):
+        """rank 0's parameters and BatchNorm buffers on every replica (model init is not seeded per rank)"""
+        if self.world > 1 and not self._synced:
+            from .distributed import broadcast_parameters
+            broadcast_parameters(self.model.flat_param, list(self.model.buffers()))
+            self.model.mark_weights_dirty()
+        self._synced = True
 
     # -- callback plumbing the reference uses
     @property
@@ -485,7 +540,10 @@ class Learner:
     def _fit(self, n_epoch, lr_f, mom_f, batch_cb=None):
         """batch_cb(it, loss_tensor, lr) -> True stops the fit after that batch (lr_find)."""
         model, opt = self.model, self.opt
+        self._sync_replicas()
         fused = isinstance(self.loss_func, (CrossEntropyLossFlat, _RegLoss))
+        if self.world > 1 and not fused:
+            raise RuntimeError("tile-DDP needs one of the fused losses (CrossEntropyLossFlat / MSELossFlat / L1LossFlat / Smoothl1)")
         step = TrainStep(model, opt, self._weights(), self.world) if fused else None
         if fused and self.regression:
             step.reg_kind, step.reg_beta = self.loss_func.kind, self.loss_func.beta
@@ -522,7 +580,7 @@ class Learner:
             self.recorder.values.append(row[1:-1])
             self.recorder.log_row = row
             self.recorder.last = dict(zip(self.recorder.metric_names[1:-1], row[1:-1]))
-            if not getattr(self, "_no_logging", False):
+            if not getattr(self, "_no_logging", False) and self.rank == 0:
                 print(dict(zip(self.recorder.metric_names, row)))
             for cb in self.cbs:
                 cb.after_epoch(self)
@@ -566,6 +624,11 @@ class Learner:
         for m in self.metrics:
             if hasattr(m, "all_reduce"):
                 m.all_reduce()
+        if self.world > 1:          # valid_loss = sum of the ranks' numerators / sum of their denominators
+            import torch.distributed as dist
+            t = torch.tensor([num, den], dtype=torch.float64, device=model._device)
+            dist.all_reduce(t)
+            num, den = float(t[0].item()), float(t[1].item())
         return [num / max(den, 1e-30)] + [m.value for m in self.metrics]
 
     # -- inference (predict.py:193)
@@ -611,7 +674,8 @@ class Learner:
         if self.opt is None:
             self.create_opt()
         num_it = max(6, int(num_it))
-        self.save("_tmp_lr_find", with_opt=True)
+        tmp = f"_tmp_lr_find_r{self.rank}"
+        self._save_local(tmp, with_opt=True)
         rec, self.recorder = self.recorder, Recorder([])
         self._no_logging = True
         cbs, self.cbs = self.cbs, []
@@ -637,10 +701,10 @@ class Learner:
             self.recorder, self.cbs, self.dls.valid = rec, cbs, valid
             self._no_logging = False
             self.model.flat_grad.zero_()
-            self.load("_tmp_lr_find", with_opt=True)
+            self.load(tmp, with_opt=True)
             self.model.mark_weights_dirty()
             try:
-                self._model_path("_tmp_lr_find").unlink()
+                self._model_path(tmp).unlink()
             except OSError:
                 pass
         lrs = np.array(smooth.lrs[num_it // 10:-5], dtype=np.float64)
@@ -661,17 +725,34 @@ class Learner:
         p.mkdir(parents=True, exist_ok=True)
         return p / f"{name}.pth"
 
-    def save(self, name, with_opt=False):
-        sd = {"model": {k: v.cpu() for k, v in self.model.state_dict().items()}}
+    def _save_local(self, name, with_opt=False):
+        """fastai ``save_model`` file layout: the bare model ``state_dict`` (what SaveModelCallback writes: with_opt=False), or
+        ``{'model': ..., 'opt': ...}`` with the optimizer state."""
+        sd = {k: v.cpu() for k, v in self.model.state_dict().items()}
         if with_opt and self.opt is not None:
-            sd["opt"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.opt.state_dict().items()}
+            sd = {"model": sd, "opt": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.opt.state_dict().items()}}
         torch.save(sd, self._model_path(name))
 
+    def save(self, name, with_opt=False):
+        if self.rank == 0:           # tile-DDP: replicas are identical, one writer
+            self._save_local(name, with_opt)
+        self._barrier()
+
     def load(self, name, with_opt=False):
+        """fastai ``load_model``: accepts both layouts; an optimizer state that is not this optimizer's (e.g. written by
+        fastai itself) is skipped with a warning, as fastai does."""
         sd = torch.load(self._model_path(name), map_location="cpu")
-        self.model.load_state_dict(sd["model"])
-        if with_opt and "opt" in sd and self.opt is not None:
-            self.opt.load_state_dict({k: (v.to(self.model._device) if torch.is_tensor(v) else v) for k, v in sd["opt"].items()})
+        hasopt = isinstance(sd, dict) and set(sd.keys()) == {"model", "opt"}
+        self.model.load_state_dict(sd["model"] if hasopt else sd)
+        if hasopt and with_opt and self.opt is not None:
+            try:
+                self.opt.load_state_dict({k: (v.to(self.model._device) if torch.is_tensor(v) else v) for k, v in sd["opt"].items()})
+            except Exception as e:      # noqa: BLE001
+                import warnings
+                warnings.warn(f"Could not load the optimizer state ({type(e).__name__}: {e}); the model weights were loaded.")
+        elif with_opt and not hasopt:
+            import warnings
+            warnings.warn("Saved file doesn't contain an optimizer state.")
         return self
 
     def export(self, fname="export.pkl"):
@@ -684,8 +765,10 @@ class Learner:
                 "regression": self.loss_func.kind if self.regression else None}
         p = Path(fname)
         p = p if p.is_absolute() else self.path / p
-        p.parent.mkdir(parents=True, exist_ok=True)
-        torch.save({"meta": meta, "model": {k: v.cpu() for k, v in m.state_dict().items()}}, p)
+        if self.rank == 0:
+            p.parent.mkdir(parents=True, exist_ok=True)
+            torch.save({"meta": meta, "model": {k: v.cpu() for k, v in m.state_dict().items()}}, p)
+        self._barrier()
 
     def summary(self) -> str:
         m = self.model

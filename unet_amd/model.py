@@ -304,9 +304,15 @@ class HipDynamicUnet(nn.Module):
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
 
     def forward_loss_backward(self, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                              grad_scale: float = 1.0, reg_kind: Optional[str] = None, reg_beta: float = 0.5) -> torch.Tensor:
+                              grad_scale: float = 1.0, reg_kind: Optional[str] = None, reg_beta: float = 0.5,
+                              world: int = 1) -> torch.Tensor:
         """One fused training pass: logits -> loss -> backward into the flat gradient buffer.  Returns the loss as a 1-element
-        device tensor (no host sync).  grad_scale multiplies the gradient (1/world for tile-DDP averaging).
+        device tensor (no host sync).  grad_scale multiplies the gradient.
+        world > 1 (tile-DDP): the weighted cross-entropy is sum_r num_r / sum_r den_r over the ranks (den_r = sum of w[y] on
+        rank r differs per rank when the class weights are not uniform): numerator and denominator are
+        all-reduced between the loss forward and backward kernels, the local gradient is taken w.r.t. the GLOBAL denominator
+        and the SUM all-reduce of the gradients then equals the single-process gradient of the global batch.  Regression
+        losses are plain means over equally many pixels per rank: gradient pre-scaled by 1/world.
         Classification (default): weighted per-pixel cross-entropy, CrossEntropyLossFlat(axis=1, weight) (train.py:195,211).
         Regression (reg_kind = "mse" | "l1" | "smoothl1", n_out = 1, float targets [B,H,W]): train.py:189-193."""
         x = x.to(self._device, torch.float32)
@@ -318,6 +324,14 @@ class HipDynamicUnet(nn.Module):
             y = y.to(self._device, torch.int64).contiguous()
             loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
             ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
+            if world > 1:
+                import torch.distributed as dist
+                nd = ctx.vec(self, "numden", 2)
+                torch.mul(loss, denom, out=nd[0:1])
+                nd[1:2].copy_(denom)
+                dist.all_reduce(nd)
+                denom.copy_(nd[1:2])
+                torch.div(nd[0:1], nd[1:2], out=loss)
             ops.ce_bwd(z, y, weight, denom, grad_scale, dz)
         else:
             if self.n_out != 1:
@@ -325,6 +339,11 @@ class HipDynamicUnet(nn.Module):
             y = y.to(self._device, torch.float32).contiguous()
             loss = ctx.vec(self, "loss", 1)
             ops.regloss_fwd(z, y, reg_kind, reg_beta, loss, ctx.workspace(ops.ce_workspace(P)))
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(loss)
+                loss.div_(world)
+                grad_scale = grad_scale / world
             ops.regloss_bwd(z, y, reg_kind, reg_beta, grad_scale, dz)
         self._ensure_grad_views()
         self._hip_backward(dz)

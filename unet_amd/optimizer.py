@@ -64,7 +64,12 @@ class FlatAdam:
         self.grad_scale = 1.0
         # hipGraph mode: hyper-parameters live in a device block refreshed by the host before each replay
         nh = ops.lib.unet_adam_hyper_floats()
-        self._hyper_host = torch.zeros(nh, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(nh)
+        # a RING of pinned staging blocks: the host runs ahead of the stream, so block i may only be refilled once the
+        # H2D copy that read it has executed (event recorded right behind that copy)
+        self._hyper_ring = [torch.zeros(nh, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(nh)
+                            for _ in range(4)]
+        self._hyper_events = [None] * len(self._hyper_ring)
+        self._hyper_slot = 0
         self._hyper_dev = torch.zeros(nh, dtype=torch.float32, device=dev)
 
     def set_lr(self, lr):
@@ -83,10 +88,19 @@ class FlatAdam:
         """host -> device copy of (lr, momentum, de-bias terms ...) for step number `step` (stream ordered, no sync)"""
         import ctypes as C
         arr = (C.c_float * 4)(*(self.lrs + [0.0] * (4 - len(self.lrs))))
-        hp = C.cast(self._hyper_host.data_ptr(), C.POINTER(C.c_float))
+        i = self._hyper_slot
+        self._hyper_slot = (i + 1) % len(self._hyper_ring)
+        if self._hyper_events[i] is not None:
+            self._hyper_events[i].synchronize()          # the copy that last read this block is done
+        host = self._hyper_ring[i]
+        hp = C.cast(host.data_ptr(), C.POINTER(C.c_float))
         ops.check(ops.lib.unet_adam_fill_hyper(hp, arr, float(self.mom), float(self.sqr_mom), float(self.eps), float(self.wd), int(step),
                                                float(self.grad_scale)), "adam_fill_hyper")
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        self._hyper_dev.copy_(host, non_blocking=True)
+        if self._hyper_dev.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_events[i] = ev
 
     def step_from_device_hyper(self):
         """the launch that gets captured in a hipGraph: every hyper-parameter is read from self._hyper_dev"""

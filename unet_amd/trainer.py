@@ -62,6 +62,9 @@ class TrainStep:
         opt.step_count += 1
         opt.upload_hyper(opt.step_count)
         self._graph.replay()
+        # every replay re-packs the filters from the pre-step parameters and then runs Adam: the packed images a later
+        # eager (eval / predict) forward would reuse are one step stale -> invalidate them after EVERY replay
+        m.mark_weights_dirty()
         return self._loss
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -70,8 +73,8 @@ class TrainStep:
             return self._graphed(x, y)
         if self.reducer is not None:
             self.reducer.reset()
-        loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0 / self.world, reg_kind=self.reg_kind,
-                                                reg_beta=self.reg_beta)
+        loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta,
+                                                world=self.world)
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
