@@ -26,6 +26,7 @@ import torch  # noqa: E402
 
 GFLOP_PER_TILE_FWD_BWD = 767.388      # BASELINE.md section 2 (conv MACs x 2, cfg2)
 PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 matrix == vector peak
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 TB/s achievable by a streaming copy)
 ARCH, N_IN, N_CLS, SIZE = "xresnet34", 4, 5, 512
 
 
@@ -118,6 +119,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 (default): the parity path, the headline.  bf16: bf16 storage / fp32 accumulate variant of configs[1]")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -140,7 +143,7 @@ def main():
     import torch.distributed as dist
 
     torch.manual_seed(0)
-    model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev)
+    model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=args.dtype)
     broadcast_parameters(model.flat_param, list(model.buffers()))
     model.mark_weights_dirty()
     model.train()
@@ -192,29 +195,42 @@ def main():
     if rank == 0:
         tiles = args.batch * world * args.steps
         value = tiles / dt
-        # dominant kernel over ALL its launches in the timed region: algorithmic FLOPs / summed launch durations
-        achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
-        traffic = None
+        # dominant kernel over ALL its launches in the timed region: algorithmic FLOPs (fp32: MFMA roofline) or algorithmic bytes
+        # (bf16 storage: HBM roofline) / summed launch durations
         pmc = ROOT / "profiles" / "pmc_traffic.json"      # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch")
+        pmc = json.loads(pmc.read_text()) if pmc.exists() else {}
+        common = {"launches_per_step": ps["launches"] // max(1, args.steps), "avg_launch_ms": round(ps["avg_ms"], 4),
+                  "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
+                  "avg_launch_alg_bytes": int(ps["bytes"] / max(1, ps["launches"])),
+                  "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)}
+        if args.dtype == "f32":
+            achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
+                                                   "conv, forward and input-gradient)",
+                        "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_F32_TFLOPS, 4),
+                        "traffic": pmc.get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"), **common}
+        else:
+            achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "conv_bf16_kernel<32,2,2,2,2,4> (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM: every wide "
+                                                  "3x3/1x1 conv, forward and input-gradient); algorithmic bytes = every operand tensor once in, the "
+                                                  "result once out, the packed filter once",
+                        "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
+                        "traffic": pmc.get("conv_bf16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"),
+                        "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1), **common}
         out = {
             "metric": "512x512 tiles/sec fwd+bwd (4-ch->5-class U-Net)", "value": round(value, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfg2: 4x512x512 tiles, xresnet34 DynamicUnet, 5 classes, fwd+bwd+fastai-Adam step, "
-                                   "BN train mode, CE weights even", "tiles_per_gpu": args.batch, "global_batch": args.batch * world,
+                                   "BN train mode, CE weights even" + ("" if args.dtype == "f32" else
+                                   "; bf16 storage of activations / gradients / packed filters, fp32 accumulate, fp32 master weights + Adam"),
+                       "tiles_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"tile-dp{world}", "self_attention": False},
             "loss": round(float(loss.item()), 5),
             "step_tflops": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
             "step_frac_of_f32_peak": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3 / (PEAK_F32_TFLOPS * world), 4),
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
-                                                     "conv, forward and input-gradient)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-                         "launches_per_step": ps["launches"] // max(1, args.steps), "avg_launch_ms": round(ps["avg_ms"], 4),
-                         "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
-                         "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)},
+            "roofline": roofline,
             "hbm_bytes_allocated": model.memory_bytes(),
             # world size the collective library itself reports (1 = no process group) and the device every rank ran on
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,

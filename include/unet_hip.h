@@ -35,10 +35,19 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 1
+#define UNET_ABI_VERSION 2
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
+
+/* Storage type of activations / activation gradients / packed filter images.  UNET_F32 is the parity path (the reference computes in
+ * fp32: train.py:141-144 has no to_fp16()).  UNET_BF16 is the bf16-storage variant of BASELINE.json configs[1]: tensors are bfloat16
+ * bit patterns (unet_bf16), channel strides / offsets are multiples of 8 (16-byte vectors), every product is accumulated in fp32
+ * (v_mfma_f32_16x16x32_bf16), per-channel vectors (bias, BatchNorm coefficients), losses, master weights and optimizer state stay
+ * fp32.  Entry points with a _bf16 suffix take bf16 tensors where the fp32 entry point takes float tensors. */
+#define UNET_F32 0
+#define UNET_BF16 1
+typedef uint16_t unet_bf16;
 
 /* ------------------------------------------------------------------ conv --
  * Implicit-GEMM convolution on fp32 MFMA, NHWC, no im2col.  Default instruction v_mfma_f32_16x16x4_f32: LDS-staged input halo
@@ -74,9 +83,12 @@ typedef struct {
     int cout_begin, cout_count;          /* produce only channels [cout_begin, cout_begin + cout_count) of the Cout-wide problem
                                             (cout_begin % 16 == 0); 0, 0 = all.  Lets a caller issue e.g. 192 channels as 128 + 64
                                             with a channel-block width that fits each part. */
-    long long wp_img_stride;             /* floats between the packed filter images of consecutive batch images; 0 = one image for all.
+    long long wp_img_stride;             /* elements between the packed filter images of consecutive batch images; 0 = one image for all.
                                             Per-image "filters" are activations: the attention products of SelfAttention run as ONE
                                             launch over the batch (unet_pack_weights_strided once per image into one buffer). */
+    int dtype;                           /* UNET_F32 (default 0) | UNET_BF16: storage type of x, res, mask, y and wp (cast the pointers);
+                                            bias stays fp32.  bf16: wp from unet_pack_weights_bf16, colsum / colsumsq unsupported */
+    int y_f32;                           /* dtype UNET_BF16 only: y is an fp32 buffer (the logits head feeds the fp32 loss kernels) */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */
@@ -100,6 +112,9 @@ int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int 
 /* 1x1 "weights" that are themselves activations (self-attention operands): element (out o, reduction r) = w[o*so + r*sr];
  * produces the same packed image as mode 0 with ks = 1 (size unet_pack_weights_size(O, R, 1, 0)). */
 int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream);
+/* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32) */
+size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode); /* elements */
+int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream);
 
 /* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
  * Replaces the autograd weight-gradient of the same nn.Conv2d modules.
@@ -112,6 +127,7 @@ typedef struct {
     int N, IH, IW, Cin, OH, OW, Cout, ks, stride;
     float* workspace; size_t workspace_floats;
     int accumulate;                      /* 0: dw = result, 1: dw += result */
+    int dtype;                           /* UNET_F32 (default 0) | UNET_BF16: storage type of x and dy; dw, dbias and the workspace are fp32 */
 } unet_wgrad_desc;
 size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d);
 int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream);
@@ -248,6 +264,25 @@ int unet_adam_step_dev(float* p, const float* g, float* m, float* v, const uint8
 int unet_mosaic_accumulate(const float* probs_nchw, int C, int th, int tw, float* mosaic /*[C,MH,MW]*/,
                            int32_t* count /*[MH,MW]*/, int MH, int MW, int y0, int x0, void* stream);
 int unet_mosaic_finalize(float* mosaic, const int32_t* count, int C, int MH, int MW, uint8_t* argmax, void* stream);
+
+/* ---------------------------------------------------- bf16-storage twins --
+ * The HBM-bound kernels of the step with bf16 activation / gradient tensors (per-channel vectors, statistics, indices, losses stay
+ * as in the fp32 entry point of the same name; arithmetic is fp32 per element, one rounding to bf16 at the store).  Used by
+ * HipDynamicUnet(act_dtype="bf16"): BASELINE.json configs[1] "bf16" variant.  The logits head writes fp32 (unet_conv_desc.y_f32), so
+ * unet_ce_fwd / unet_softmax_argmax are shared; unet_ce_bwd_bf16 writes the bf16 logit gradient. */
+int unet_bn_stats_bf16(const unet_bf16* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream);
+int unet_affine_act_bf16(const unet_bf16* x, int x_cs, int x_co, const float* scale, const float* shift, const unet_bf16* x2, int x2_cs, int x2_co, const float* scale2, const float* shift2, unet_bf16* y, int y_cs, int y_co, long long P, int C, int relu, void* stream);
+int unet_bn_bwd_reduce_bf16(const unet_bf16* dout, int d_cs, int d_co, const unet_bf16* out, int o_cs, int o_co, const unet_bf16* x, int x_cs, int x_co, const float* mean, const float* invstd, long long P, int C, float* partial, void* stream);
+int unet_bn_bwd_apply_bf16(const unet_bf16* dout, int d_cs, int d_co, const unet_bf16* out, int o_cs, int o_co, const unet_bf16* x, int x_cs, int x_co, const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2, unet_bf16* dx, int dx_cs, int dx_co, unet_bf16* gout, int g_cs, int g_co, int g_accumulate, long long P, int C, void* stream);
+int unet_maxpool3x3s2_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW, int C, int OH, int OW, void* stream);
+int unet_maxpool3x3s2_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, const uint8_t* idx, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
+int unet_avgpool2_ceil_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH, int OW, void* stream);
+int unet_avgpool2_ceil_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
+int unet_shuffle_blur_bf16(const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* X, int X_cs, int X_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+int unet_shuffle_blur_bwd_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+int unet_nchw_to_nhwc_bf16(const float* x, unet_bf16* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream);
+int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate, void* stream);
+int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream);
 
 #ifdef __cplusplus
 }

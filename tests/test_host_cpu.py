@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(L.lib, s), s
-    assert L.lib.unet_abi_version() == 1
+    assert L.lib.unet_abi_version() == 2
     # pure host-side queries work without a GPU
     assert L.lib.unet_pack_weights_size(100, 100, 3, 0) == 9 * 7 * 128 * 16
     assert L.lib.unet_bn_stats_rows(10) == 1 and L.lib.unet_bn_stats_rows(1 << 30) == 512

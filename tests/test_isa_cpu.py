@@ -9,10 +9,11 @@ from unet_amd.build import CSRC, HIPCC
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not available")
-def test_no_instruction_touches_an_in_flight_register():
-    asm = isa_check.compile_to_asm(CSRC / "conv_igemm.hip")
+@pytest.mark.parametrize("src,min_kernels", [("conv_igemm.hip", 30), ("conv_bf16.hip", 30)])
+def test_no_instruction_touches_an_in_flight_register(src, min_kernels):
+    asm = isa_check.compile_to_asm(CSRC / src)
     kernels, bad = isa_check.check_asm(asm)
-    assert len(kernels) >= 30, f"expected every conv_igemm16 instantiation to carry asm loads, saw {len(kernels)}"
+    assert len(kernels) >= min_kernels, f"expected every direct-operand conv instantiation of {src} to carry asm loads, saw {len(kernels)}"
     assert not bad, "\n".join(bad[:20])
 
 

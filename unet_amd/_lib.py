@@ -19,6 +19,8 @@ CONV_RELU = 1
 CONV_MASK = 4
 CONV_FWD = 0
 CONV_DGRAD = 1
+F32 = 0
+BF16 = 1
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -40,6 +42,7 @@ class ConvDesc(C.Structure):
         ("colsumsq", vp),
         ("cout_begin", C.c_int), ("cout_count", C.c_int),
         ("wp_img_stride", C.c_longlong),
+        ("dtype", C.c_int), ("y_f32", C.c_int),
     ]
 
 
@@ -53,6 +56,7 @@ class WgradDesc(C.Structure):
         ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("ks", C.c_int), ("stride", C.c_int),
         ("workspace", vp), ("workspace_floats", C.c_size_t),
         ("accumulate", C.c_int),
+        ("dtype", C.c_int),
     ]
 
 
@@ -130,6 +134,13 @@ _sig = {
     "unet_mosaic_accumulate": (i, [vp, i, i, i, vp, vp, i, i, i, i, vp]),
     "unet_mosaic_finalize": (i, [vp, vp, i, i, i, vp, vp]),
 }
+# bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
+for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
+           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
+    _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
+_sig["unet_pack_weights_size_bf16"] = _sig["unet_pack_weights_size"]
+_sig["unet_pack_weights_bf16"] = _sig["unet_pack_weights"]
+
 for _name, (_res, _args) in _sig.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
@@ -139,7 +150,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 1:
+if lib.unet_abi_version() != 2:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 

@@ -42,6 +42,8 @@ static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool slice_ok(int cs, int co, int C) { return cs > 0 && co >= 0 && (cs & 3) == 0 && (co & 3) == 0 && co + C <= cs; }
+// v = channels per 16-byte access of the tensor's storage type (4 fp32, 8 bf16)
+static inline bool slice_ok_v(int cs, int co, int C, int v) { return cs > 0 && co >= 0 && cs % v == 0 && co % v == 0 && co + C <= cs; }
 
 // hipFuncSetAttribute is per device: one bit per device ordinal in a per-call-site mask (one process may drive several GPUs).
 // Returns true the first time the call site runs on the current device.

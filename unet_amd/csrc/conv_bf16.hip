@@ -1,0 +1,347 @@
+// Implicit-GEMM convolution with bf16 storage and fp32 accumulation for gfx950 (MI355X): v_mfma_f32_16x16x32_bf16.
+//
+// The bf16-storage variant of BASELINE.json configs[1]: activations, activation gradients and the packed filter image are bf16,
+// every product is accumulated in fp32 by the matrix core, master weights / optimizer state stay fp32 (conv_igemm.hip is the fp32
+// parity path).  Same workgroup geometry, halo staging, direct global -> VGPR filter operand, asm-scheduled loads and XCD-aware
+// tile order as conv_igemm16_kernel -- a reduction chunk is again 64 bytes per pixel, now 32 channels, and ONE MFMA consumes
+// what four v_mfma_f32_16x16x4_f32 did -- with two differences:
+//   * operand roles are swapped: A = filter tile (16 output channels x 32 k), B = pixel tile (32 k x 16 pixels), so that the
+//     accumulator of lane (pixel l&15, quad l>>4) holds FOUR CONSECUTIVE CHANNELS of one pixel: the epilogue moves 8-byte
+//     (bf16) / 16-byte (fp32 logits) vectors per lane instead of scalars;
+//   * a reduction tail (Cin % 32 != 0) is zero padded (the math is 16x cheaper than fp32; the kernel is load bound).
+//
+// lane l: A[i = l&15][k = 8(l>>4) + j] = W[cout i][channel 8(l>>4) + j]   (packed image wp[tap][chunk][cout][32], 1 KiB per tile)
+//         B[k = 8(l>>4) + j][col = l&15] = halo[pixel l&15 shifted by tap][channel 8(l>>4) + j]   (one ds_read_b128)
+//         D[row = 4(l>>4) + r][col = l&15] -> channel 4(l>>4) + r of pixel l&15
+//
+// Replaces the same ATen conv kernels as conv_igemm.hip (fastai ConvLayer convs of the model built at reference train.py:128-144).
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace unetconv;
+
+constexpr int KCB = 32;   // reduction channels per chunk (64 bytes of bf16)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ f32x4 ld_bf16x4(const u16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void st_bf16x4(u16* p, f32x4 v) {
+    const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};       // v_cvt_pk_bf16_f32: round to nearest even
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+
+template <int TW, int MT, int NT, int WM, int WN, int HIT>
+__global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kernel(const KArgs a, const int y_f32) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
+    constexpr int M16 = 2 * MT, N16 = 2 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const TapSet& ts = a.taps[blockIdx.z];
+
+    // XCD-aware tile order (see conv_igemm16_kernel): every XCD owns one contiguous range of tiles
+    const int per_xcd = (int)(gridDim.x >> 3);
+    int bid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (bid >= a.mtiles * a.ntn) return;
+    const int nt = __builtin_amdgcn_readfirstlane(bid % a.ntn); bid /= a.ntn;
+    const int tx_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_x); bid /= a.tiles_x;
+    const int ty_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_y);
+    const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
+    const int oy0 = ty_t * TH, ox0 = tx_t * TW;
+    const int n0 = a.n_base + nt * BN;
+
+    const int S = a.S;
+    const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
+    const int HPIX = HH * HW;
+    float* lds0 = smem + 32;
+    auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDK); };
+    const unsigned long long dpack = ts.dpack, wpack = ts.wpack;
+#define TAP_OFF(t_) ({ const unsigned d_ = (unsigned)(dpack >> (4 * (t_))); (int)(((d_ & 3u) * HW + ((d_ >> 2) & 3u)) * LDK); })
+#define TAP_WIDX(t_) ((int)((unsigned)(wpack >> (4 * (t_))) & 15u))
+
+    // halo items: 16 bytes = 8 channels; 4 items per pixel and chunk.  goff = bf16 ELEMENT offset inside the image
+    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * 2;
+    const int iy0 = oy0 * S + ts.min_dy, ix0 = ox0 * S + ts.min_dx;
+    int goff[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        const int p = e >> 2, q = e & 3;
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool inb = (e < HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        goff[it] = inb ? ((iy * a.IW + ix) * a.x_cs + a.x_co + 8 * q) : -1;
+    }
+
+    v4f hreg[HIT];
+#define HALO_OK(it_, c0_) (goff[it_] >= 0 && ((c0_) + 8 * ((tid + (it_) * NTH) & 3)) < a.Cin4)
+#define LOAD_HALO(chunk_, on_) do { const int c0_ = (chunk_) * KCB; unsigned vo_[HIT]; \
+        if (on_) { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = HALO_OK(it, c0_) ? (unsigned)(goff[it] + c0_) * 2u : 0u; } \
+        else { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = 0u; } \
+        gld_halo<HIT>(hreg, vo_, xb, (on_)); } while (0)
+#define STORE_HALO(dst_, chunk_) do { const int c0_ = (chunk_) * KCB; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) { \
+            const int e_ = tid + it * NTH; \
+            if (e_ < HPIX * 4) { \
+                const v4f v_ = HALO_OK(it, c0_) ? hreg[it] : (v4f){0.f, 0.f, 0.f, 0.f}; \
+                *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDK + (e_ & 3) * 4) = v_; \
+            } } } while (0)
+
+    // pixel-operand row bases (dwords) inside the halo tile
+    int pbase[M16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m) {
+        const int pix = (wm * M16 + m) * 16 + l15;
+        const int ty = pix / TW, tx = pix % TW;
+        pbase[m] = ((ty * S) * HW + tx * S) * LDK + 4 * kq;
+    }
+    // 16-wide output-channel tiles dealt round-robin to the WN waves; tiles entirely beyond the produced range are skipped
+    int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
+    nvalid = (a.n_end - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    const unsigned lane_b = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
+    const char* wbase = reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2;
+    const size_t slab_b = (size_t)a.coutPad * KCB * 2;
+    constexpr int TSTR = WN * 16 * 64;     // bytes between two of this wave's filter tiles
+    v4f b0[N16], b1[N16];
+#define LOAD_B(dst_, widx_, chunk_) gld_b<TSTR, N16>((dst_), lane_b, wbase + (size_t)((widx_) * a.nchunks + (chunk_)) * slab_b)
+
+    f32x4 acc[M16][N16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m)
+#pragma unroll
+        for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntaps = ts.n;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+    LOAD_HALO(0, true);
+    LOAD_B(b0, ts.widx[0], 0);
+    wait_loads(b0, hreg);
+    STORE_HALO(halo_buf(0), 0);
+    __syncthreads();
+
+    int t = 0, chunk = 0;
+    const float* hb = halo_buf(0);
+    // stage = (chunk, tap): the next stage's filter tiles (and, during the first tap of a chunk, the next chunk's halo items) are
+    // issued at the top and waited for behind the stage's MFMAs; ONE wait asm per stage redefines every register a load writes
+#define STAGE_BODY(bu_, bl_) do { \
+        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks); \
+        LOAD_B(bl_, has_next_ ? TAP_WIDX(tn_) : 0, has_next_ ? cn_ : 0); \
+        const float* ha_ = hb + TAP_OFF(t); \
+        bf16x8 pv_[M16]; \
+        _Pragma("unroll") for (int m = 0; m < M16; ++m) pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(ha_ + pbase[m])); \
+        _Pragma("unroll") for (int n = 0; n < N16; ++n) { \
+            if (n < nvalid) { \
+                const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
+                _Pragma("unroll") for (int m = 0; m < M16; ++m) \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, pv_[m], acc[m][n], 0, 0, 0); \
+            } \
+        } \
+        wait_loads(bl_, hreg); \
+    } while (0)
+#define STAGE(bu_, bl_) do { \
+        int tn_ = t + 1, cn_ = chunk; \
+        if (tn_ == ntaps) { tn_ = 0; cn_ = chunk + 1; } \
+        const bool has_next_ = cn_ < a.nchunks; \
+        STAGE_BODY(bu_, bl_); \
+        if (tn_ == 0 && has_next_) { \
+            STORE_HALO(halo_buf(cn_ & 1), cn_); \
+            __syncthreads(); \
+            hb = halo_buf(cn_ & 1); \
+        } \
+        t = tn_; chunk = cn_; \
+    } while (0)
+
+    const int total = a.nchunks * ntaps;
+    for (int s = 0; s + 1 < total; s += 2) {
+        STAGE(b0, b1);
+        STAGE(b1, b0);
+    }
+    if (total & 1) STAGE(b0, b1);
+#undef STAGE_BODY
+#undef STAGE
+#undef TAP_OFF
+#undef TAP_WIDX
+#undef HALO_OK
+#undef LOAD_HALO
+#undef STORE_HALO
+#undef LOAD_B
+
+    // ---- epilogue: lane (pixel l15 of every pixel tile) x (4 consecutive channels 4kq.. of every channel tile) ----
+    const bool relu = a.flags & UNET_CONV_RELU;
+    const int OS = a.OS;
+    const size_t img_pix = (size_t)img * a.OH * a.OW;
+    const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
+    const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+    int pidx[M16];
+    bool pval[M16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m) {
+        const int pix = (wm * M16 + m) * 16 + l15;
+        const int ty = pix / TW, tx = pix % TW;
+        const int oyt = oy0 + ty, oxt = ox0 + tx;
+        const int oy = oyt * OS + ts.py, ox = oxt * OS + ts.px;
+        pval[m] = oyt < a.TSH && oxt < a.TSW && oy < a.OH && ox < a.OW;
+        pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
+    }
+#pragma unroll
+    for (int n = 0; n < N16; ++n) {
+        if (n >= nvalid) continue;
+        const int c4 = n0 + (n * WN + wn) * 16 + 4 * kq;
+        const bool cvalid = c4 < a.n_end;       // channels c4..c4+3 beyond Cout (Cout % 4 != 0) are zero filters: zeros land in pad lanes
+        const int cc = cvalid ? c4 : 0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && cvalid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (c4 + r < a.Cout) ? a.bias[c4 + r] : 0.f;
+        }
+        f32x4 v[M16];
+#pragma unroll
+        for (int m = 0; m < M16; ++m) v[m] = acc[m][n] + bv;
+        if (resb != nullptr) {
+            f32x4 rv[M16];
+#pragma unroll
+            for (int m = 0; m < M16; ++m) rv[m] = ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+#pragma unroll
+            for (int m = 0; m < M16; ++m) v[m] += rv[m];
+        }
+        if (relu) {
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.f);
+        }
+        if (maskb != nullptr) {
+            f32x4 mv[M16];
+#pragma unroll
+            for (int m = 0; m < M16; ++m) mv[m] = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = mv[m][r] > 0.f ? v[m][r] : 0.f;
+        }
+        if (y_f32) {
+            float* yb = a.y + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+                if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
+        } else {
+            u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+                if (cvalid && pval[m]) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
+        }
+    }
+}
+
+// packed filter image wp[tap][chunk][o][32] (bf16) from the fp32 master parameter [Cout,Cin,ks,ks]
+//   mode 0: o = cout, reduction r = cin;  mode 1 (input gradient): o = cin, reduction r = cout
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin, int T, int mode, int nchunks,
+                                         int outPad, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i & 31);
+        size_t j = i >> 5;
+        const int o = (int)(j % outPad); j /= outPad;
+        const int chunk = (int)(j % nchunks);
+        const int tap = (int)(j / nchunks);
+        const int r = chunk * 32 + rr;
+        float v = 0.f;
+        if (mode == 0) {
+            if (o < Cout && r < Cin) v = w[((size_t)o * Cin + r) * T + tap];
+        } else {
+            if (o < Cin && r < Cout) v = w[((size_t)r * Cin + o) * T + tap];
+        }
+        wp[i] = __builtin_bit_cast(u16, (__bf16)v);
+    }
+}
+
+template <int TW, int MT, int NT, int WM, int WN, int HIT>
+int launch_cfg(const Plan& p, int y_f32, hipStream_t st) {
+    auto kern = conv_bf16_kernel<TW, MT, NT, WM, WN, HIT>;
+    static unsigned long long configured = 0;  // per instantiation, one bit per device
+    if (unet::first_use_on_device(&configured))
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k, y_f32);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+template <int TW, int HIT>
+int launch_bn(const Plan& p, int y_f32, hipStream_t st) {
+    if (p.bm == 64) {
+        if (p.bn == 64) return launch_cfg<TW, 1, 1, 2, 2, HIT>(p, y_f32, st);
+        return launch_cfg<TW, 1, 2, 2, 2, HIT>(p, y_f32, st);
+    }
+    switch (p.bn) {
+        case 32: return launch_cfg<TW, 1, 1, 4, 1, HIT>(p, y_f32, st);
+        case 64: return launch_cfg<TW, 2, 1, 2, 2, HIT>(p, y_f32, st);
+        default: return launch_cfg<TW, 2, 2, 2, 2, HIT>(p, y_f32, st);
+    }
+}
+
+template <int HIT>
+int launch_tw(const Plan& p, int y_f32, hipStream_t st) {
+    switch (p.tw) {
+        case 32: return launch_bn<32, HIT>(p, y_f32, st);
+        case 16: return launch_bn<16, HIT>(p, y_f32, st);
+        default: return launch_bn<8, HIT>(p, y_f32, st);
+    }
+}
+
+int plan_bf16(const unet_conv_desc* d, Plan* p) {
+    int rc = unetconv::make_plan(d, p, KCB, 8, 16);
+    if (rc != UNET_OK) return rc;
+    UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
+    UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
+    UNET_CHECK_ARG(unet::aligned16(d->y) && (!d->res || unet::aligned16(d->res)) && (!d->mask || unet::aligned16(d->mask)),
+                   "conv bf16: y/res/mask must be 16-byte aligned");
+    return UNET_OK;
+}
+
+}  // namespace
+
+namespace unetconv {
+
+int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
+    Plan p;
+    int rc = plan_bf16(d, &p);
+    if (rc != UNET_OK) return rc;
+    return (p.hit == 10) ? launch_tw<10>(p, d->y_f32, st) : launch_tw<4>(p, d->y_f32, st);
+}
+
+int conv2d_bf16_variant(const unet_conv_desc* d) {
+    Plan p;
+    int rc = plan_bf16(d, &p);
+    if (rc != UNET_OK) return rc;
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0);
+}
+
+}  // namespace unetconv
+
+extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode) {
+    const int T = ks * ks;
+    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    return (size_t)T * unet::cdiv(red, KCB) * unet::roundup(out, 128) * KCB;
+}
+
+extern "C" int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream) {
+    UNET_CHECK_ARG(w && wp, "pack_weights_bf16: null pointer");
+    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1) && Cout > 0 && Cin > 0, "pack_weights_bf16: bad args");
+    const int T = ks * ks;
+    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int nchunks = unet::cdiv(red, KCB), outPad = unet::roundup(out, 128);
+    const size_t total = (size_t)T * nchunks * outPad * KCB;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout,
+                       Cin, T, mode, nchunks, outPad, total);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}

@@ -22,38 +22,16 @@
 // Replaces the ATen conv kernels behind fastai ConvLayer (layers.py) as used by
 // XResNet / DynamicUnet built at reference train.py:128-144.
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
+
+using namespace unetconv;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 16;   // reduction channels per chunk
-constexpr int LDK = 20;  // LDS row length in floats (16 + 4 pad); 24 would make the 16x16x4 operand reads conflict-free, measured no gain
 
-struct TapSet {
-    int n;              // number of taps
-    int min_dy, min_dx; // halo origin offset (input coords relative to tile origin * S)
-    int ext_y, ext_x;   // halo extent beyond (T-1)*S
-    int py, px;         // output parity offsets (OS == 2)
-    signed char dy[9], dx[9], widx[9];
-    // the same tables packed 4 bits per tap for scalar decoding (16x16x4 kernel): dpack nibble t = (dy - min_dy) | (dx - min_dx) << 2,
-    // wpack nibble t = widx
-    unsigned long long dpack, wpack;
-};
-
-struct KArgs {
-    const float* x; const float* wp; const float* bias; const float* res; const float* mask;
-    float* y; float* colsum; float* colsumsq;
-    int x_cs, x_co, res_cs, res_co, mask_cs, mask_co, y_cs, y_co;
-    int N, IH, IW, Cin, Cin4;
-    int OH, OW, Cout;
-    int S, OS, TSH, TSW, tiles_y, tiles_x, ntn;
-    int nchunks, coutPad, flags, mtiles;
-    int n_base, n_end;   // produced-channel range of this launch (unet_conv_desc.cout_begin / cout_count); n_end <= Cout
-    long long wp_stride; // floats between the packed filter images of consecutive batch images (0: one image for all)
-    TapSet taps[4];
-};
 
 template <int HIT, int NTH>
 __device__ __forceinline__ void ld_halo(float4 (&hreg)[HIT], const int (&goff)[HIT], const float* xb, int c0, int Cin4, int tid) {
@@ -311,85 +289,6 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
             }
         }
     }
-}
-
-// ---- explicitly scheduled global loads for the 16x16x4 kernel -------------------------------------------------
-// The compiler's s_waitcnt insertion merges the wait state of conditional loads conservatively (it drained vmcnt to 0 in
-// the middle of the MFMA stream: a full L2 round trip per stage).  The main loop therefore issues its loads as inline asm
-// (SGPR base + 32-bit lane offset) and places the vmcnt waits itself; vmcnt counts in issue order, and every path issues a
-// fixed number of loads per stage (invalid items load from a clamped, always addressable offset and are zeroed later).
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
-// wave-uniform pointer -> SGPR pair for the saddr form.  The leading s_nop 4 of every load group covers the "VALU writes
-// SGPR -> VMEM reads it" hazard (5 wait states): the compiler's hazard recognizer does not look inside inline asm.
-__device__ __forceinline__ u64 sgpr_ptr(const void* p) {
-    const u64 b = reinterpret_cast<u64>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    return ((u64)hi << 32) | lo;
-}
-// operand-B tiles of one stage: tiles 0/1 at p + {0, TSTR}, tiles 2/3 at p + 2*TSTR + {0, TSTR}; one lane offset
-template <int TSTR, int N>
-__device__ __forceinline__ void gld_b(v4f (&d)[N], unsigned voff, const char* p) {
-    static_assert(N == 2 || N == 4, "operand-B tiles per wave");
-    const u64 s0 = sgpr_ptr(p);
-    if constexpr (N == 2) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:%4"
-                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(voff), "s"(s0), "n"(TSTR));
-    } else {
-        const u64 s1 = sgpr_ptr(p + 2 * TSTR);
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:%7\n\t"
-                     "global_load_dwordx4 %2, %4, %6\n\tglobal_load_dwordx4 %3, %4, %6 offset:%7"
-                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(voff), "s"(s0), "s"(s1), "n"(TSTR));
-    }
-}
-// The halo items of one chunk: one base, one lane offset per item.  Executed in EVERY stage with `on` = all ones (fetch) or
-// 0 (EXEC is cleared around the loads: nothing is fetched, the registers keep their values).  For the compiler the halo
-// registers are thus one unbroken chain of tied asm operands -- no conditional definition, no phi, hence no register copy
-// it could schedule between a load and its wait.
-template <int N>
-__device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], const void* p, bool fetch) {
-    static_assert(N == 4 || N == 10, "halo items per thread");
-    const u64 sb = sgpr_ptr(p);
-    const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
-    u64 sv;
-    if constexpr (N == 4) {
-        asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
-                     "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
-                     "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [sv] "=&s"(sv)
-                     : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [sb] "s"(sb), [on] "s"(on)
-                     : "scc");   // s_and_saveexec writes SCC
-    } else {
-        asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
-                     "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
-                     "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
-                     "global_load_dwordx4 %[h4], %[o4], %[sb]\n\tglobal_load_dwordx4 %[h5], %[o5], %[sb]\n\t"
-                     "global_load_dwordx4 %[h6], %[o6], %[sb]\n\tglobal_load_dwordx4 %[h7], %[o7], %[sb]\n\t"
-                     "global_load_dwordx4 %[h8], %[o8], %[sb]\n\tglobal_load_dwordx4 %[h9], %[o9], %[sb]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]),
-                       [h6] "+v"(h[6]), [h7] "+v"(h[7]), [h8] "+v"(h[8]), [h9] "+v"(h[9]), [sv] "=&s"(sv)
-                     : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]),
-                       [o6] "v"(vo[6]), [o7] "v"(vo[7]), [o8] "v"(vo[8]), [o9] "v"(vo[9]), [sb] "s"(sb), [on] "s"(on)
-                     : "scc");   // s_and_saveexec writes SCC
-    }
-}
-// s_waitcnt vmcnt(0) that also "defines" every register the outstanding loads write (operand-B tiles and halo items), so
-// that no consumer is scheduled above it
-template <int NB, int NH>
-__device__ __forceinline__ void wait_loads(v4f (&b)[NB], v4f (&h)[NH]) {
-    static_assert((NB == 2 || NB == 4) && (NH == 4 || NH == 10), "register groups");
-    // ONE statement (a tied operand's input copy, if the compiler ever made one, must not be able to slip in front of the
-    // s_waitcnt of a sibling statement); 14 tied operands = 28 of the 30 asm operands allowed
-#define UNET_H4 "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
-#define UNET_H10 UNET_H4, "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]), "+v"(h[8]), "+v"(h[9])
-    if constexpr (NB == 2 && NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H4);
-    else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H10);
-    else if constexpr (NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H4);
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H10);
-#undef UNET_H4
-#undef UNET_H10
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,153 +619,8 @@ __global__ void pack_weights_strided_kernel(const float* __restrict__ w, long lo
 // MFMA shape of the conv kernels: 16 = v_mfma_f32_16x16x4_f32 with per-tile skipping (default), 32 = v_mfma_f32_32x32x2_f32
 static int g_mfma_shape = 16;
 
-struct Plan {
-    KArgs k;
-    int tw, bm, bn, hit, nparity, mf;
-    size_t lds_bytes;
-    dim3 grid;
-};
+static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_plan(d, p, KC, 4, g_mfma_shape); }
 
-int make_plan(const unet_conv_desc* d, Plan* p) {
-    UNET_CHECK_ARG(d != nullptr, "conv: null desc");
-    UNET_CHECK_ARG(d->x && d->wp && d->y, "conv: null tensor pointer");
-    UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv: ks must be 1 or 3 (got %d)", d->ks);
-    UNET_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
-    UNET_CHECK_ARG(!(d->ks == 1 && d->stride != 1), "conv: 1x1 stride 2 unsupported");
-    UNET_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH > 0 && d->OW > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims");
-    UNET_CHECK_ARG(unet::slice_ok(d->x_cs, d->x_co, d->Cin), "conv: bad x slice cs=%d co=%d C=%d", d->x_cs, d->x_co, d->Cin);
-    UNET_CHECK_ARG(unet::slice_ok(d->y_cs, d->y_co, d->Cout), "conv: bad y slice cs=%d co=%d C=%d", d->y_cs, d->y_co, d->Cout);
-    UNET_CHECK_ARG(unet::aligned16(d->x) && unet::aligned16(d->wp), "conv: x/wp must be 16-byte aligned");
-    if (d->res) UNET_CHECK_ARG(unet::slice_ok(d->res_cs, d->res_co, d->Cout), "conv: bad res slice");
-    if (d->flags & UNET_CONV_MASK) UNET_CHECK_ARG(d->mask && unet::slice_ok(d->mask_cs, d->mask_co, d->Cout), "conv: bad mask slice");
-    const int pad = (d->ks - 1) / 2;
-    if (d->kind == UNET_CONV_FWD) {
-        UNET_CHECK_ARG(d->OH == (d->IH + 2 * pad - d->ks) / d->stride + 1 && d->OW == (d->IW + 2 * pad - d->ks) / d->stride + 1,
-                       "conv fwd: output dims %dx%d inconsistent with input %dx%d ks %d stride %d", d->OH, d->OW, d->IH, d->IW, d->ks, d->stride);
-    } else if (d->kind == UNET_CONV_DGRAD) {
-        // here I* = dims of the forward OUTPUT gradient, O* = dims of the forward INPUT
-        UNET_CHECK_ARG(d->IH == (d->OH + 2 * pad - d->ks) / d->stride + 1 && d->IW == (d->OW + 2 * pad - d->ks) / d->stride + 1,
-                       "conv dgrad: grad dims %dx%d inconsistent with input dims %dx%d", d->IH, d->IW, d->OH, d->OW);
-    } else {
-        UNET_CHECK_ARG(false, "conv: bad kind %d", d->kind);
-    }
-    // the image-local offsets are 32-bit
-    UNET_CHECK_ARG((long long)d->IH * d->IW * d->x_cs < (1ll << 31) && (long long)d->OH * d->OW * d->y_cs < (1ll << 31) &&
-                       (long long)d->OH * d->OW * (d->res ? d->res_cs : 1) < (1ll << 31) &&
-                       (long long)d->OH * d->OW * ((d->flags & UNET_CONV_MASK) ? d->mask_cs : 1) < (1ll << 31),
-                   "conv: image too large for 32-bit in-image offsets");
-
-    KArgs& k = p->k;
-    memset(&k, 0, sizeof(k));
-    k.x = d->x; k.wp = d->wp; k.bias = d->bias; k.res = d->res; k.mask = (d->flags & UNET_CONV_MASK) ? d->mask : nullptr;
-    k.y = d->y; k.colsum = d->colsum; k.colsumsq = d->colsumsq;
-    k.x_cs = d->x_cs; k.x_co = d->x_co; k.res_cs = d->res_cs; k.res_co = d->res_co;
-    k.mask_cs = d->mask_cs; k.mask_co = d->mask_co; k.y_cs = d->y_cs; k.y_co = d->y_co;
-    k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, 4);
-    k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
-    // optional produced-channel range (a wide layer can be issued as several launches with different channel-block widths)
-    const int cols = d->cout_count > 0 ? d->cout_count : d->Cout;
-    UNET_CHECK_ARG(d->cout_begin >= 0 && (d->cout_begin & 15) == 0 && d->cout_begin + cols <= d->Cout, "conv: bad cout range [%d,+%d) of %d",
-                   d->cout_begin, cols, d->Cout);
-    k.n_base = d->cout_begin; k.n_end = d->cout_begin + cols;
-    UNET_CHECK_ARG(d->wp_img_stride >= 0 && (d->wp_img_stride & 3) == 0, "conv: bad wp_img_stride");
-    k.wp_stride = d->wp_img_stride;
-    k.flags = d->flags;
-    k.nchunks = unet::cdiv(d->Cin, KC);
-    k.coutPad = unet::roundup(d->Cout, 128);
-    p->nparity = 1;
-    k.S = 1; k.OS = 1; k.TSH = d->OH; k.TSW = d->OW;
-
-    const int T = d->ks * d->ks;
-    if (d->kind == UNET_CONV_FWD) {
-        k.S = d->stride;
-        TapSet& t = k.taps[0];
-        t.n = T; t.min_dy = -pad; t.min_dx = -pad; t.ext_y = d->ks; t.ext_x = d->ks; t.py = t.px = 0;
-        for (int r = 0; r < d->ks; ++r)
-            for (int s = 0; s < d->ks; ++s) {
-                const int i = r * d->ks + s;
-                t.dy[i] = (signed char)(r - pad); t.dx[i] = (signed char)(s - pad); t.widx[i] = (signed char)i;
-            }
-    } else if (d->stride == 1) {
-        TapSet& t = k.taps[0];
-        t.n = T; t.min_dy = -pad; t.min_dx = -pad; t.ext_y = d->ks; t.ext_x = d->ks; t.py = t.px = 0;
-        for (int r = 0; r < d->ks; ++r)
-            for (int s = 0; s < d->ks; ++s) {
-                const int i = r * d->ks + s;
-                t.dy[i] = (signed char)(pad - r); t.dx[i] = (signed char)(pad - s); t.widx[i] = (signed char)i;
-            }
-    } else {
-        // stride-2 3x3 pad-1 dgrad: 4 output parity classes.  Output row 2*o+py receives
-        //   py = 0: r = 1 from grad row o        py = 1: r = 0 from grad row o+1, r = 2 from grad row o
-        k.OS = 2; k.TSH = (d->OH + 1) / 2; k.TSW = (d->OW + 1) / 2;
-        p->nparity = 4;
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px) {
-                TapSet& t = k.taps[py * 2 + px];
-                int rs[2], rdy[2], nr, ss[2], sdx[2], ns;
-                if (py == 0) { nr = 1; rs[0] = 1; rdy[0] = 0; } else { nr = 2; rs[0] = 0; rdy[0] = 1; rs[1] = 2; rdy[1] = 0; }
-                if (px == 0) { ns = 1; ss[0] = 1; sdx[0] = 0; } else { ns = 2; ss[0] = 0; sdx[0] = 1; ss[1] = 2; sdx[1] = 0; }
-                t.n = nr * ns; t.min_dy = 0; t.min_dx = 0; t.ext_y = (py == 0) ? 1 : 2; t.ext_x = (px == 0) ? 1 : 2;
-                t.py = py; t.px = px;
-                int i = 0;
-                for (int a = 0; a < nr; ++a)
-                    for (int b = 0; b < ns; ++b, ++i) {
-                        t.dy[i] = (signed char)rdy[a]; t.dx[i] = (signed char)sdx[b]; t.widx[i] = (signed char)(rs[a] * 3 + ss[b]);
-                    }
-            }
-    }
-
-    for (int z = 0; z < p->nparity; ++z) {
-        TapSet& t = k.taps[z];
-        t.dpack = 0; t.wpack = 0;
-        for (int i = 0; i < t.n; ++i) {
-            const int dyi = t.dy[i] - t.min_dy, dxi = t.dx[i] - t.min_dx;
-            UNET_CHECK_ARG(dyi >= 0 && dyi < 4 && dxi >= 0 && dxi < 4 && t.widx[i] >= 0 && t.widx[i] < 16, "conv: tap table out of range");
-            t.dpack |= (unsigned long long)(dyi | (dxi << 2)) << (4 * i);
-            t.wpack |= (unsigned long long)t.widx[i] << (4 * i);
-        }
-    }
-
-    p->tw = k.TSW >= 32 ? 32 : (k.TSW >= 16 ? 16 : 8);
-    p->bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
-    p->bm = 128;
-    p->hit = (k.S == 2) ? 10 : 4;
-    p->mf = g_mfma_shape;
-    // small problems (deep 16x16 / 32x32 stages): shrink the tile until the grid can fill 256 CUs x 2
-    auto blocks = [&](int bm, int bn) {
-        const int th_ = bm / p->tw;
-        return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(cols, bn) * p->nparity;
-    };
-    if (p->bn >= 64 && blocks(128, p->bn) < 400) {
-        p->bm = 64;
-        if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
-    }
-    const int th = p->bm / p->tw;
-    k.tiles_y = unet::cdiv(k.TSH, th);
-    k.tiles_x = unet::cdiv(k.TSW, p->tw);
-    k.ntn = unet::cdiv(cols, p->bn);
-    UNET_CHECK_ARG(k.n_base + k.ntn * p->bn <= k.coutPad, "conv: cout range leaves the packed filter image");
-    // in-image element offsets are 32-bit inside the kernels (the image index is applied in 64 bits)
-    UNET_CHECK_ARG((long long)d->IH * d->IW * d->x_cs < (1ll << 31) && (long long)d->OH * d->OW * d->y_cs < (1ll << 31) &&
-                   (d->res == nullptr || (long long)d->OH * d->OW * d->res_cs < (1ll << 31)) &&
-                   (d->mask == nullptr || (long long)d->OH * d->OW * d->mask_cs < (1ll << 31)),
-                   "conv: one image of a tensor exceeds 2^31 elements");
-    const long long mtiles_ll = (long long)d->N * k.tiles_y * k.tiles_x;
-    UNET_CHECK_ARG(mtiles_ll * k.ntn < (1ll << 31) - 8, "conv: grid too large (%lld pixel tiles x %d channel blocks)", mtiles_ll, k.ntn);
-    k.mtiles = (int)mtiles_ll;
-    int max_hpix = 0;
-    for (int z = 0; z < p->nparity; ++z) {
-        const int hh = (th - 1) * k.S + k.taps[z].ext_y, hw = (p->tw - 1) * k.S + k.taps[z].ext_x;
-        if (hh * hw > max_hpix) max_hpix = hh * hw;
-    }
-    UNET_CHECK_ARG(max_hpix * 4 <= p->hit * 256, "conv: halo tile too large (%d pixels)", max_hpix);
-    // the 16x16x4 kernel keeps no filter slab in LDS (operand B goes global -> VGPR)
-    p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + (p->mf == 16 ? 0 : 2 * p->bn * LDK)) * sizeof(float);
-    // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
-    p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), 1, (unsigned)p->nparity);
-    UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");
-    return UNET_OK;
-}
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
 int launch_cfg(const Plan& p, hipStream_t st) {
@@ -927,6 +681,7 @@ extern "C" int unet_set_mfma_shape(int shape) {
 }
 
 extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
+    if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16_variant(d);
     Plan p;
     int rc = make_plan(d, &p);
     if (rc != UNET_OK) return rc;
@@ -934,6 +689,8 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
 }
 
 extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
+    if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16(d, (hipStream_t)stream);
+    UNET_CHECK_ARG(d == nullptr || d->dtype == UNET_F32, "conv: unknown dtype %d", d->dtype);
     Plan p;
     int rc = make_plan(d, &p);
     if (rc != UNET_OK) return rc;

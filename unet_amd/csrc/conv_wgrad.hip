@@ -515,6 +515,153 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16-storage weight gradient: x and dy are bf16 NHWC, products are accumulated in fp32 (v_mfma_f32_16x16x32_bf16), partials and
+// dW are fp32.  The reduction runs over PIXELS, which are the strided dimension of NHWC: both MFMA operands are K-major reads of a
+// row-major [pixel][channel] LDS image -- exactly what ds_read_b64_tr_b16 delivers (a 4-pixel x 16-channel block, column-major,
+// per 16-lane group).  MFMA k index -> pixel: lane group g reads pixels {4g..4g+3} and {16+4g..16+4g+3} of the 32-pixel tile
+// (the same map for both operands), so that the two groups of a 32-lane half touch 8 CONSECUTIVE pixel rows: with a row stride
+// of 160 bytes (stride-2 inputs: 144) they fall into 8 disjoint 32-byte bank windows -- conflict-free.
+//   A[row = k][kk] = dy[pixel(kk)][k0 + 16 mt + row]     B[kk][col = c] = x[pixel(kk) shifted by tap][c0 + 16 nt + col]
+//   D[row = 4(l>>4) + r][col = l&15] -> dW partial [tap][k][c]
+// Workgroup = 64 output x 64 input channels x all taps (each wave 2 x 2 tiles of 16 x 16 per tap: 144 accumulator VGPRs for 3x3),
+// split-K over pixel tiles, second-stage sum by wgrad_reduce_kernel as in the fp32 path.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ bf16x8 ld_tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int PTW, int S, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
+    constexpr int PT = 32, PTH = PT / PTW, PAD = (KS - 1) / 2, T = KS * KS;
+    constexpr int HH = (PTH - 1) * S + KS, HW = (PTW - 1) * S + KS, HPIX = HH * HW;
+    constexpr int RSD = 160, RSX = (S == 1) ? 160 : 144;         // LDS row strides in bytes (64 channels = 128 bytes + pad)
+    constexpr int XIT = (HPIX * 8 + 255) / 256;                  // 16-byte x items per thread
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smemb[];
+    char* dyT = smemb;                      // [PT][RSD]
+    char* xh = smemb + PT * RSD;            // [HPIX][RSX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = l15 & 3;
+    const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
+    const int k0 = kblk * BK, c0 = cblk * BC;
+    const int split = blockIdx.y;
+    const int tile_begin = split * a.tiles_per_block;
+    int tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+
+    f32x4 acc[2][2][T];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[i][j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const u16* xg = reinterpret_cast<const u16*>(a.x);
+    const u16* dyg = reinterpret_cast<const u16*>(a.dy);
+    auto stage_tile = [&](int tile) {
+        int b = tile;
+        const int tx = b % a.tiles_x; b /= a.tiles_x;
+        const int ty = b % a.tiles_y;
+        const int img = b / a.tiles_y;
+        const int oy0 = ty * PTH, ox0 = tx * PTW;
+        const u16* dyb = dyg + (size_t)img * a.OH * a.OW * a.dy_cs;
+        const u16* xb = xg + (size_t)img * a.IH * a.IW * a.x_cs;
+        {   // dy tile: 32 pixels x 8 items of 8 channels = one 16-byte item per thread
+            const int p = tid >> 3, qq = tid & 7;
+            const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
+            const bool ok = oy < a.OH && ox < a.OW && (k0 + 8 * qq) < a.Cout4;
+            const uint4 v = ok ? *reinterpret_cast<const uint4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 8 * qq)
+                               : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(dyT + p * RSD + qq * 16) = v;
+        }
+        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+        uint4 r[XIT];
+#pragma unroll
+        for (int j = 0; j < XIT; ++j) {
+            const int e = tid + j * 256;
+            const int p = e >> 3, qq = e & 7;
+            const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+            const bool ok = (e < HPIX * 8) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 8 * qq) < a.Cin4;
+            r[j] = ok ? *reinterpret_cast<const uint4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 8 * qq) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < XIT; ++j) {
+            const int e = tid + j * 256;
+            if (e < HPIX * 8) *reinterpret_cast<uint4*>(xh + (e >> 3) * RSX + (e & 7) * 16) = r[j];
+        }
+    };
+
+    // per-lane transposed-read addresses: this lane supplies pixel row P1 = 4g + q (first read) / P2 = 16 + 4g + q (second), columns 4pp..4pp+3
+    const int P1 = 4 * g + q, P2 = 16 + 4 * g + q;
+    const char* a1 = dyT + P1 * RSD + (wk * 32 + 4 * pp) * 2;
+    const char* a2 = dyT + P2 * RSD + (wk * 32 + 4 * pp) * 2;
+    const int xr1 = ((P1 / PTW) * S * HW + (P1 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
+    const int xr2 = ((P2 / PTW) * S * HW + (P2 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
+    // which of this wave's 2 x 2 tiles hold real channels (wave-uniform)
+    const bool mv1 = k0 + wk * 32 + 16 < a.Cout, nv1 = c0 + wc * 32 + 16 < a.Cin;
+    const bool mv0 = k0 + wk * 32 < a.Cout, nv0 = c0 + wc * 32 < a.Cin;
+
+    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
+    float bsum = 0.f;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        stage_tile(tile);
+        __syncthreads();
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) bsum += __uint_as_float((unsigned)*reinterpret_cast<const u16*>(dyT + p * RSD + tid * 2) << 16);
+        }
+        if (mv0 && nv0) {
+            const bf16x8 av0 = ld_tr_pair(a1, a2);
+            const bf16x8 av1 = ld_tr_pair(a1 + 32, a2 + 32);
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const int t = r * KS + s_;
+                    const int off = (r * HW + s_) * RSX;
+                    const bf16x8 bv0 = ld_tr_pair(xh + xr1 + off, xh + xr2 + off);
+                    acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv0, acc[0][0][t], 0, 0, 0);
+                    if (mv1) acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv0, acc[1][0][t], 0, 0, 0);
+                    if (nv1) {
+                        const bf16x8 bv1 = ld_tr_pair(xh + xr1 + off + 32, xh + xr2 + off + 32);
+                        acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv1, acc[0][1][t], 0, 0, 0);
+                        if (mv1) acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv1, acc[1][1][t], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    const size_t KC_ = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)split * T * KC_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 32 + 16 * j + l15;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = k0 + wk * 32 + 16 * i + 4 * g + r;
+                    if (k < a.Cout && c < a.Cin) pb[(size_t)t * KC_ + (size_t)k * a.Cin + c] = acc[i][j][t][r];
+                }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 weight gradient = a plain GEMM dW[k][c] = sum_p dy[p][k] x[p][c] over FLAT pixels (PixelShuffle_ICNR convs,
 // identity-path convs, head, self-attention products).  The 64x64-tiled kernel stages 512 B per pixel for 8 kFLOP
 // (L2->LDS bound, ~46 TFLOP/s); here a workgroup owns 128 x 128 channels (each wave 64 x 64 = 2x2 MFMA tiles, 64
@@ -745,7 +892,7 @@ static int g_wgrad_1x1 = 1;           // 128x128-tiled GEMM kernel for 1x1 weigh
 
 struct WPlan {
     WArgs k;
-    int ptw, splits, T, narrow, gemm1x1, small1x1, ps;
+    int ptw, splits, T, narrow, gemm1x1, small1x1, ps, bf16;
     long long pix_per_block;
     size_t lds_bytes, lds_bytes16;
 };
@@ -761,18 +908,21 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     const int pad = (d->ks - 1) / 2;
     UNET_CHECK_ARG(d->OH == (d->IH + 2 * pad - d->ks) / d->stride + 1 && d->OW == (d->IW + 2 * pad - d->ks) / d->stride + 1,
                    "wgrad: output dims inconsistent");
-    UNET_CHECK_ARG(unet::slice_ok(d->x_cs, d->x_co, d->Cin), "wgrad: bad x slice");
-    UNET_CHECK_ARG(unet::slice_ok(d->dy_cs, d->dy_co, d->Cout), "wgrad: bad dy slice");
+    UNET_CHECK_ARG(d->dtype == UNET_F32 || d->dtype == UNET_BF16, "wgrad: unknown dtype %d", d->dtype);
+    const int vec = d->dtype == UNET_BF16 ? 8 : 4;
+    p->bf16 = d->dtype == UNET_BF16;
+    UNET_CHECK_ARG(unet::slice_ok_v(d->x_cs, d->x_co, d->Cin, vec), "wgrad: bad x slice");
+    UNET_CHECK_ARG(unet::slice_ok_v(d->dy_cs, d->dy_co, d->Cout, vec), "wgrad: bad dy slice");
     UNET_CHECK_ARG(unet::aligned16(d->x) && unet::aligned16(d->dy), "wgrad: x/dy must be 16-byte aligned");
     WArgs& k = p->k;
     memset(&k, 0, sizeof(k));
     k.x = d->x; k.dy = d->dy; k.part = d->workspace;
     k.x_cs = d->x_cs; k.x_co = d->x_co; k.dy_cs = d->dy_cs; k.dy_co = d->dy_co;
-    k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, 4);
-    k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cout4 = unet::roundup(d->Cout, 4);
+    k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, vec);
+    k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cout4 = unet::roundup(d->Cout, vec);
     p->T = d->ks * d->ks;
     p->ptw = d->OW >= 32 ? 32 : (d->OW >= 16 ? 16 : 8);
-    const int pt = d->stride == 1 ? 64 : 32;
+    const int pt = (d->stride == 1 && !p->bf16) ? 64 : 32;      // bf16: one MFMA k-block of 32 pixels per tile
     const int pth = pt / p->ptw;
     k.tiles_y = unet::cdiv(d->OH, pth);
     k.tiles_x = unet::cdiv(d->OW, p->ptw);
@@ -780,7 +930,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.kt = unet::cdiv(d->Cout, BK);
     k.ct = unet::cdiv(d->Cin, BC);
     // narrow-output specialisation (taps flattened into the column dimension): only where the 64x64-tiled kernel pads
-    p->narrow = (g_wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 80 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
+    p->narrow = (!p->bf16 && g_wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 80 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
     int cols = k.kt * k.ct;
     if (p->narrow) {
         p->ptw = 32;
@@ -794,7 +944,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         cols = nch * k.nnb;
     }
     // heads: 1x1 with <= 16 output channels and <= 1024 input channels -> FMA kernel, one partial row per (workgroup, pixel lane)
-    p->small1x1 = (d->ks == 1 && d->Cout <= 16 && k.Cin4 <= 512 && g_wgrad_1x1) ? 1 : 0;
+    p->small1x1 = (!p->bf16 && d->ks == 1 && d->Cout <= 16 && k.Cin4 <= 512 && g_wgrad_1x1) ? 1 : 0;
     p->ps = 1; p->pix_per_block = 0;
     if (p->small1x1) {
         const long long P = (long long)d->N * d->OH * d->OW;
@@ -814,7 +964,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         p->lds_bytes = p->lds_bytes16 = 0;
         return UNET_OK;
     }
-    p->gemm1x1 = (d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
+    p->gemm1x1 = (!p->bf16 && d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
     if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
         k.kt = unet::cdiv(d->Cout, 128);
         k.ct = unet::cdiv(d->Cin, 128);
@@ -834,6 +984,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     const int hh = (pth - 1) * d->stride + d->ks, hw = (p->ptw - 1) * d->stride + d->ks;
     p->lds_bytes = (size_t)(pt * BK + hh * hw * BC) * sizeof(float);
     p->lds_bytes16 = (size_t)(pt + hh * hw) * (d->stride == 1 ? 80 : 72) * sizeof(float);
+    if (p->bf16) p->lds_bytes = (size_t)pt * 160 + (size_t)hh * hw * (d->stride == 1 ? 160 : 144);
     return UNET_OK;
 }
 
@@ -862,6 +1013,25 @@ int launch_w(const WPlan& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes, st, p.k);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
+}
+
+template <int PTW, int S, int KS>
+int launch_wb(const WPlan& p, hipStream_t st) {
+    auto kern = wgrad_bf16_kernel<PTW, S, KS>;
+    static unsigned long long configured = 0;   // one bit per device
+    if (unet::first_use_on_device(&configured)) {
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes, st, p.k);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+template <int PTW>
+int launch_wb_ptw(const WPlan& p, int ks, int stride, hipStream_t st) {
+    if (ks == 1) return launch_wb<PTW, 1, 1>(p, st);
+    if (stride == 1) return launch_wb<PTW, 1, 3>(p, st);
+    return launch_wb<PTW, 2, 3>(p, st);
 }
 
 template <int PTW>
@@ -906,7 +1076,13 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
                    d->workspace_floats, need);
     p.k.bpart = d->dbias != nullptr ? d->workspace + npart : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (p.small1x1) {
+    if (p.bf16) {
+        switch (p.ptw) {
+            case 32: rc = launch_wb_ptw<32>(p, d->ks, d->stride, st); break;
+            case 16: rc = launch_wb_ptw<16>(p, d->ks, d->stride, st); break;
+            default: rc = launch_wb_ptw<8>(p, d->ks, d->stride, st); break;
+        }
+    } else if (p.small1x1) {
         const long long P = (long long)d->N * d->OH * d->OW;
         const dim3 grid((unsigned)p.splits);
         const int k4 = (d->Cout + 3) / 4;

@@ -36,6 +36,20 @@ using unet::roundup;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// bf16 storage (unet_bf16 = bfloat16 bit pattern): 4 channels = one 8-byte access; arithmetic is always fp32
+__device__ __forceinline__ float4 ld4(const unet_bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(unet_bf16* p, float4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};          // round to nearest even (v_cvt_pk_bf16_f32)
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float ld1(const unet_bf16* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st1(unet_bf16* p, float v) { *p = __builtin_bit_cast(unet_bf16, (__bf16)v); }
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -94,7 +108,8 @@ static int stats_rows(long long P) {
     return (int)r;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int cs, int co, long long P, int C4, int TC,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int cs, int co, long long P, int C4, int TC,
                                                        float* out0, float* out1, int Cp) {
     channel_reduce(
         [&](long long p, int c4, float4& v0, float4& v1) {
@@ -183,10 +198,11 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float* __restrict__ x2, int x2_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int x_cs, int x_co, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ x2, int x2_cs,
                                                          int x2_co, const float* __restrict__ scale2, const float* __restrict__ shift2,
-                                                         float* __restrict__ y, int y_cs, int y_co, long long P, int C4, int relu) {
+                                                         T* __restrict__ y, int y_cs, int y_co, long long P, int C4, int relu) {
     const long long total = P * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / C4;
@@ -203,9 +219,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, int d_cs, int d_co,
-                                                            const float* __restrict__ out, int o_cs, int o_co,
-                                                            const float* __restrict__ x, int x_cs, int x_co,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int d_cs, int d_co,
+                                                            const T* __restrict__ out, int o_cs, int o_co,
+                                                            const T* __restrict__ x, int x_cs, int x_co,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             long long P, int C4, int TC, float* out0, float* out1, int Cp) {
     channel_reduce(
@@ -230,13 +247,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     c2[c] = (float)(q / count);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int d_cs, int d_co,
-                                                           const float* __restrict__ out, int o_cs, int o_co,
-                                                           const float* __restrict__ x, int x_cs, int x_co,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, int d_cs, int d_co,
+                                                           const T* __restrict__ out, int o_cs, int o_co,
+                                                           const T* __restrict__ x, int x_cs, int x_co,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ c1,
-                                                           const float* __restrict__ c2, float* __restrict__ dx, int dx_cs, int dx_co,
-                                                           float* gout, int g_cs, int g_co, int g_acc, long long P, int C4) {
+                                                           const float* __restrict__ c2, T* __restrict__ dx, int dx_cs, int dx_co,
+                                                           T* gout, int g_cs, int g_co, int g_acc, long long P, int C4) {
     const long long total = P * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / C4;
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float4 r = gm * is * (g - ld4(c1 + c) - xh * ld4(c2 + c));
         st4(dx + (size_t)p * dx_cs + dx_co + c, r);
         if (gout != nullptr) {
-            float* gp = gout + (size_t)p * g_cs + g_co + c;
+            T* gp = gout + (size_t)p * g_cs + g_co + c;
             st4(gp, g_acc ? (ld4(gp) + g) : g);
         }
     }
@@ -257,7 +275,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ------------------------------------------------------------------ pooling
 
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, int x_cs, int x_co, T* __restrict__ y, int y_cs,
                                                       int y_co, uint8_t* __restrict__ idx, int N, int IH, int IW, int C4, int OH, int OW) {
     const long long total = (long long)N * OH * OW * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -290,8 +309,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, const uint8_t* __restrict__ idx,
-                                                          float* __restrict__ dx, int dx_cs, int dx_co, int N, int IH, int IW, int C4,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_co, const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ dx, int dx_cs, int dx_co, int N, int IH, int IW, int C4,
                                                           int OH, int OW, int accumulate) {
     const long long total = (long long)N * IH * IW * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -319,13 +339,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                 if (k.w == code) acc[3] += g.w;
             }
         }
-        float* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
+        T* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
         float4 r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
         st4(dp, accumulate ? (ld4(dp) + r4) : r4);
     }
 }
 
-__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, int x_cs, int x_co, T* __restrict__ y, int y_cs,
                                                       int y_co, int N, int IH, int IW, int C4, int OH, int OW) {
     const long long total = (long long)N * OH * OW * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -351,7 +372,8 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_co, T* __restrict__ dx,
                                                           int dx_cs, int dx_co, int N, int IH, int IW, int C4, int OH, int OW,
                                                           int accumulate) {
     const long long total = (long long)N * IH * IW * C4;
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
         const int ch = (2 * oy + 1 < IH) ? 2 : 1, cw = (2 * ox + 1 < IW) ? 2 : 1;
         const float inv = 1.f / (float)(ch * cw);
         const float4 g = ld4(dy + ((size_t)(n * OH + oy) * OW + ox) * dy_cs + dy_co + c);
-        float* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
+        T* dp = dx + ((size_t)(n * IH + iy) * IW + ix) * dx_cs + dx_co + c;
         float4 r4 = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
         st4(dp, accumulate ? (ld4(dp) + r4) : r4);
     }
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // blur: out[y][x] = mean P[max(y-a,0)][max(x-b,0)], a,b in {0,1}.
 // One thread owns the 2x2 output block of one channel of one low-res pixel: it needs
 // P at rows 2h-1..2h+1, cols 2w-1..2w+1 = yc of 4 low-res neighbours (float4 each).
-__global__ __launch_bounds__(256) void shuffle_blur_kernel(const float* __restrict__ yc, int yc_cs, int yc_co, float* __restrict__ X,
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle_blur_kernel(const T* __restrict__ yc, int yc_cs, int yc_co, T* __restrict__ X,
                                                            int X_cs, int X_co, int N, int h, int w, int Cu, int do_blur) {
     const long long total = (long long)N * h * w * Cu;
     const int H = 2 * h, W = 2 * w;
@@ -407,18 +430,19 @@ __global__ __launch_bounds__(256) void shuffle_blur_kernel(const float* __restri
             o10 = 0.25f * (p[1][0] + p[1][1] + p[2][0] + p[2][1]);
             o11 = 0.25f * (p[1][1] + p[1][2] + p[2][1] + p[2][2]);
         }
-        float* o = X + ((size_t)(n * H + 2 * hh) * W + 2 * ww) * X_cs + X_co + c;
-        o[0] = o00;
-        o[X_cs] = o01;
-        o[(size_t)W * X_cs] = o10;
-        o[(size_t)W * X_cs + X_cs] = o11;
+        T* o = X + ((size_t)(n * H + 2 * hh) * W + 2 * ww) * X_cs + X_co + c;
+        st1(o, o00);
+        st1(o + X_cs, o01);
+        st1(o + (size_t)W * X_cs, o10);
+        st1(o + (size_t)W * X_cs + X_cs, o11);
     }
 }
 
 // adjoint: dyc[h][w][4c+2i+j] = (yc > 0) * dP[2h+i][2w+j][c], dP = blur^T(dX)
-__global__ __launch_bounds__(256) void shuffle_blur_bwd_kernel(const float* __restrict__ dX, int dX_cs, int dX_co,
-                                                               const float* __restrict__ yc, int yc_cs, int yc_co,
-                                                               float* __restrict__ dyc, int dyc_cs, int dyc_co, int N, int h, int w,
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle_blur_bwd_kernel(const T* __restrict__ dX, int dX_cs, int dX_co,
+                                                               const T* __restrict__ yc, int yc_cs, int yc_co,
+                                                               T* __restrict__ dyc, int dyc_cs, int dyc_co, int N, int h, int w,
                                                                int Cu, int do_blur) {
     const long long total = (long long)N * h * w * Cu;
     const int H = 2 * h, W = 2 * w;
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(256) void shuffle_blur_bwd_kernel(const float* __re
         const int hh = (int)(t % h);
         const int n = (int)(t / h);
         auto D = [&](int y, int x) -> float {
-            return (y < H && x < W) ? dX[((size_t)(n * H + y) * W + x) * dX_cs + dX_co + c] : 0.f;
+            return (y < H && x < W) ? ld1(dX + ((size_t)(n * H + y) * W + x) * dX_cs + dX_co + c) : 0.f;
         };
         float g[2][2];
         if (!do_blur) {
@@ -508,13 +532,14 @@ __global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const float* __
 }
 
 // ------------------------------------------------------ layout conversion
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int y_cs, int y_co, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int y_cs, int y_co, int N,
                                                            int C, int H, int W) {
     const long long HW = (long long)H * W, total = (long long)N * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / HW, p = i - n * HW;
-        float* o = y + (size_t)i * y_cs + y_co;
-        for (int c = 0; c < C; ++c) o[c] = x[((size_t)n * C + c) * HW + p];
+        T* o = y + (size_t)i * y_cs + y_co;
+        for (int c = 0; c < C; ++c) st1(o + c, x[((size_t)n * C + c) * HW + p]);
     }
 }
 
@@ -528,14 +553,15 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void copy_slice_kernel(const T* __restrict__ x, int x_cs, int x_co, T* __restrict__ y, int y_cs,
                                                          int y_co, long long P, int C4, int accumulate) {
     const long long total = P * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / C4;
         const int c = 4 * (int)(i - p * C4);
         const float4 v = ld4(x + (size_t)p * x_cs + x_co + c);
-        float* o = y + (size_t)p * y_cs + y_co + c;
+        T* o = y + (size_t)p * y_cs + y_co + c;
         st4(o, accumulate ? (ld4(o) + v) : v);
     }
 }
@@ -592,15 +618,16 @@ __global__ void ce_finalize_kernel(const float* __restrict__ part, int rows, flo
     *denom = (float)d;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const int64_t* __restrict__ target,
                                                      const float* __restrict__ weight, long long P, int C, const float* __restrict__ denom,
-                                                     float gscale, float* __restrict__ dz, int dz_cs, int dz_co) {
+                                                     float gscale, T* __restrict__ dz, int dz_cs, int dz_co) {
     const float inv = gscale / *denom;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
         const long long y = target[p];
-        float* dp = dz + (size_t)p * dz_cs + dz_co;
+        T* dp = dz + (size_t)p * dz_cs + dz_co;
         if (y < 0 || y >= C) {
-            for (int c = 0; c < C; ++c) dp[c] = 0.f;
+            for (int c = 0; c < C; ++c) st1(dp + c, 0.f);
             continue;
         }
         const float* zp = z + (size_t)p * z_cs + z_co;
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
         for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
         const float w = (weight ? weight[y] : 1.f) * inv;
         const float is = 1.f / s;
-        for (int c = 0; c < C; ++c) dp[c] = w * (expf(zp[c] - m) * is - (c == y ? 1.f : 0.f));
+        for (int c = 0; c < C; ++c) st1(dp + c, w * (expf(zp[c] - m) * is - (c == y ? 1.f : 0.f)));
     }
 }
 
@@ -806,14 +833,17 @@ inline bool pslice_ok(int cs, int co, int C) { return unet::slice_ok(cs, co, rou
 
 extern "C" int unet_bn_stats_rows(long long P) { return stats_rows(P); }
 
-extern "C" int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream) {
+template <typename T>
+static int bn_stats_impl(const T* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream) {
     UNET_CHECK_ARG(x && partial && P > 0 && C > 0 && (C & 3) == 0, "bn_stats: bad args (C must be a multiple of 4)");
     UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C), "bn_stats: bad slice");
     const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, partial, partial + (size_t)rows * C, C);
+    hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, partial, partial + (size_t)rows * C, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_bn_stats(const float* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream) { return bn_stats_impl<float>(x, x_cs, x_co, P, C, partial, stream); }
+extern "C" int unet_bn_stats_bf16(const unet_bf16* x, int x_cs, int x_co, long long P, int C, float* partial, void* stream) { return bn_stats_impl<unet_bf16>(x, x_cs, x_co, P, C, partial, stream); }
 
 extern "C" int unet_bn_finalize(const float* psum, const float* psumsq, int rows, long long count, int C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
@@ -834,8 +864,9 @@ extern "C" int unet_bn_eval_coeffs(const float* gamma, const float* beta, const 
     return UNET_OK;
 }
 
-extern "C" int unet_affine_act(const float* x, int x_cs, int x_co, const float* scale, const float* shift, const float* x2, int x2_cs,
-                               int x2_co, const float* scale2, const float* shift2, float* y, int y_cs, int y_co, long long P, int C,
+template <typename T>
+static int affine_act_impl(const T* x, int x_cs, int x_co, const float* scale, const float* shift, const T* x2, int x2_cs,
+                               int x2_co, const float* scale2, const float* shift2, T* y, int y_cs, int y_co, long long P, int C,
                                int relu, void* stream) {
     UNET_CHECK_ARG(x && y && P > 0 && C > 0, "affine_act: bad args");
     UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "affine_act: bad slice");
@@ -843,23 +874,34 @@ extern "C" int unet_affine_act(const float* x, int x_cs, int x_co, const float* 
     UNET_CHECK_ARG((scale == nullptr && scale2 == nullptr) || (C & 3) == 0, "affine_act: per-channel vectors need C % 4 == 0");
     if (x2) UNET_CHECK_ARG(pslice_ok(x2_cs, x2_co, C), "affine_act: bad x2 slice");
     const int C4 = c4of(C);
-    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2,
+    hipLaunchKernelGGL((affine_act_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2,
                        shift2, y, y_cs, y_co, P, C4, relu);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_affine_act(const float* x, int x_cs, int x_co, const float* scale, const float* shift, const float* x2, int x2_cs,
+                               int x2_co, const float* scale2, const float* shift2, float* y, int y_cs, int y_co, long long P, int C,
+                               int relu, void* stream) { return affine_act_impl<float>(x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2, shift2, y, y_cs, y_co, P, C, relu, stream); }
+extern "C" int unet_affine_act_bf16(const unet_bf16* x, int x_cs, int x_co, const float* scale, const float* shift, const unet_bf16* x2, int x2_cs,
+                               int x2_co, const float* scale2, const float* shift2, unet_bf16* y, int y_cs, int y_co, long long P, int C,
+                               int relu, void* stream) { return affine_act_impl<unet_bf16>(x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2, shift2, y, y_cs, y_co, P, C, relu, stream); }
 
-extern "C" int unet_bn_bwd_reduce(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dout, int d_cs, int d_co, const T* out, int o_cs, int o_co, const T* x, int x_cs,
                                   int x_co, const float* mean, const float* invstd, long long P, int C, float* partial, void* stream) {
     UNET_CHECK_ARG(dout && x && mean && invstd && partial && P > 0 && C > 0 && (C & 3) == 0, "bn_bwd_reduce: bad args");
     UNET_CHECK_ARG(unet::slice_ok(d_cs, d_co, C) && unet::slice_ok(x_cs, x_co, C), "bn_bwd_reduce: bad slice");
     if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_reduce: bad out slice");
     const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P,
                        C4, TC, partial, partial + (size_t)rows * C, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_bn_bwd_reduce(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+                                  int x_co, const float* mean, const float* invstd, long long P, int C, float* partial, void* stream) { return bn_bwd_reduce_impl<float>(dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P, C, partial, stream); }
+extern "C" int unet_bn_bwd_reduce_bf16(const unet_bf16* dout, int d_cs, int d_co, const unet_bf16* out, int o_cs, int o_co, const unet_bf16* x, int x_cs,
+                                  int x_co, const float* mean, const float* invstd, long long P, int C, float* partial, void* stream) { return bn_bwd_reduce_impl<unet_bf16>(dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P, C, partial, stream); }
 
 extern "C" int unet_bn_bwd_finalize(const float* partial, int rows, long long count, int C, float* dgamma, float* dbeta, float* c1,
                                     float* c2, void* stream) {
@@ -870,88 +912,127 @@ extern "C" int unet_bn_bwd_finalize(const float* partial, int rows, long long co
     return UNET_OK;
 }
 
-extern "C" int unet_bn_bwd_apply(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+template <typename T>
+static int bn_bwd_apply_impl(const T* dout, int d_cs, int d_co, const T* out, int o_cs, int o_co, const T* x, int x_cs,
                                  int x_co, const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
-                                 float* dx, int dx_cs, int dx_co, float* gout, int g_cs, int g_co, int g_accumulate, long long P, int C,
+                                 T* dx, int dx_cs, int dx_co, T* gout, int g_cs, int g_co, int g_accumulate, long long P, int C,
                                  void* stream) {
     UNET_CHECK_ARG(dout && x && mean && invstd && c1 && c2 && dx && P > 0 && C > 0 && (C & 3) == 0, "bn_bwd_apply: bad args");
     UNET_CHECK_ARG(unet::slice_ok(d_cs, d_co, C) && unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(dx_cs, dx_co, C), "bn_bwd_apply: bad slice");
     if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_apply: bad out slice");
     if (gout) UNET_CHECK_ARG(unet::slice_ok(g_cs, g_co, C), "bn_bwd_apply: bad gout slice");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co,
                        mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C4);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_bn_bwd_apply(const float* dout, int d_cs, int d_co, const float* out, int o_cs, int o_co, const float* x, int x_cs,
+                                 int x_co, const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
+                                 float* dx, int dx_cs, int dx_co, float* gout, int g_cs, int g_co, int g_accumulate, long long P, int C,
+                                 void* stream) { return bn_bwd_apply_impl<float>(dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C, stream); }
+extern "C" int unet_bn_bwd_apply_bf16(const unet_bf16* dout, int d_cs, int d_co, const unet_bf16* out, int o_cs, int o_co, const unet_bf16* x, int x_cs,
+                                 int x_co, const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
+                                 unet_bf16* dx, int dx_cs, int dx_co, unet_bf16* gout, int g_cs, int g_co, int g_accumulate, long long P, int C,
+                                 void* stream) { return bn_bwd_apply_impl<unet_bf16>(dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C, stream); }
 
-extern "C" int unet_maxpool3x3s2(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW,
+template <typename T>
+static int maxpool3x3s2_impl(const T* x, int x_cs, int x_co, T* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW,
                                  int C, int OH, int OW, void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0 && (C & 3) == 0, "maxpool: bad args");
     UNET_CHECK_ARG(OH == (IH + 2 - 3) / 2 + 1 && OW == (IW + 2 - 3) / 2 + 1, "maxpool: bad output dims");
     UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(y_cs, y_co, C), "maxpool: bad slice");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, idx, N,
+    hipLaunchKernelGGL((maxpool_kernel<T>), dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, idx, N,
                        IH, IW, C4, OH, OW);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_maxpool3x3s2(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW,
+                                 int C, int OH, int OW, void* stream) { return maxpool3x3s2_impl<float>(x, x_cs, x_co, y, y_cs, y_co, idx, N, IH, IW, C, OH, OW, stream); }
+extern "C" int unet_maxpool3x3s2_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, uint8_t* idx, int N, int IH, int IW,
+                                 int C, int OH, int OW, void* stream) { return maxpool3x3s2_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, idx, N, IH, IW, C, OH, OW, stream); }
 
-extern "C" int unet_maxpool3x3s2_bwd(const float* dy, int dy_cs, int dy_co, const uint8_t* idx, float* dx, int dx_cs, int dx_co, int N,
+template <typename T>
+static int maxpool3x3s2_bwd_impl(const T* dy, int dy_cs, int dy_co, const uint8_t* idx, T* dx, int dx_cs, int dx_co, int N,
                                      int IH, int IW, int C, int OH, int OW, int accumulate, void* stream) {
     UNET_CHECK_ARG(dy && idx && dx && N > 0 && C > 0 && (C & 3) == 0, "maxpool_bwd: bad args");
     UNET_CHECK_ARG(unet::slice_ok(dy_cs, dy_co, C) && unet::slice_ok(dx_cs, dx_co, C), "maxpool_bwd: bad slice");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, idx, dx, dx_cs,
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, idx, dx, dx_cs,
                        dx_co, N, IH, IW, C4, OH, OW, accumulate);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_maxpool3x3s2_bwd(const float* dy, int dy_cs, int dy_co, const uint8_t* idx, float* dx, int dx_cs, int dx_co, int N,
+                                     int IH, int IW, int C, int OH, int OW, int accumulate, void* stream) { return maxpool3x3s2_bwd_impl<float>(dy, dy_cs, dy_co, idx, dx, dx_cs, dx_co, N, IH, IW, C, OH, OW, accumulate, stream); }
+extern "C" int unet_maxpool3x3s2_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, const uint8_t* idx, unet_bf16* dx, int dx_cs, int dx_co, int N,
+                                     int IH, int IW, int C, int OH, int OW, int accumulate, void* stream) { return maxpool3x3s2_bwd_impl<unet_bf16>(dy, dy_cs, dy_co, idx, dx, dx_cs, dx_co, N, IH, IW, C, OH, OW, accumulate, stream); }
 
-extern "C" int unet_avgpool2_ceil(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH,
+template <typename T>
+static int avgpool2_ceil_impl(const T* x, int x_cs, int x_co, T* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH,
                                   int OW, void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0 && (C & 3) == 0, "avgpool: bad args");
     UNET_CHECK_ARG(OH == (IH + 1) / 2 && OW == (IW + 1) / 2, "avgpool: bad output dims");
     UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C) && unet::slice_ok(y_cs, y_co, C), "avgpool: bad slice");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, N, IH,
+    hipLaunchKernelGGL((avgpool_kernel<T>), dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, N, IH,
                        IW, C4, OH, OW);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_avgpool2_ceil(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH,
+                                  int OW, void* stream) { return avgpool2_ceil_impl<float>(x, x_cs, x_co, y, y_cs, y_co, N, IH, IW, C, OH, OW, stream); }
+extern "C" int unet_avgpool2_ceil_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH,
+                                  int OW, void* stream) { return avgpool2_ceil_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, N, IH, IW, C, OH, OW, stream); }
 
-extern "C" int unet_avgpool2_ceil_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C,
+template <typename T>
+static int avgpool2_ceil_bwd_impl(const T* dy, int dy_cs, int dy_co, T* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C,
                                       int OH, int OW, int accumulate, void* stream) {
     UNET_CHECK_ARG(dy && dx && N > 0 && C > 0 && (C & 3) == 0, "avgpool_bwd: bad args");
     UNET_CHECK_ARG(OH == (IH + 1) / 2 && OW == (IW + 1) / 2, "avgpool_bwd: bad output dims");
     UNET_CHECK_ARG(unet::slice_ok(dy_cs, dy_co, C) && unet::slice_ok(dx_cs, dx_co, C), "avgpool_bwd: bad slice");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx, dx_cs,
+    hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx, dx_cs,
                        dx_co, N, IH, IW, C4, OH, OW, accumulate);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_avgpool2_ceil_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C,
+                                      int OH, int OW, int accumulate, void* stream) { return avgpool2_ceil_bwd_impl<float>(dy, dy_cs, dy_co, dx, dx_cs, dx_co, N, IH, IW, C, OH, OW, accumulate, stream); }
+extern "C" int unet_avgpool2_ceil_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C,
+                                      int OH, int OW, int accumulate, void* stream) { return avgpool2_ceil_bwd_impl<unet_bf16>(dy, dy_cs, dy_co, dx, dx_cs, dx_co, N, IH, IW, C, OH, OW, accumulate, stream); }
 
-extern "C" int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X, int X_cs, int X_co, int N, int h, int w, int Cu,
+template <typename T>
+static int shuffle_blur_impl(const T* yc, int yc_cs, int yc_co, T* X, int X_cs, int X_co, int N, int h, int w, int Cu,
                                  int do_blur, void* stream) {
     UNET_CHECK_ARG(yc && X && N > 0 && h > 0 && w > 0 && Cu > 0, "shuffle_blur: bad args");
     UNET_CHECK_ARG(unet::slice_ok(yc_cs, yc_co, 4 * Cu) && X_cs > 0 && X_co >= 0 && X_co + Cu <= X_cs, "shuffle_blur: bad slice");
-    hipLaunchKernelGGL(shuffle_blur_kernel, dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, yc, yc_cs, yc_co, X, X_cs, X_co, N,
+    hipLaunchKernelGGL((shuffle_blur_kernel<T>), dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, yc, yc_cs, yc_co, X, X_cs, X_co, N,
                        h, w, Cu, do_blur);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X, int X_cs, int X_co, int N, int h, int w, int Cu,
+                                 int do_blur, void* stream) { return shuffle_blur_impl<float>(yc, yc_cs, yc_co, X, X_cs, X_co, N, h, w, Cu, do_blur, stream); }
+extern "C" int unet_shuffle_blur_bf16(const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* X, int X_cs, int X_co, int N, int h, int w, int Cu,
+                                 int do_blur, void* stream) { return shuffle_blur_impl<unet_bf16>(yc, yc_cs, yc_co, X, X_cs, X_co, N, h, w, Cu, do_blur, stream); }
 
-extern "C" int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, const float* yc, int yc_cs, int yc_co, float* dyc, int dyc_cs,
+template <typename T>
+static int shuffle_blur_bwd_impl(const T* dX, int dX_cs, int dX_co, const T* yc, int yc_cs, int yc_co, T* dyc, int dyc_cs,
                                      int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream) {
     UNET_CHECK_ARG(dX && yc && dyc && N > 0 && h > 0 && w > 0 && Cu > 0, "shuffle_blur_bwd: bad args");
     UNET_CHECK_ARG(unet::slice_ok(yc_cs, yc_co, 4 * Cu) && unet::slice_ok(dyc_cs, dyc_co, 4 * Cu) && dX_cs > 0 && dX_co + Cu <= dX_cs,
                    "shuffle_blur_bwd: bad slice");
-    hipLaunchKernelGGL(shuffle_blur_bwd_kernel, dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, dX, dX_cs, dX_co, yc, yc_cs,
+    hipLaunchKernelGGL((shuffle_blur_bwd_kernel<T>), dim3(ew_grid((long long)N * h * w * Cu, 256)), dim3(256), 0, ST, dX, dX_cs, dX_co, yc, yc_cs,
                        yc_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, do_blur);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, const float* yc, int yc_cs, int yc_co, float* dyc, int dyc_cs,
+                                     int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream) { return shuffle_blur_bwd_impl<float>(dX, dX_cs, dX_co, yc, yc_cs, yc_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, do_blur, stream); }
+extern "C" int unet_shuffle_blur_bwd_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* dyc, int dyc_cs,
+                                     int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream) { return shuffle_blur_bwd_impl<unet_bf16>(dX, dX_cs, dX_co, yc, yc_cs, yc_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, do_blur, stream); }
 
 extern "C" int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW,
                                    int C, void* stream) {
@@ -975,12 +1056,15 @@ extern "C" int unet_resize_nearest_bwd(const float* dy, int dy_cs, int dy_co, fl
     return UNET_OK;
 }
 
-extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) {
+template <typename T>
+static int nchw_to_nhwc_impl(const float* x, T* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && y_co >= 0 && y_co + C <= y_cs, "nchw_to_nhwc: bad args");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, x, y, y_cs, y_co, N, C, H, W);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(ew_grid((long long)N * H * W, 256)), dim3(256), 0, ST, x, y, y_cs, y_co, N, C, H, W);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) { return nchw_to_nhwc_impl<float>(x, y, y_cs, y_co, N, C, H, W, stream); }
+extern "C" int unet_nchw_to_nhwc_bf16(const float* x, unet_bf16* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) { return nchw_to_nhwc_impl<unet_bf16>(x, y, y_cs, y_co, N, C, H, W, stream); }
 
 extern "C" int unet_nhwc_to_nchw(const float* x, int x_cs, int x_co, float* y, int N, int C, int H, int W, void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && x_co >= 0 && x_co + C <= x_cs, "nhwc_to_nchw: bad args");
@@ -989,15 +1073,20 @@ extern "C" int unet_nhwc_to_nchw(const float* x, int x_cs, int x_co, float* y, i
     return UNET_OK;
 }
 
-extern "C" int unet_copy_slice(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, int accumulate,
+template <typename T>
+static int copy_slice_impl(const T* x, int x_cs, int x_co, T* y, int y_cs, int y_co, long long P, int C, int accumulate,
                                void* stream) {
     UNET_CHECK_ARG(x && y && P > 0 && C > 0, "copy_slice: bad args");
     UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "copy_slice: bad slice");
     const int C4 = c4of(C);
-    hipLaunchKernelGGL(copy_slice_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, accumulate);
+    hipLaunchKernelGGL((copy_slice_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, accumulate);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_copy_slice(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, int accumulate,
+                               void* stream) { return copy_slice_impl<float>(x, x_cs, x_co, y, y_cs, y_co, P, C, accumulate, stream); }
+extern "C" int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate,
+                               void* stream) { return copy_slice_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, P, C, accumulate, stream); }
 
 extern "C" int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_cs, int r_co, float* y, int y_cs, int y_co,
                               long long P, int C, void* stream) {
@@ -1043,15 +1132,20 @@ extern "C" int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* ta
     return UNET_OK;
 }
 
-extern "C" int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
-                           const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream) {
+template <typename T>
+static int ce_bwd_impl(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                           const float* denom, float gscale, T* dz, int dz_cs, int dz_co, void* stream) {
     UNET_CHECK_ARG(z && target && denom && dz && P > 0 && C > 0 && C <= CE_MAXC, "ce_bwd: bad args");
     UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs && dz_co >= 0 && dz_co + C <= dz_cs, "ce_bwd: bad slice");
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs,
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs,
                        dz_co);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                           const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream) { return ce_bwd_impl<float>(z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs, dz_co, stream); }
+extern "C" int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                           const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream) { return ce_bwd_impl<unet_bf16>(z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs, dz_co, stream); }
 
 extern "C" int unet_regloss_fwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta, float* loss,
                                 float* workspace, void* stream) {

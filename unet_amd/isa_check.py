@@ -154,13 +154,18 @@ def check_asm(asm: str) -> Tuple[Dict[str, int], List[str]]:
     return kernels, bad
 
 
+SOURCES = ("conv_igemm.hip", "conv_bf16.hip")     # every file whose kernels issue asm loads
+
+
 def main() -> int:
-    asm = compile_to_asm(CSRC / "conv_igemm.hip")
-    kernels, bad = check_asm(asm)
-    print(f"{len(kernels)} kernels with asm loads, {sum(kernels.values())} loads checked, {len(bad)} violations")
-    for b in bad[:40]:
-        print("  ", b)
-    return 1 if bad else 0
+    rc = 0
+    for src in SOURCES:
+        kernels, bad = check_asm(compile_to_asm(CSRC / src))
+        print(f"{src}: {len(kernels)} kernels with asm loads, {sum(kernels.values())} loads checked, {len(bad)} violations")
+        for b in bad[:40]:
+            print("  ", b)
+        rc |= 1 if bad else 0
+    return rc
 
 
 if __name__ == "__main__":

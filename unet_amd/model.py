@@ -40,8 +40,17 @@ class _Marker(nn.Module):
 
 class HipDynamicUnet(nn.Module):
     def __init__(self, arch: str, n_in: int, n_out: int, img_size: Sequence[int] = (512, 512), self_attention: bool = False,
-                 device="cuda"):
+                 device="cuda", act_dtype: str = "f32"):
+        """act_dtype "f32": the parity path (the reference computes in fp32).  "bf16": bf16 storage of activations, activation
+        gradients and packed filters with fp32 accumulation in the matrix cores; parameters, gradients of parameters, BatchNorm
+        statistics, logits, loss and optimizer state stay fp32 (BASELINE.json configs[1] variant; classification, tiles divisible
+        by 32, no self-attention)."""
         super().__init__()
+        if act_dtype not in ("f32", "bf16"):
+            raise ValueError(f"act_dtype must be 'f32' or 'bf16', not {act_dtype!r}")
+        if act_dtype == "bf16" and self_attention:
+            raise ValueError("self-attention is only available on the fp32 path")
+        self.act_dtype = act_dtype
         self.arch, self.n_in, self.n_out = arch, n_in, n_out
         self.img_size = tuple(img_size)
         enc = Encoder(arch, n_in)
@@ -113,7 +122,7 @@ class HipDynamicUnet(nn.Module):
             p.data = view
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
             self._param_offsets[id(p)] = (o, p.numel())
-        self.ctx = Ctx(dev)
+        self.ctx = Ctx(dev, torch.bfloat16 if self.act_dtype == "bf16" else torch.float32)
         enc = self.layers[0]
         self._enc_child_offset = {}
         for i, child in enumerate(enc):
@@ -152,6 +161,8 @@ class HipDynamicUnet(nn.Module):
     def _hip_forward(self, x: torch.Tensor, training: bool) -> TS:
         """x: [B, n_in, H, W] fp32 (device).  Returns the logits slice (NHWC)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.n_in, x.shape
+        if self.act_dtype == "bf16" and (x.shape[2] % 32 or x.shape[3] % 32):
+            raise ValueError("bf16 storage mode needs tile sides divisible by 32 (no nearest-resize kernels in bf16)")
         x = x.contiguous()
         ctx = self.ctx
         ctx.training = training
@@ -196,7 +207,7 @@ class HipDynamicUnet(nn.Module):
         L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
         ops.nchw_to_nhwc(x, X.sub(self.up_c, self.n_in))
         o = L[nb + 3].hip_fwd(ctx, X)
-        z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True)
+        z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True, dtype=torch.float32)      # logits are fp32 in both modes
         head: ConvLayer = L[nb + 4]
         head.cx.fwd(o, z)
         ctx.saved[(id(head), "x")] = o

@@ -36,8 +36,9 @@ BN_MOM = 0.1
 # --------------------------------------------------------------------------
 
 class Ctx:
-    def __init__(self, device):
+    def __init__(self, device, act_dtype=torch.float32):
         self.device = device
+        self.act_dtype = act_dtype          # storage type of activations / activation gradients / packed filters
         self.training = True
         self.need_grad = True
         self._acts: Dict[tuple, TS] = {}
@@ -49,11 +50,11 @@ class Ctx:
         self.weights_epoch = 0
 
     # activations are keyed by (owner id, tag, shape): allocated once per input geometry
-    def act(self, owner, tag, N, H, W, C, zero=False) -> TS:
+    def act(self, owner, tag, N, H, W, C, zero=False, dtype=None) -> TS:
         key = (id(owner), tag, N, H, W, C)
         t = self._acts.get(key)
         if t is None:
-            t = ops.new_act(N, H, W, C, self.device, zero=zero)
+            t = ops.new_act(N, H, W, C, self.device, zero=zero, dtype=self.act_dtype if dtype is None else dtype)
             self._acts[key] = t
         return t
 
@@ -72,7 +73,7 @@ class Ctx:
         return self._ws
 
     def bytes_allocated(self) -> int:
-        n = sum(t.buf.numel() * 4 for t in self._acts.values()) + sum(v.numel() * v.element_size() for v in self._vecs.values())
+        n = sum(t.buf.numel() * t.buf.element_size() for t in self._acts.values()) + sum(v.numel() * v.element_size() for v in self._vecs.values())
         return n + (0 if self._ws is None else self._ws.numel() * 4)
 
 
@@ -105,13 +106,14 @@ class _ConvExec:
     def packed(self, mode: int) -> torch.Tensor:
         w = self.conv.weight
         ver = (w._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
+        dt = torch.float32 if self.ctx is None else self.ctx.act_dtype
         if mode == 0:
             if self.wp_f is None or self._ver_f != ver:
-                self.wp_f = ops.pack_weights(w.data, 0, self.wp_f)
+                self.wp_f = ops.pack_weights(w.data, 0, self.wp_f, dtype=dt)
                 self._ver_f = ver
             return self.wp_f
         if self.wp_d is None or self._ver_d != ver:
-            self.wp_d = ops.pack_weights(w.data, 1, self.wp_d)
+            self.wp_d = ops.pack_weights(w.data, 1, self.wp_d, dtype=dt)
             self._ver_d = ver
         return self.wp_d
 
@@ -240,7 +242,7 @@ class ConvLayer(nn.Sequential):
 
     def _conv_bn(self, ctx: Ctx, x: TS, y: TS):
         """conv + BatchNorm coefficients; in train mode the batch statistics come out of the conv epilogue"""
-        if ctx.training and FUSE_BN_STATS and not (self.nf > 128 and 0 < self.nf % 128 <= 64):    # (not for split launches)
+        if ctx.training and FUSE_BN_STATS and ctx.act_dtype == torch.float32 and not (self.nf > 128 and 0 < self.nf % 128 <= 64):    # (not for split launches)
             return self.bx.coeffs(ctx, y, self.cx.fwd_stats(ctx, x, y))
         self.cx.fwd(x, y)
         return self.bx.coeffs(ctx, y)

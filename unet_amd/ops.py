@@ -28,16 +28,30 @@ def rup4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def vec_of(dtype) -> int:
+    """channels per 16-byte access: channel strides / offsets of a tensor are multiples of this"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def rupv(c: int, dtype) -> int:
+    v = vec_of(dtype)
+    return (c + v - 1) // v * v
+
+
 @dataclass
 class TS:
-    """Channel slice of an NHWC fp32 buffer."""
-    buf: torch.Tensor   # [N, H, W, cs] contiguous fp32
+    """Channel slice of an NHWC buffer: fp32 (the parity path) or bf16 storage (BASELINE configs[1] variant)."""
+    buf: torch.Tensor   # [N, H, W, cs] contiguous fp32 | bf16
     co: int
     C: int
 
     def __post_init__(self):
-        assert self.buf.dtype == torch.float32 and self.buf.is_contiguous() and self.buf.dim() == 4
-        assert self.co % 4 == 0 and self.co + self.C <= self.cs, (self.co, self.C, self.cs)
+        assert self.buf.dtype in (torch.float32, torch.bfloat16) and self.buf.is_contiguous() and self.buf.dim() == 4
+        v = vec_of(self.buf.dtype)
+        assert self.co % v == 0 and self.cs % v == 0 and self.co + self.C <= self.cs, (self.co, self.C, self.cs)
+
+    @property
+    def bf16(self) -> bool: return self.buf.dtype == torch.bfloat16
 
     @property
     def cs(self) -> int: return self.buf.shape[3]
@@ -59,11 +73,22 @@ class TS:
         return TS(self.buf, self.co + off, C)
 
 
-def new_act(N, H, W, C, device, zero=False) -> TS:
-    cs = rup4(C)
+def new_act(N, H, W, C, device, zero=False, dtype=torch.float32) -> TS:
+    cs = rupv(C, dtype)
     need_zero = zero or cs != C
-    buf = (torch.zeros if need_zero else torch.empty)((N, H, W, cs), dtype=torch.float32, device=device)
+    buf = (torch.zeros if need_zero else torch.empty)((N, H, W, cs), dtype=dtype, device=device)
     return TS(buf, 0, C)
+
+
+def _fn(name: str, t: "TS"):
+    """the entry point for t's storage type: unet_<name> (fp32) or unet_<name>_bf16"""
+    return getattr(lib, f"unet_{name}_bf16" if t.bf16 else f"unet_{name}")
+
+
+def _need_f32(what: str, *ts):
+    for t in ts:
+        if t is not None and t.bf16:
+            raise L.UnetHipError(f"{what}: not available with bf16 storage (fp32 parity path only)")
 
 
 def full(buf: torch.Tensor, C: Optional[int] = None) -> TS:
@@ -77,12 +102,20 @@ def conv_out_hw(H, W, ks, stride):
     return (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
 
 
-def pack_weights(w: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """w: [Cout, Cin, ks, ks] contiguous.  mode 0 = forward image, 1 = dgrad image."""
+def pack_weights(w: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None, dtype=torch.float32) -> torch.Tensor:
+    """w: [Cout, Cin, ks, ks] contiguous fp32 master parameter.  mode 0 = forward image, 1 = dgrad image; dtype = storage type of
+    the packed image (bf16: rounded once here, products accumulate in fp32)."""
     Cout, Cin, ks, _ = w.shape
     assert w.is_contiguous() and w.dtype == torch.float32
+    if dtype == torch.bfloat16:
+        n = lib.unet_pack_weights_size_bf16(Cout, Cin, ks, mode)
+        if out is None or out.dtype != dtype:
+            out = torch.empty(n, dtype=dtype, device=w.device)
+        assert out.numel() >= n
+        check(lib.unet_pack_weights_bf16(w.data_ptr(), out.data_ptr(), Cout, Cin, ks, mode, _stream()), "pack_weights_bf16")
+        return out
     n = lib.unet_pack_weights_size(Cout, Cin, ks, mode)
-    if out is None:
+    if out is None or out.dtype != dtype:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
     assert out.numel() >= n
     check(lib.unet_pack_weights(w.data_ptr(), out.data_ptr(), Cout, Cin, ks, mode, _stream()), "pack_weights")
@@ -97,10 +130,12 @@ def pack_weights_strided(w_base_ptr: int, so: int, sr: int, O: int, R: int, out:
 
 
 def row_softmax(x: "TS", y: "TS"):
+    _need_f32("row_softmax", x, y)
     check(lib.unet_row_softmax(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, _stream()), "row_softmax")
 
 
 def row_softmax_bwd(y: "TS", dy: "TS", dx: "TS"):
+    _need_f32("row_softmax_bwd", y, dy, dx)
     check(lib.unet_row_softmax_bwd(y.ptr, y.cs, y.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, y.P, y.C, _stream()), "row_softmax_bwd")
 
 
@@ -121,6 +156,11 @@ def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, 
     d.OH, d.OW, d.Cout = y.H, y.W, y.C
     d.ks, d.stride, d.kind, d.flags = ks, stride, kind, flags
     d.colsum, d.colsumsq = _p(colsum), _p(colsumsq)
+    if x.bf16:
+        assert wp.dtype == torch.bfloat16 and (res is None or res.bf16) and (mask is None or mask.bf16)
+        d.dtype, d.y_f32 = L.BF16, int(not y.bf16)
+    else:
+        assert wp.dtype == torch.float32 and not y.bf16
     return d
 
 
@@ -132,11 +172,12 @@ class ConvProbe:
         self.variant = variant
         self.events = []
         self.flops = 0.0
+        self.bytes = 0.0          # ALGORITHMIC bytes of the probed launches: every operand tensor once in, the result once out
         self.detail = []          # (what, N, H, W, Cin, Cout, ks, stride, flops) per probed launch
 
     def summary(self):
         ms = [a.elapsed_time(b) for a, b in self.events]
-        return {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms)), "flops": self.flops}
+        return {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms)), "flops": self.flops, "bytes": self.bytes}
 
 
 CONV_PROBE: Optional[ConvProbe] = None
@@ -151,6 +192,12 @@ def _launch_conv_part(d: ConvDesc, what: str, alg_flops: float):
         e1.record()
         pr.events.append((e0, e1))
         pr.flops += alg_flops
+        # x + y (+ residual, + mask) once each at the storage width, the packed filter image once, the bias vector
+        es = 2 if d.dtype == L.BF16 else 4
+        co = d.cout_count or d.Cout
+        pix_in, pix_out = d.N * d.IH * d.IW, d.N * d.OH * d.OW
+        pr.bytes += (es * (pix_in * d.Cin + pix_out * co * (1 + (1 if d.res else 0) + (1 if d.mask else 0)))
+                     + (4 - es) * pix_out * co * d.y_f32 + es * d.ks * d.ks * d.Cin * co)
         pr.detail.append((what, d.N, d.OH, d.OW, d.Cin, d.cout_count or d.Cout, d.ks, d.stride, alg_flops))
         return
     check(lib.unet_conv2d(C.byref(d), _stream()), what)
@@ -204,6 +251,8 @@ def _wgrad_desc(x: TS, dy: TS, dw, dbias, ks, stride, ws, accumulate) -> WgradDe
     d.workspace = _p(ws)
     d.workspace_floats = 0 if ws is None else ws.numel()
     d.accumulate = int(accumulate)
+    assert x.bf16 == dy.bf16
+    d.dtype = L.BF16 if x.bf16 else L.F32
     return d
 
 
@@ -225,7 +274,7 @@ def bn_stats_rows(P: int) -> int:
 
 
 def bn_stats(x: TS, partial: torch.Tensor):
-    check(lib.unet_bn_stats(x.ptr, x.cs, x.co, x.P, x.C, partial.data_ptr(), _stream()), "bn_stats")
+    check(_fn("bn_stats", x)(x.ptr, x.cs, x.co, x.P, x.C, partial.data_ptr(), _stream()), "bn_stats")
 
 
 def bn_finalize(psum, psumsq, rows, count, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinvstd, tracked=None):
@@ -240,13 +289,13 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
 
 
 def affine_act(x: TS, y: TS, scale=None, shift=None, x2: Optional[TS] = None, scale2=None, shift2=None, relu=False):
-    check(lib.unet_affine_act(x.ptr, x.cs, x.co, _p(scale), _p(shift),
+    check(_fn("affine_act", x)(x.ptr, x.cs, x.co, _p(scale), _p(shift),
                               None if x2 is None else x2.ptr, 0 if x2 is None else x2.cs, 0 if x2 is None else x2.co,
                               _p(scale2), _p(shift2), y.ptr, y.cs, y.co, x.P, x.C, int(relu), _stream()), "affine_act")
 
 
 def bn_bwd_reduce(dout: TS, out: Optional[TS], x: TS, mean, invstd, partial):
-    check(lib.unet_bn_bwd_reduce(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
+    check(_fn("bn_bwd_reduce", x)(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
                                  0 if out is None else out.co, x.ptr, x.cs, x.co, _p(mean), _p(invstd), x.P, x.C,
                                  partial.data_ptr(), _stream()), "bn_bwd_reduce")
 
@@ -257,7 +306,7 @@ def bn_bwd_finalize(partial, rows, count, C_, dgamma, dbeta, c1, c2):
 
 def bn_bwd_apply(dout: TS, out: Optional[TS], x: TS, mean, invstd, gamma, c1, c2, dx: TS, gout: Optional[TS] = None,
                  g_accumulate=False):
-    check(lib.unet_bn_bwd_apply(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
+    check(_fn("bn_bwd_apply", x)(dout.ptr, dout.cs, dout.co, None if out is None else out.ptr, 0 if out is None else out.cs,
                                 0 if out is None else out.co, x.ptr, x.cs, x.co, _p(mean), _p(invstd), _p(gamma), _p(c1), _p(c2),
                                 dx.ptr, dx.cs, dx.co, None if gout is None else gout.ptr, 0 if gout is None else gout.cs,
                                 0 if gout is None else gout.co, int(g_accumulate), x.P, x.C, _stream()), "bn_bwd_apply")
@@ -266,20 +315,20 @@ def bn_bwd_apply(dout: TS, out: Optional[TS], x: TS, mean, invstd, gamma, c1, c2
 # ------------------------------------------------------------------ pooling
 
 def maxpool(x: TS, y: TS, idx: Optional[torch.Tensor]):
-    check(lib.unet_maxpool3x3s2(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, _p(idx), x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "maxpool")
+    check(_fn("maxpool3x3s2", x)(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, _p(idx), x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "maxpool")
 
 
 def maxpool_bwd(dy: TS, idx: torch.Tensor, dx: TS, accumulate=False):
-    check(lib.unet_maxpool3x3s2_bwd(dy.ptr, dy.cs, dy.co, idx.data_ptr(), dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W,
+    check(_fn("maxpool3x3s2_bwd", dy)(dy.ptr, dy.cs, dy.co, idx.data_ptr(), dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W,
                                     int(accumulate), _stream()), "maxpool_bwd")
 
 
 def avgpool(x: TS, y: TS):
-    check(lib.unet_avgpool2_ceil(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "avgpool")
+    check(_fn("avgpool2_ceil", x)(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, x.C, y.H, y.W, _stream()), "avgpool")
 
 
 def avgpool_bwd(dy: TS, dx: TS, accumulate=False):
-    check(lib.unet_avgpool2_ceil_bwd(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W, int(accumulate),
+    check(_fn("avgpool2_ceil_bwd", dy)(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W, int(accumulate),
                                      _stream()), "avgpool_bwd")
 
 
@@ -287,20 +336,22 @@ def avgpool_bwd(dy: TS, dx: TS, accumulate=False):
 
 def shuffle_blur(yc: TS, X: TS, blur: bool):
     assert yc.C == 4 * X.C and X.H == 2 * yc.H and X.W == 2 * yc.W
-    check(lib.unet_shuffle_blur(yc.ptr, yc.cs, yc.co, X.ptr, X.cs, X.co, yc.N, yc.H, yc.W, X.C, int(blur), _stream()), "shuffle_blur")
+    check(_fn("shuffle_blur", yc)(yc.ptr, yc.cs, yc.co, X.ptr, X.cs, X.co, yc.N, yc.H, yc.W, X.C, int(blur), _stream()), "shuffle_blur")
 
 
 def shuffle_blur_bwd(dX: TS, yc: TS, dyc: TS, blur: bool):
     assert yc.C == 4 * dX.C and dX.H == 2 * yc.H and dX.W == 2 * yc.W
-    check(lib.unet_shuffle_blur_bwd(dX.ptr, dX.cs, dX.co, yc.ptr, yc.cs, yc.co, dyc.ptr, dyc.cs, dyc.co, yc.N, yc.H, yc.W, dX.C,
+    check(_fn("shuffle_blur_bwd", dX)(dX.ptr, dX.cs, dX.co, yc.ptr, yc.cs, yc.co, dyc.ptr, dyc.cs, dyc.co, yc.N, yc.H, yc.W, dX.C,
                                     int(blur), _stream()), "shuffle_blur_bwd")
 
 
 def resize_nearest(x: TS, y: TS):
+    _need_f32("resize_nearest", x, y)
     check(lib.unet_resize_nearest(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, y.H, y.W, x.C, _stream()), "resize_nearest")
 
 
 def resize_nearest_bwd(dy: TS, dx: TS):
+    _need_f32("resize_nearest_bwd", dy, dx)
     check(lib.unet_resize_nearest_bwd(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dy.H, dy.W, dx.C, _stream()),
           "resize_nearest_bwd")
 
@@ -308,19 +359,21 @@ def resize_nearest_bwd(dy: TS, dx: TS):
 def nchw_to_nhwc(x: torch.Tensor, y: TS):
     N, C_, H, W = x.shape
     assert x.is_contiguous() and y.C == C_
-    check(lib.unet_nchw_to_nhwc(x.data_ptr(), y.ptr, y.cs, y.co, N, C_, H, W, _stream()), "nchw_to_nhwc")
+    check(_fn("nchw_to_nhwc", y)(x.data_ptr(), y.ptr, y.cs, y.co, N, C_, H, W, _stream()), "nchw_to_nhwc")
 
 
 def nhwc_to_nchw(x: TS, y: torch.Tensor):
+    _need_f32("nhwc_to_nchw", x)
     assert y.is_contiguous()
     check(lib.unet_nhwc_to_nchw(x.ptr, x.cs, x.co, y.data_ptr(), x.N, x.C, x.H, x.W, _stream()), "nhwc_to_nchw")
 
 
 def copy_slice(x: TS, y: TS, accumulate=False):
-    check(lib.unet_copy_slice(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, int(accumulate), _stream()), "copy_slice")
+    check(_fn("copy_slice", x)(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, int(accumulate), _stream()), "copy_slice")
 
 
 def relu_mask(g: TS, ref: TS, y: TS):
+    _need_f32("relu_mask", g, ref, y)
     check(lib.unet_relu_mask(g.ptr, g.cs, g.co, ref.ptr, ref.cs, ref.co, y.ptr, y.cs, y.co, g.P, g.C, _stream()), "relu_mask")
 
 
@@ -329,6 +382,7 @@ def colsum_workspace(P, C_) -> int:
 
 
 def colsum(x: TS, out: torch.Tensor, ws: torch.Tensor):
+    _need_f32("colsum", x)
     assert ws.numel() >= colsum_workspace(x.P, x.C)
     check(lib.unet_colsum(x.ptr, x.cs, x.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "colsum")
 
@@ -340,13 +394,14 @@ def ce_workspace(P) -> int:
 
 
 def ce_fwd(z: TS, target: torch.Tensor, weight, loss, denom, ws):
+    _need_f32("ce_fwd", z)
     assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == z.P
     check(lib.unet_ce_fwd(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, loss.data_ptr(), denom.data_ptr(),
                           ws.data_ptr(), _stream()), "ce_fwd")
 
 
 def ce_bwd(z: TS, target, weight, denom, gscale: float, dz: TS):
-    check(lib.unet_ce_bwd(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, denom.data_ptr(), gscale, dz.ptr, dz.cs,
+    check(_fn("ce_bwd", dz)(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, denom.data_ptr(), gscale, dz.ptr, dz.cs,
                           dz.co, _stream()), "ce_bwd")
 
 
@@ -354,17 +409,20 @@ REG_KINDS = {"mse": 0, "l1": 1, "smoothl1": 2}
 
 
 def regloss_fwd(z: TS, target: torch.Tensor, kind: str, beta: float, loss, ws):
+    _need_f32("regloss_fwd", z)
     assert target.dtype == torch.float32 and target.is_contiguous() and target.numel() == z.P and z.C == 1
     check(lib.unet_regloss_fwd(z.ptr, z.cs, z.co, target.data_ptr(), z.P, REG_KINDS[kind], float(beta), loss.data_ptr(), ws.data_ptr(),
                                _stream()), "regloss_fwd")
 
 
 def regloss_bwd(z: TS, target: torch.Tensor, kind: str, beta: float, gscale: float, dz: TS):
+    _need_f32("regloss_bwd", z, dz)
     check(lib.unet_regloss_bwd(z.ptr, z.cs, z.co, target.data_ptr(), z.P, REG_KINDS[kind], float(beta), float(gscale), dz.ptr, dz.cs,
                                dz.co, _stream()), "regloss_bwd")
 
 
 def softmax_argmax(z: TS, probs: Optional[torch.Tensor], amax: Optional[torch.Tensor]):
+    _need_f32("softmax_argmax", z)
     check(lib.unet_softmax_argmax(z.ptr, z.cs, z.co, z.N, z.H, z.W, z.C, _p(probs), _p(amax), _stream()), "softmax_argmax")
 
 
