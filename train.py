@@ -132,11 +132,19 @@ def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, v
         "VALID_SCENES": VALID_SCENES, "info": info, "class_zero": class_zero, "dtype": dtype}, indent=1, default=str))
     tfm = None
     if transforms:
-        # the reference's default aug_pipe is HorizontalFlip + VerticalFlip (params_and_main.py:105-115); any other
-        # albumentations pipeline is not available here (albumentations is not installed)
-        if aug_pipe is not None and not isinstance(aug_pipe, FlipAugment):
-            warnings.warn("only the built-in flip augmentation is available on this path; using it instead of aug_pipe")
-        tfm = aug_pipe if isinstance(aug_pipe, FlipAugment) else FlipAugment(n_transform_imgs=n_transform_imgs)
+        # aug_pipe: None = the reference's default pipeline HorizontalFlip + VerticalFlip (params_and_main.py:105-115); or a
+        # unet_amd.augment.Compose (HorizontalFlip / VerticalFlip / RandomBrightnessContrast / CoarseDropout with albumentations'
+        # semantics, applied on the device); a ready batch transform (FlipAugment / BatchAugment) is used as is
+        from unet_amd.augment import BatchAugment, Compose
+        if isinstance(aug_pipe, (FlipAugment, BatchAugment)):
+            tfm = aug_pipe
+        elif isinstance(aug_pipe, Compose):
+            tfm = BatchAugment(aug_pipe, n_transform_imgs=n_transform_imgs)
+        else:
+            if aug_pipe is not None:
+                warnings.warn("aug_pipe is not a unet_amd.augment.Compose (albumentations itself is not available on this path); "
+                              "using the default flip pipeline")
+            tfm = FlipAugment(n_transform_imgs=n_transform_imgs)
     dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, train_tfm=tfm, regression=bool(enable_regression))
     if enable_regression:
         CLASS_WEIGHTS = [1]                                           # train.py:334-335
