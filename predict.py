@@ -18,7 +18,7 @@ import torch
 
 from unet_amd import ops
 from unet_amd.learner import load_learner, open_tile, scale_input
-from unet_amd.tiffio import read_tiff, write_tiff
+from unet_amd.tiffio import read_tiff, tiff_info, write_tiff
 
 
 def store_tif(output_file, data, geotrans=None, tags=None, nodata=None, class_zero=False):
@@ -30,10 +30,15 @@ def store_tif(output_file, data, geotrans=None, tags=None, nodata=None, class_ze
 
 
 def _geo(path):
+    """(geotransform, GeoTIFF tags, height, width) from the header alone (.npy tiles carry no georeference)"""
     if Path(path).suffix == ".npy":
-        return None, {}
-    _, meta = read_tiff(path)
-    return meta["geotransform"], meta["tags"]
+        a = np.load(path, mmap_mode="r")
+        return None, {}, int(a.shape[-2]), int(a.shape[-1])
+    meta = tiff_info(path)
+    return meta["geotransform"], meta["tags"], meta["height"], meta["width"]
+
+
+LARGE_FILE_SCALE = (128 / 4) - 1        # predict.py:209-214: probabilities stretched to int8 as around(p * 31)
 
 
 def save_predictions(predict_model, predict_path, regression, merge=False, all_classes=False, specific_class=None, large_file=False,
@@ -52,25 +57,50 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
     print(f"Started at: {time.strftime('%H:%M:%S')}  ({len(tiles)} tiles)")
     dtype = learn.dls.train_ds.dtype
     geos = [_geo(t) for t in tiles]
-    if merge:
-        gts = np.array([[g[0][0], 0, g[0][1], g[0][3], 0, g[0][5]] for g in geos], dtype=np.float64)
-    results = []          # (tile index, probs [C,H,W] device tensor) when merging
+    dev = model._device
+    C = model.n_out
+    int8_merge = bool(merge and large_file and not regression)
     mosaic = count = None
+    if merge:
+        # overlap merge (predict.py:257-355).  The extent follows from the tiles' geotransforms and sizes, which are known from the
+        # headers BEFORE any tile is predicted: every batch is accumulated into the device mosaic as soon as it is computed and its
+        # probabilities are dropped (the reference keeps all tiles' probabilities until the end).
+        gts = np.array([[g[0][0], g[3], g[0][1], g[0][3], g[2], g[0][5]] for g in geos], dtype=np.float64)
+        ulx_full, uly_full = gts[:, 0].min(), gts[:, 3].max()
+        xres, yres = gts[0, 2], gts[0, 5]
+        xmax_i, ymin_i = gts[:, 0].argmax(), gts[:, 3].argmin()
+        lrx_full = gts[:, 0].max() + gts[xmax_i, 1] * gts[xmax_i, 2]
+        lry_full = gts[:, 3].min() + gts[ymin_i, 4] * gts[ymin_i, 5]
+        if len(set(gts[:, 1])) != 1 or len(set(gts[:, 4])) != 1:
+            warnings.warn("Not all tiles have the same resolution.")
+        MW, MH = round((lrx_full - ulx_full) / xres), round((lry_full - uly_full) / yres)
+        print(f"True merged raster size: {C * MH * MW * (1 if int8_merge else 4) / (1024 ** 2): .1f}MB.")
+        if int8_merge:      # the reference's int8 arrays (merged raster AND hit counter are int8 per class, wrap-around included)
+            mosaic = torch.zeros((C, MH, MW), dtype=torch.int8, device=dev)
+            count = torch.zeros((C, MH, MW), dtype=torch.int8, device=dev)
+        else:
+            mosaic = torch.zeros((C, MH, MW), dtype=torch.float32, device=dev)
+            count = torch.zeros((MH, MW), dtype=torch.int32, device=dev)
     mine = list(range(rank, len(tiles), world))
     for b0 in range(0, len(mine), batch_size):
         ids = mine[b0:b0 + batch_size]
         chunk = [tiles[i] for i in ids]
         x = torch.from_numpy(np.stack([scale_input(open_tile(t), dtype) for t in chunk]))
         if regression:       # predict.py:195-197: tile_preds[1] = raw outputs [1,H,W]
-            probs, amax = model.predict_values(x.to(model._device)), None
+            probs, amax = model.predict_values(x.to(dev)), None
         else:
-            probs, amax = model.predict_probs(x.to(model._device))
+            probs, amax = model.predict_probs(x.to(dev))
         for j, t in enumerate(chunk):
             i = ids[j]
-            gt, tags = geos[i]
+            gt, tags = geos[i][0], geos[i][1]
             if merge:
-                results.append((i, probs[j]))
-                gts[i, 1], gts[i, 4] = probs.shape[3], probs.shape[2]
+                x0, y0 = round((gts[i, 0] - ulx_full) / xres), round((gts[i, 3] - uly_full) / yres)
+                if int8_merge:
+                    q = torch.round(probs[j] * LARGE_FILE_SCALE).to(torch.int8)          # np.around: half to even, as torch.round
+                    mosaic[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += q
+                    count[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += 1
+                else:
+                    ops.mosaic_accumulate(probs[j].contiguous(), mosaic, count, int(y0), int(x0))
                 continue
             if regression or all_classes:
                 out = probs[j].cpu().numpy()
@@ -79,7 +109,7 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
             else:
                 out = probs[j, specific_class].cpu().numpy()
             if large_file and out.dtype.kind == "f" and out.max() <= 1 and (all_classes or specific_class):
-                out = np.around(out * ((128 / 4) - 1)).astype(np.int8)
+                out = np.around(out * LARGE_FILE_SCALE).astype(np.int8)
             name = t.name if t.suffix != ".npy" else t.stem + ".tif"
             store_tif(output_folder / name, out, gt, tags, None, class_zero)
     if validation_vision:
@@ -89,47 +119,26 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
             dist.barrier()
         print(f"Prediction stored in {output_folder}.")
         return output_folder
-    if world > 1:       # every rank needs every tile's size for the mosaic extent
-        sizes = torch.from_numpy(gts[:, [1, 4]].copy()).to(model._device)
-        dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
-        gts[:, [1, 4]] = sizes.cpu().numpy()
-    # ---- overlap merge (predict.py:257-355): mosaic extent from the tiles' geotransforms
-    ulx_full, uly_full = gts[:, 0].min(), gts[:, 3].max()
-    xres, yres = gts[0, 2], gts[0, 5]
-    xmax_i, ymin_i = gts[:, 0].argmax(), gts[:, 3].argmin()
-    lrx_full = gts[:, 0].max() + gts[xmax_i, 1] * gts[xmax_i, 2]
-    lry_full = gts[:, 3].min() + gts[ymin_i, 4] * gts[ymin_i, 5]
-    if len(set(gts[:, 1])) != 1 or len(set(gts[:, 4])) != 1:
-        warnings.warn("Not all tiles have the same resolution.")
-    MW, MH = round((lrx_full - ulx_full) / xres), round((lry_full - uly_full) / yres)
-    C = model.n_out
-    print(f"True merged raster size: {C * MH * MW * 4 / (1024 ** 2): .1f}MB.")
-    if large_file and not regression:
-        # int8 path of the reference: probabilities * 31 rounded to int8, integer division by the hit counter (host)
-        merged = np.zeros((C, MH, MW), dtype=np.int8)
-        counter = np.zeros((C, MH, MW), dtype=np.int8)
-        for i, p in results:
-            x0, y0 = round((gts[i, 0] - ulx_full) / xres), round((gts[i, 3] - uly_full) / yres)
-            q = np.around(p.cpu().numpy() * ((128 / 4) - 1)).astype(np.int8)
-            merged[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += q
-            counter[:, y0:y0 + q.shape[1], x0:x0 + q.shape[2]] += 1
-        if world > 1:
-            raise NotImplementedError("large_file merge is single-process (int8 host arrays)")
-        m = counter > 0
-        merged[m] //= counter[m]
-        amax_full = merged.argmax(axis=0)
-    else:
-        mosaic = torch.zeros((C, MH, MW), dtype=torch.float32, device=model._device)
-        count = torch.zeros((MH, MW), dtype=torch.int32, device=model._device)
-        for i, p in results:
-            x0, y0 = round((gts[i, 0] - ulx_full) / xres), round((gts[i, 3] - uly_full) / yres)
-            ops.mosaic_accumulate(p.contiguous(), mosaic, count, int(y0), int(x0))
-        if world > 1:   # partial (sum-probs, hit-count) rasters of the ranks -> one mosaic
+    if world > 1:       # partial rasters of the ranks -> one mosaic on every rank; rank 0 writes
+        if int8_merge:
+            # int8 + int8 wraps modulo 256 in the single-process reference; a SUM in int32 followed by the wrapping cast back to int8
+            # is the same number whatever the order of the tiles
+            for t8 in (mosaic, count):
+                t32 = t8.to(torch.int32)
+                dist.all_reduce(t32)
+                t8.copy_(t32.to(torch.int8))
+        else:
             dist.all_reduce(mosaic)
             dist.all_reduce(count)
-            if rank != 0:
-                return None
-        am = torch.empty((MH, MW), dtype=torch.uint8, device=model._device)
+        if rank != 0:
+            return None
+    if int8_merge:
+        merged, counter = mosaic.cpu().numpy(), count.cpu().numpy()
+        m = counter > 0
+        merged[m] //= counter[m]                       # predict.py:324-329: integer floor division, numpy semantics
+        amax_full = merged.argmax(axis=0)
+    else:
+        am = torch.empty((MH, MW), dtype=torch.uint8, device=dev)
         ops.mosaic_finalize(mosaic, count, am)
         merged, amax_full = mosaic.cpu().numpy(), am.cpu().numpy()
         if regression:       # predict.py:306-315: mean of the overlapping tiles, -9999 where no prediction was placed

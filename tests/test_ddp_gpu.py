@@ -72,12 +72,13 @@ def test_two_ranks_one_gpu_gloo():
     assert [r[:3] for r in res] == [(0, True, True), (1, True, True)], res
 
 
-def _predict_worker(rank, world, port, pkl, tiles_dir, q):
+def _predict_worker(rank, world, port, pkl, tiles_dir, q, large_file=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       UNET_DIST_BACKEND="gloo", UNET_FORCE_DEVICE="0")
     import torch.distributed as dist
     import predict as P
-    out = P.save_predictions(pkl, tiles_dir, False, merge=True, AOI="ddp", year=None, validation_vision=False, batch_size=2)
+    out = P.save_predictions(pkl, tiles_dir, False, merge=True, all_classes=large_file, large_file=large_file, AOI="ddp8" if large_file else "ddp",
+                             year=None, validation_vision=False, batch_size=2)
     q.put((rank, None if out is None else str(out)))
     dist.barrier()
     dist.destroy_process_group()
@@ -117,3 +118,27 @@ def test_tile_sharded_prediction_two_ranks(tmp_path):
     assert res[1] is None and res[0] is not None
     got, meta = read_tiff(res[0])
     assert got.shape == ref.shape == (64, 192) and np.array_equal(got, ref)
+    # large_file = True (reference predict.py:288-289,324-329): int8 rasters of around(p * 31), int8 hit counters, integer floor
+    # division -- the 2-rank run (partial int8 rasters summed in int32 and wrapped back) equals the single process, which equals
+    # the reference's host arithmetic restated in numpy
+    single8 = P.save_predictions(pkl, tiles, False, merge=True, all_classes=True, large_file=True, AOI="single8", year=None,
+                                 validation_vision=False, batch_size=2)
+    ref8, _ = read_tiff(single8)
+    lr = P.load_learner(pkl)
+    acc = np.zeros((3, 64, 192), dtype=np.int8); cnt = np.zeros((3, 64, 192), dtype=np.int8)
+    for i in range(5):
+        _, _, pr = lr.predict(tiles / f"p{i}.tif")
+        acc[:, :, i * 32:i * 32 + 64] += np.around(pr.numpy() * 31).astype(np.int8)
+        cnt[:, :, i * 32:i * 32 + 64] += 1
+    acc[cnt > 0] //= cnt[cnt > 0]
+    assert ref8.dtype == np.int8 and np.array_equal(ref8, acc)
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, 2, port, str(pkl), str(tiles), q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    got8, _ = read_tiff(res[0])
+    assert np.array_equal(got8, ref8)

@@ -24,11 +24,9 @@ def _dtype(bits: int, fmt: int, bo: str) -> np.dtype:
     return np.dtype(f"{bo}{kind}{bits // 8}")
 
 
-def read_tiff(path) -> Tuple[np.ndarray, Dict]:
-    """Returns (array [C,H,W] (or [H,W] for one band), meta) with meta['geotransform'] = (ulx, xres, 0, uly, 0, -yres)
-    when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags."""
-    b = Path(path).read_bytes()
-    bo = {b"II": "<", b"MM": ">"}[b[:2]]
+def _parse_tags(b, path):
+    """IFD 0 of a classic TIFF held in a bytes-like object (bytes or mmap): {tag: values}, byte-order prefix"""
+    bo = {b"II": "<", b"MM": ">"}[bytes(b[:2])]
     magic = struct.unpack(bo + "H", b[2:4])[0]
     if magic != 42:
         raise NotImplementedError(f"{path}: BigTIFF / unknown magic {magic}")
@@ -36,15 +34,53 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     n = struct.unpack(bo + "H", b[off:off + 2])[0]
     tags: Dict[int, tuple] = {}
     for i in range(n):
-        e = b[off + 2 + 12 * i: off + 14 + 12 * i]
+        e = bytes(b[off + 2 + 12 * i: off + 14 + 12 * i])
         tag, typ, cnt = struct.unpack(bo + "HHI", e[:8])
         fmt, sz = _TYPES[typ]
         total = sz * cnt
-        data = e[8:8 + total] if total <= 4 else b[struct.unpack(bo + "I", e[8:12])[0]:][:total]
+        if total <= 4:
+            data = e[8:8 + total]
+        else:
+            o = struct.unpack(bo + "I", e[8:12])[0]
+            data = bytes(b[o:o + total])
         if typ == 2:
             tags[tag] = (data.rstrip(b"\0").decode("latin1"),)
         else:
             tags[tag] = struct.unpack(bo + fmt[0] * (cnt * len(fmt)), data)
+    return tags, bo
+
+
+def _geo_meta(tags) -> Dict:
+    meta = {"tags": {t: tags[t] for t in GEO_TAGS if t in tags}, "geotransform": None}
+    if 33550 in tags and 33922 in tags:
+        sx, sy = tags[33550][0], tags[33550][1]
+        i, j, _, x, y, _ = tags[33922][:6]
+        meta["geotransform"] = (x - i * sx, sx, 0.0, y + j * sy, 0.0, -sy)
+    if 42113 in tags:
+        try:
+            meta["nodata"] = float(tags[42113][0])
+        except ValueError:
+            meta["nodata"] = None
+    return meta
+
+
+def tiff_info(path) -> Dict:
+    """Header-only read (memory-mapped: the pixel data is never touched): meta of read_tiff plus 'height', 'width', 'bands'.
+    What the prediction merge needs from every tile before any of them is predicted (reference predict.py:206-222 takes the same
+    numbers from gdal.Open(...).GetGeoTransform() / RasterXSize / RasterYSize)."""
+    import mmap
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as b:
+        tags, _ = _parse_tags(b, path)
+    meta = _geo_meta(tags)
+    meta.update(height=tags[257][0], width=tags[256][0], bands=tags.get(277, (1,))[0])
+    return meta
+
+
+def read_tiff(path) -> Tuple[np.ndarray, Dict]:
+    """Returns (array [C,H,W] (or [H,W] for one band), meta) with meta['geotransform'] = (ulx, xres, 0, uly, 0, -yres)
+    when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags."""
+    b = Path(path).read_bytes()
+    tags, bo = _parse_tags(b, path)
     W, H = tags[256][0], tags[257][0]
     spp = tags.get(277, (1,))[0]
     bits = tags.get(258, (1,))[0]
@@ -78,16 +114,8 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
                 rows = min(rps, H - r0)
                 out[p, r0:r0 + rows] = np.frombuffer(b, dtype=dt, count=rows * W * pix, offset=offs[p * spi + s]).reshape(rows, W, pix)
     arr = out[:, :, :, 0] if planar == 2 else np.moveaxis(out[0], -1, 0)
-    meta = {"tags": {t: tags[t] for t in GEO_TAGS if t in tags}, "dtype": arr.dtype, "geotransform": None}
-    if 33550 in tags and 33922 in tags:
-        sx, sy = tags[33550][0], tags[33550][1]
-        i, j, _, x, y, _ = tags[33922][:6]
-        meta["geotransform"] = (x - i * sx, sx, 0.0, y + j * sy, 0.0, -sy)
-    if 42113 in tags:
-        try:
-            meta["nodata"] = float(tags[42113][0])
-        except ValueError:
-            meta["nodata"] = None
+    meta = _geo_meta(tags)
+    meta["dtype"] = arr.dtype
     return (arr[0] if arr.shape[0] == 1 else arr), meta
 
 
