@@ -209,6 +209,10 @@ int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_c
                    float* y, int y_cs, int y_co, long long P, int C, void* stream);
 int unet_colsum(const float* x, int x_cs, int x_co, long long P, int C, float* out, float* workspace, void* stream);
 size_t unet_colsum_workspace(long long P, int C);
+/* out[0] = sum over pixels and channels of x * y (fp64 second stage); workspace = unet_colsum_workspace(P, C) floats.
+ * SelfAttention.gamma gradient: sum(O * dout) (fastai layers.py SelfAttention: o = gamma * (h beta) + x). */
+int unet_dot(const float* x, int x_cs, int x_co, const float* y, int y_cs, int y_co, long long P, int C, float* out,
+             float* workspace, void* stream);
 
 /* ----------------------------------------------------------------- loss --
  * CrossEntropyLossFlat(axis=1, weight=w) (fastai losses.py; train.py:195,211):

@@ -481,3 +481,53 @@ def test_hipgraph_training_interleaved_with_eval_uses_fresh_weights():
     for a, b in zip(*evals):
         assert (a - b).abs().max().item() < 1e-5 * max(1.0, a.abs().max().item())
     assert (evals[0][0] - evals[0][1]).abs().max().item() > 1e-3        # the second phase did change the network
+
+
+def test_self_attention_row_blocks_with_recomputation_match_the_single_chunk():
+    """Blockwise SelfAttention: with a scratch budget below one N x N matrix the rows of beta^T are processed in blocks (exact
+    softmax per block, P recomputed in the backward pass, dF / dH accumulated over the blocks); with a budget of two matrices the
+    batch of 3 runs as image groups 2 + 1.  Outputs equal the single-chunk program, gradients agree to rounding, and the oracle
+    bar of the single-chunk test holds."""
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.modules import SelfAttention
+    torch.manual_seed(5)
+    size, bs = (128, 96), 3
+    ref = O.DynamicUnet("xresnet34", 4, 5, size, self_attention=True)
+    O.randomize_bn_and_zero_gammas(ref, seed=6)
+    with torch.no_grad():
+        ref.layers[5].conv2[2].gamma.fill_(0.1)
+    _make_all_active(ref)
+    x, y = O.synthetic_batch(bs, 4, size[0], size[1], 5)
+    N = (size[0] // 8) * (size[1] // 8)
+    results = []
+    old = SelfAttention.budget_elems
+    try:
+        for budget in (old, 2 * N * N, N * N // 2):
+            SelfAttention.budget_elems = budget
+            model = HipDynamicUnet("xresnet34", 4, 5, size, self_attention=True)
+            model.load_state_dict(ref.state_dict())
+            sa = model.layers[5].sa
+            chunks = sa._chunks(bs, size[0] // 8, size[1] // 8)
+            model.eval()
+            with torch.no_grad():
+                z = model(x.cuda()).clone()
+            model.train()
+            loss = model.forward_loss_backward(x.cuda(), y.cuda(), None)
+            torch.cuda.synchronize()
+            results.append((len(chunks), z.cpu(), float(loss.item()), model.flat_grad.clone().cpu()))
+    finally:
+        SelfAttention.budget_elems = old
+    assert [r[0] for r in results] == [1, 2, 6]
+    (_, z0, l0, g0) = results[0]
+    for n, z, l, g in results[1:]:
+        assert torch.equal(z, z0), n                                      # every row of T is complete in its chunk: same arithmetic
+        assert abs(l - l0) <= 1e-6 * abs(l0)
+        assert ((g - g0).double().norm() / g0.double().norm()).item() < 1e-5, n
+    ref.train()
+    loss_ref = O.CrossEntropyLossFlat()(ref(x), y)
+    loss_ref.backward()
+    assert abs(results[2][2] - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    model_grads = results[2][3]
+    gr = torch.cat([torch.cat([q.grad.flatten(), torch.zeros((-q.numel()) % 4)]) for q in ref.parameters()])
+    assert gr.numel() == model_grads.numel()
+    assert ((model_grads.double() - gr.double()).norm() / gr.double().norm()).item() < 2e-3

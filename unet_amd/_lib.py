@@ -121,6 +121,7 @@ _sig = {
     "unet_relu_mask": (i, [vp, i, i, vp, i, i, vp, i, i, ll, i, vp]),
     "unet_colsum": (i, [vp, i, i, ll, i, vp, vp, vp]),
     "unet_colsum_workspace": (sz, [ll, i]),
+    "unet_dot": (i, [vp, i, i, vp, i, i, ll, i, vp, vp, vp]),
     "unet_ce_workspace": (sz, [ll]),
     "unet_ce_fwd": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp, vp]),
     "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),

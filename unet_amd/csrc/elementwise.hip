@@ -130,6 +130,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         P, C4, TC, out0, nullptr, Cp);
 }
 
+// per-channel partial sums of x * y (self-attention: dL/dgamma = sum O * dout)
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ y, int y_cs,
+                                                  int y_co, long long P, int C4, int TC, float* out0, int Cp) {
+    channel_reduce(
+        [&](long long p, int c4, float4& v0, float4& v1) {
+            v0 = ld4(x + (size_t)p * x_cs + x_co + 4 * c4) * ld4(y + (size_t)p * y_cs + y_co + 4 * c4);
+            v1 = f4(0.f);
+        },
+        P, C4, TC, out0, nullptr, Cp);
+}
+
+// one workgroup: fp64 sum of n floats in a fixed order -> out[0]
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ part, long long n, float* __restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+
 // Sum rows of one or two [rows][stride] planes for 32 consecutive channels per workgroup:
 // 256 threads = 32 channels (tx, coalesced 128-B row segments) x 8 row lanes (ty), fp64 accumulation,
 // one LDS hop.  Result for channel c lands in thread (tx = c % 32, ty = 0).
@@ -1107,6 +1132,18 @@ extern "C" int unet_colsum(const float* x, int x_cs, int x_co, long long P, int 
     hipLaunchKernelGGL(colsum_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, workspace, Cp);
     UNET_CHECK_LAUNCH();
     hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, ST, workspace, rows, Cp, C, out);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_dot(const float* x, int x_cs, int x_co, const float* y, int y_cs, int y_co, long long P, int C, float* out,
+                        float* workspace, void* stream) {
+    UNET_CHECK_ARG(x && y && out && workspace && P > 0 && C > 0, "dot: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "dot: bad slice");
+    const int rows = stats_rows(P), C4 = c4of(C), Cp = 4 * C4, TC = pick_tc(C4);
+    hipLaunchKernelGGL(dot_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, TC, workspace, Cp);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, ST, workspace, (long long)rows * Cp, out);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

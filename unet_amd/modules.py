@@ -436,13 +436,20 @@ def icnr_init(x: torch.Tensor, scale=2, init=nn.init.kaiming_normal_) -> torch.T
 class SelfAttention(nn.Module):
     """x -> gamma * (h beta) + x with f,g,h = spectral-normed 1x1 projections, beta = softmax(f^T g, dim=1).
 
-    Device program (NHWC, rows = positions): QKV = X [Wq;Wk;Wv]^T in ONE 1x1 conv; per image b the N x N products run on the
-    MFMA conv / wgrad kernels with operands packed from activations (unet_pack_weights_strided):
+    Device program (NHWC, rows = positions): QKV = X [Wq;Wk;Wv]^T in ONE 1x1 conv; the N x N products run on the MFMA conv / wgrad
+    kernels with operands packed from activations (unet_pack_weights_strided):
         T[j][i] = sum_c G[j][c] F[i][c]      (= S^T)          P = row-softmax(T)  (= beta^T)
         O[j][c] = sum_i P[j][i] H[i][c]                        out = gamma * O + X
+    BLOCKWISE over the rows j: a chunk is either a group of whole images (one launch per product over the group,
+    unet_conv_desc.wp_img_stride) or, when one N x N matrix exceeds ``budget_elems``, a block of rows of one image.  Every row of T is
+    complete inside its chunk, so the softmax is exact without online rescaling; the chunk's T / P / dP live in two scratch buffers
+    of at most ``budget_elems`` floats each, and when there is more than one chunk P is NOT kept for the backward pass but recomputed
+    from QKV (one extra N^2 C/8 product: the flash-attention trade).  xresnet50 at 1024 x 1024 (N = 16384, 1 GiB per N x N fp32
+    matrix) therefore needs 2 x budget instead of 3 GiB per tile.
     Spectral normalisation (legacy torch.nn.utils.spectral_norm: one power iteration per training forward) acts on three
     tiny matrices and stays in torch; its backward is torch autograd on those matrices, fed with the HIP weight gradient."""
     forward = _no_forward
+    budget_elems = 1 << 28          # floats per N x N scratch buffer (1 GiB); tests lower it to force row blocks
 
     def __init__(self, n_channels):
         super().__init__()
@@ -461,10 +468,43 @@ class SelfAttention(nn.Module):
             hook(m, None)
         return m.weight
 
+    # ---- chunking: (b0, nb, j0, nj) = images [b0, b0+nb) x rows [j0, j0+nj) of their N x N attention matrix
+    def _chunks(self, B, H, W):
+        N, budget = H * W, int(self.budget_elems)
+        if N * N <= budget:
+            nb = max(1, min(B, budget // (N * N)))
+            return [(b0, min(nb, B - b0), 0, N) for b0 in range(0, B, nb)]
+        unit = 4 * W                                     # whole image rows, a multiple of the conv kernel's 4-row pixel tile
+        rows = min(N, max(unit, budget // N // unit * unit))
+        return [(b, 1, j0, min(rows, N - j0)) for b in range(B) for j0 in range(0, N, rows)]
+
+    @staticmethod
+    def _rows(buf: torch.Tensor, co: int, C: int, b0: int, nb: int, j0: int, nj: int, W: int) -> TS:
+        """rows [j0, j0+nj) of images [b0, b0+nb) of an activation buffer as a TS over [nb, nj / W, W] pixels"""
+        if j0 == 0 and nj == buf.shape[1] * buf.shape[2]:
+            return TS(buf[b0:b0 + nb], co, C)
+        cs = buf.shape[3]
+        return TS(buf[b0].view(-1, cs)[j0:j0 + nj].view(1, nj // W, W, cs), co, C)
+
+    def _scratch(self, ctx: Ctx, tag: str, chunks, N: int, nb: int, nj: int, W: int) -> TS:
+        big = max(c[1] * c[3] for c in chunks) * N
+        buf = ctx.vec(self, tag, big)
+        return TS(buf[:nb * nj * N].view(nb, nj // W, W, N), 0, N)
+
+    def _scores(self, ctx: Ctx, qkv: TS, TP: TS, ch, W: int, wpa: torch.Tensor):
+        """TP <- row-softmax(G_chunk F^T): the rows of beta^T that belong to the chunk"""
+        b0, nb, j0, nj = ch
+        N, c8, CQ = TP.C, self.c8, qkv.cs
+        img = qkv.buf.shape[1] * qkv.buf.shape[2] * CQ * 4
+        sz = int(ops.lib.unet_pack_weights_size(N, c8, 1, 0))
+        for k in range(nb):
+            ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, CQ, 1, N, c8, wpa[k * sz:])                 # (o=i, r=c) = F_b[i][c]
+        ops.conv2d(self._rows(qkv.buf, c8, c8, b0, nb, j0, nj, W), wpa, TP, 1, wp_img_stride=sz)          # T = G F^T
+        ops.row_softmax(TP, TP)                                                                            # in place
+
     def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
         B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
         N, CQ = H * W, 2 * c8 + C_
-        dev = x.buf.device
         with torch.enable_grad():
             wcat = torch.cat([self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)], 0)
             wcat = wcat.reshape(CQ, C_, 1, 1)
@@ -474,27 +514,26 @@ class SelfAttention(nn.Module):
         ops.pack_weights(wq, 0, wp)
         qkv = ctx.act(self, "qkv", B, H, W, CQ)
         ops.conv2d(x, wp, qkv, 1)
-        T = ctx.act(self, "T", B, H, W, N)
-        # per-image operand matrices are packed once per image into one buffer; every product is ONE launch over the batch
-        # (unet_conv_desc.wp_img_stride): O_b = P_b H_b alone would be 96 workgroups per image
+        chunks = self._chunks(B, H, W)
+        nbmax = max(c[1] for c in chunks)
         szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
                int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
-        wpa = ctx.vec(self, "wp_a", B * max(szs))
-        img = N * CQ * 4      # bytes per image of qkv
-        for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img, CQ, 1, N, c8, wpa[b * szs[0]:])         # (o=i, r=c) = F_b[i][c]
-        ops.conv2d(TS(qkv.buf, c8, c8), wpa, T, 1, wp_img_stride=szs[0])                         # T_b = G_b F_b^T
-        P = ctx.act(self, "P", B, H, W, N)
-        ops.row_softmax(T, P)
+        wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
         O = ctx.act(self, "O", B, H, W, C_)
-        for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, 1, CQ, C_, N, wpa[b * szs[1]:])  # (o=c, r=i) = H_b[i][c]
-        ops.conv2d(P, wpa, O, 1, wp_img_stride=szs[1])                                           # O_b = P_b H_b
+        img = N * CQ * 4      # bytes per image of qkv
+        for ch in chunks:
+            b0, nb, j0, nj = ch
+            TP = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
+            self._scores(ctx, qkv, TP, ch, W, wpa)
+            for k in range(nb):
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8, 1, CQ, C_, N, wpa[k * szs[1]:])      # (o=c, r=i) = H_b[i][c]
+            ops.conv2d(TP, wpa, self._rows(O.buf, 0, C_, b0, nb, j0, nj, W), 1, wp_img_stride=szs[1])             # O = P H
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         gvec.copy_(self.gamma.data.expand(C_))
         out = ctx.act(self, "out", B, H, W, C_)
         ops.affine_act(O, out, gvec, zvec, x2=x)
         ctx.saved[(id(self), "x")] = x
+        ctx.saved[(id(self), "P_kept")] = len(chunks) == 1      # a single chunk leaves its P in the scratch buffer for the backward
         return out
 
     def hip_bwd(self, ctx: Ctx, dout: TS) -> TS:
@@ -502,35 +541,49 @@ class SelfAttention(nn.Module):
         x: TS = ctx.saved[(id(self), "x")]
         B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
         N, CQ = H * W, 2 * c8 + C_
-        qkv, P, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "P", B, H, W, N), ctx.act(self, "O", B, H, W, C_)
+        qkv, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "O", B, H, W, C_)
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
-        self.gamma.grad.copy_((O.view() * dout.view()).sum().reshape(1))
+        ops.dot(O, dout, self.gamma.grad, ctx.workspace(ops.colsum_workspace(O.P, C_)))        # dL/dgamma = sum O * dout
         dO = ctx.act(self, "dO", B, H, W, C_)
         ops.affine_act(dout, dO, gvec, zvec)
         dqkv = ctx.act(self, "dqkv", B, H, W, CQ)
-        dP = ctx.act(self, "dP", B, H, W, N)
+        chunks = self._chunks(B, H, W)
+        kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
+        nbmax = max(c[1] for c in chunks)
         szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
                int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
-        wpa = ctx.vec(self, "wp_a", B * max(szs))
-        tmp = ctx.vec(self, "tmp", N * C_)
+        wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
+        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8)
         img = N * CQ * 4
-        for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img + 8 * c8, CQ, 1, N, C_, wpa[b * szs[2]:])  # (o=i, r=c) = H_b[i][c]
-        ops.conv2d(dO, wpa, dP, 1, wp_img_stride=szs[2])                                          # dP_b = dO_b H_b^T
-        for b in range(B):
-            dO_b, P_b = TS(dO.buf[b:b + 1], 0, C_), TS(P.buf[b:b + 1], 0, N)
-            n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
-            ops.conv2d_wgrad(dO_b, P_b, tmp, 1, 1, ctx.workspace(n))                              # dH_b = P_b^T dO_b  -> [N][C]
-            ops.copy_slice(TS(tmp[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8, C_))
-        ops.row_softmax_bwd(P, dP, dP)                                                            # dT in place
-        for b in range(B):
-            ops.pack_weights_strided(qkv.ptr + b * img, 1, CQ, c8, N, wpa[b * szs[3]:])           # (o=c, r=i) = F_b[i][c]
-        ops.conv2d(dP, wpa, TS(dqkv.buf, c8, c8), 1, wp_img_stride=szs[3])                        # dG_b = dT_b F_b
-        for b in range(B):
-            dT_b, G_b = TS(dP.buf[b:b + 1], 0, N), TS(qkv.buf[b:b + 1], c8, c8)
-            n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
-            ops.conv2d_wgrad(G_b, dT_b, tmp, 1, 1, ctx.workspace(n))                              # dF_b = dT_b^T G_b -> [N][c8]
-            ops.copy_slice(TS(tmp[:N * c8].view(1, H, W, c8), 0, c8), TS(dqkv.buf[b:b + 1], 0, c8))
+        for ch in chunks:
+            b0, nb, j0, nj = ch
+            P = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
+            if not kept:
+                self._scores(ctx, qkv, P, ch, W, wpa)                                            # recompute beta^T rows
+            dP = self._scratch(ctx, "dP", chunks, N, nb, nj, W)
+            dO_c = self._rows(dO.buf, 0, C_, b0, nb, j0, nj, W)
+            for k in range(nb):
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8, CQ, 1, N, C_, wpa[k * szs[2]:])       # (o=i, r=c) = H_b[i][c]
+            ops.conv2d(dO_c, wpa, dP, 1, wp_img_stride=szs[2])                                                     # dP = dO H^T
+            last = j0 + nj == N
+            for k in range(nb):
+                b = b0 + k
+                dO_b, P_b = self._rows(dO.buf, 0, C_, b, 1, j0, nj, W), TS(P.buf[k:k + 1], 0, N)
+                n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
+                ops.conv2d_wgrad(dO_b, P_b, tmpH, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dH_b (+)= P^T dO -> [N][C]
+                if last:
+                    ops.copy_slice(TS(tmpH[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8, C_))
+            ops.row_softmax_bwd(P, dP, dP)                                                                         # dT in place
+            for k in range(nb):
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, 1, CQ, c8, N, wpa[k * szs[3]:])                 # (o=c, r=i) = F_b[i][c]
+            ops.conv2d(dP, wpa, self._rows(dqkv.buf, c8, c8, b0, nb, j0, nj, W), 1, wp_img_stride=szs[3])          # dG = dT F
+            for k in range(nb):
+                b = b0 + k
+                dT_b, G_b = TS(dP.buf[k:k + 1], 0, N), self._rows(qkv.buf, c8, c8, b, 1, j0, nj, W)
+                n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
+                ops.conv2d_wgrad(G_b, dT_b, tmpF, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dF_b (+)= dT^T G -> [N][c8]
+                if last:
+                    ops.copy_slice(TS(tmpF[:N * c8].view(1, H, W, c8), 0, c8), TS(dqkv.buf[b:b + 1], 0, c8))
         # back through the fused QKV projection
         wcat: torch.Tensor = ctx.saved[(id(self), "wcat")]
         dw = ctx.vec(self, "dwcat", CQ * C_).view(CQ, C_, 1, 1)

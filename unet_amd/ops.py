@@ -387,6 +387,13 @@ def colsum(x: TS, out: torch.Tensor, ws: torch.Tensor):
     check(lib.unet_colsum(x.ptr, x.cs, x.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "colsum")
 
 
+def dot(x: TS, y: TS, out: torch.Tensor, ws: torch.Tensor):
+    """out[0] = sum(x * y) over all pixels and channels"""
+    _need_f32("dot", x, y)
+    assert ws.numel() >= colsum_workspace(x.P, x.C)
+    check(lib.unet_dot(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "dot")
+
+
 # ------------------------------------------------------------------ loss
 
 def ce_workspace(P) -> int:
