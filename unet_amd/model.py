@@ -227,23 +227,30 @@ class HipDynamicUnet(nn.Module):
         o: TS = ctx.saved[(id(head), "x")]
         do = head.bwd_from_dy(ctx, dz, mask=o)                  # masked by relu of the final ResBlock
         dX = L[nb + 3].bwd_nonorm(ctx, do, dx_channels=self.up_c)    # no gradient for the network-input channels of the concat
+        ctx.free(do)
         d = L[nb].hip_bwd(ctx, dX.sub(0, self.up_c))            # -> masked grad wrt UnetBlock 3 conv2 pre-activation
+        ctx.free(dX)
         dskips: Dict[int, TS] = {}
         for k in range(len(self.sz_chg_idxs) - 1, -1, -1):
             idx = self.sz_chg_idxs[k]
             s = skips[idx]
-            ds = ctx.act(self, f"dskip{idx}", s.N, s.H, s.W, s.C)
-            d = L[4 + k].hip_bwd(ctx, d, ds, False)
+            ds = ctx.tmp(s.N, s.H, s.W, s.C)                    # lives until the encoder backward reaches child idx
+            dn = L[4 + k].hip_bwd(ctx, d, ds, False)
+            ctx.free(d)
+            d = dn
             dskips[idx] = ds
         # middle_conv (d is masked wrt middle_conv[1] pre-activation)
         mids = list(L[3])
         for j in range(len(mids) - 1, -1, -1):
             xin: TS = ctx.saved[(id(mids[j]), "x")]
-            d = mids[j].bwd_from_dy(ctx, d, mask=xin)           # xin is a ReLU output in both cases (m0, mid0 out)
+            dn = mids[j].bwd_from_dy(ctx, d, mask=xin)          # xin is a ReLU output in both cases (m0, mid0 out)
+            ctx.free(d)
+            d = dn
         # post-encoder BN (ReLU already applied through the mask above)
         e: TS = ctx.saved[(id(self), "e")]
-        de = ctx.act(self, "de", e.N, e.H, e.W, e.C)
+        de = ctx.tmp(e.N, e.H, e.W, e.C)
         self._post_bx.bwd(ctx, d, None, e, de)
+        ctx.free(d)
         hook = self.grad_ready_hook
         if hook is not None:
             hook(self._decoder_offset)
@@ -254,19 +261,28 @@ class HipDynamicUnet(nn.Module):
             child = children[i]
             if i in dskips and i != len(children) - 1:
                 ops.copy_slice(dskips[i], d, accumulate=True)   # skip gradient joins the encoder gradient
+                ctx.free(dskips.pop(i))
             if i > 3:
                 for blk in reversed(list(child)):
-                    d = blk.hip_bwd(ctx, d)
+                    dn = blk.hip_bwd(ctx, d)
+                    ctx.free(d)
+                    d = dn
             elif i == 3:
                 xin: TS = ctx.saved[(id(child), "x")]
                 idxb = ctx.vec(child, f"idx{d.N}x{d.H}x{d.W}", d.N * d.H * d.W * d.C, dtype=torch.uint8)
-                dx = ctx.act(child, "dx", xin.N, xin.H, xin.W, xin.C)
+                dx = ctx.tmp(xin.N, xin.H, xin.W, xin.C)
                 ops.maxpool_bwd(d, idxb, dx)
+                ctx.free(d)
                 d = dx
             else:
-                d = child.hip_bwd(ctx, d, need_dx=(i != 0))
+                dn = child.hip_bwd(ctx, d, need_dx=(i != 0))
+                ctx.free(d)
+                d = dn
             if hook is not None and i in self._enc_child_offset:
                 hook(self._enc_child_offset[i])
+        for t in dskips.values():
+            ctx.free(t)
+        assert not ctx._pool_live, "a backward temporary was not returned to the pool"
 
     # ------------------------------------------------------------------ torch-facing surface
     def forward(self, x: torch.Tensor) -> torch.Tensor:

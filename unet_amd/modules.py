@@ -43,6 +43,10 @@ class Ctx:
         self.need_grad = True
         self._acts: Dict[tuple, TS] = {}
         self._vecs: Dict[tuple, torch.Tensor] = {}
+        self._pool: Dict[tuple, list] = {}
+        self._pool_all: List[torch.Tensor] = []
+        self._pool_key: Dict[int, tuple] = {}
+        self._pool_live: set = set()
         self._ws: Optional[torch.Tensor] = None
         self.saved: Dict[tuple, object] = {}
         # bumped whenever parameter memory is rewritten behind torch's back (HIP Adam step, all-reduce ...):
@@ -57,6 +61,37 @@ class Ctx:
             t = ops.new_act(N, H, W, C, self.device, zero=zero, dtype=self.act_dtype if dtype is None else dtype)
             self._acts[key] = t
         return t
+
+    # Backward temporaries (activation gradients): every one is written by one backward block and read by the next, so they come
+    # from a pool keyed by geometry and go back to it as soon as their consumer has been launched (launches are stream ordered:
+    # the next user of the memory is queued behind the last reader).  LIFO free lists + a fixed program order = the same buffer
+    # for the same role in every step, i.e. addresses stay static for hipGraph capture.  Padding lanes (cs != C) are zero at
+    # allocation and every user of a (N, H, W, C) class writes only real channels or zeros there.
+    def tmp(self, N, H, W, C, dtype=None) -> TS:
+        dt = self.act_dtype if dtype is None else dtype
+        key = (N, H, W, C, dt)
+        free = self._pool.setdefault(key, [])
+        if free:
+            buf = free.pop()
+        else:
+            buf = ops.new_act(N, H, W, C, self.device, zero=True, dtype=dt).buf
+            self._pool_all.append(buf)
+            self._pool_key[buf.data_ptr()] = key
+        self._pool_live.add(buf.data_ptr())
+        return TS(buf, 0, C)
+
+    def free(self, t: Optional[TS]):
+        """return a ctx.tmp() buffer (any channel slice of it) to the pool; None and non-pool buffers are ignored"""
+        if t is None:
+            return
+        ptr = t.buf.data_ptr()
+        key = self._pool_key.get(ptr)
+        if key is None:
+            return
+        if ptr not in self._pool_live:
+            raise RuntimeError("backward temporary freed twice")
+        self._pool_live.discard(ptr)
+        self._pool[key].append(t.buf)
 
     def vec(self, owner, tag, n, dtype=torch.float32) -> torch.Tensor:
         key = (id(owner), tag, n, dtype)
@@ -74,6 +109,7 @@ class Ctx:
 
     def bytes_allocated(self) -> int:
         n = sum(t.buf.numel() * t.buf.element_size() for t in self._acts.values()) + sum(v.numel() * v.element_size() for v in self._vecs.values())
+        n += sum(b.numel() * b.element_size() for b in self._pool_all)
         return n + (0 if self._ws is None else self._ws.numel() * 4)
 
 
@@ -253,19 +289,22 @@ class ConvLayer(nn.Sequential):
         x: TS = ctx.saved[(id(self), "x")]
         y = ctx.act(self, "y", da.N, da.H, da.W, self.nf)
         a = ctx.act(self, "a", da.N, da.H, da.W, self.nf)
-        dy = ctx.act(self, "dy", da.N, da.H, da.W, self.nf)
+        dy = ctx.tmp(da.N, da.H, da.W, self.nf)
         self.bx.bwd(ctx, da, a if self.has_act else None, y, dy)
-        return self.bwd_from_dy(ctx, dy, need_dx, dx_res)
+        dx = self.bwd_from_dy(ctx, dy, need_dx, dx_res)
+        ctx.free(dy)
+        return dx
 
     def bwd_from_dy(self, ctx: Ctx, dy: TS, need_dx=True, dx_res: Optional[TS] = None, mask: Optional[TS] = None,
                     dx_channels: Optional[int] = None) -> Optional[TS]:
         """dy = dL/d(conv output).  wgrad (+bias) then dgrad; `mask` fuses the ReLU backward of the producer of x.
-        dx_channels: only the first dx_channels input channels need a gradient (the rest is the network input)."""
+        dx_channels: only the first dx_channels input channels need a gradient (the rest is the network input).
+        The returned dx is a ctx.tmp() buffer owned by the caller (ctx.free it after its last reader); dy stays the caller's."""
         x: TS = ctx.saved[(id(self), "x")]
         self.cx.bwd_w(ctx, x, dy)
         if not need_dx:
             return None
-        dx = ctx.act(self, "dx", x.N, x.H, x.W, x.C)
+        dx = ctx.tmp(x.N, x.H, x.W, x.C)
         if dx_channels is not None and dx_channels < x.C and (dx_channels + 127) // 128 == (x.C + 127) // 128:
             # same packed-filter padding: the kernel simply produces fewer channels
             self.cx.bwd_x(dy, dx.sub(0, dx_channels), res=None if dx_res is None else dx_res.sub(0, dx_channels),
@@ -332,27 +371,33 @@ class ResBlock(nn.Module):
         last: ConvLayer = self.convpath[-1]
         out = ctx.act(self, "out", dout.N, dout.H, dout.W, self.nf)
         y2 = ctx.act(last, "y", dout.N, dout.H, dout.W, self.nf)
-        dy2 = ctx.act(last, "dy", dout.N, dout.H, dout.W, self.nf)
+        dy2 = ctx.tmp(dout.N, dout.H, dout.W, self.nf)
         # identity branch first so that its gradient can be fused into the conv path's last dgrad
         if self.idconv is not None:
             last.bx.bwd(ctx, dout, out, y2, dy2)
             yi = ctx.act(self.idconv, "y", dout.N, dout.H, dout.W, self.nf)
-            dyi = ctx.act(self.idconv, "dy", dout.N, dout.H, dout.W, self.nf)
+            dyi = ctx.tmp(dout.N, dout.H, dout.W, self.nf)
             self.idconv.bx.bwd(ctx, dout, out, yi, dyi)
             dp = self.idconv.bwd_from_dy(ctx, dyi, need_dx=need_dx)
+            ctx.free(dyi)
         else:
-            dp = ctx.act(self, "g", dout.N, dout.H, dout.W, self.nf)
+            dp = ctx.tmp(dout.N, dout.H, dout.W, self.nf)
             last.bx.bwd(ctx, dout, out, y2, dy2, gout=dp)
         dxb = dp
         if need_dx and self.pool:
-            dxb = ctx.act(self, "dpool", x.N, x.H, x.W, x.C)
+            dxb = ctx.tmp(x.N, x.H, x.W, x.C)
             ops.avgpool_bwd(dp, dxb)
+            ctx.free(dp)
         # conv path, last to first
         d = last.bwd_from_dy(ctx, dy2)
+        ctx.free(dy2)
         cls = list(self.convpath)[:-1]
         for i in range(len(cls) - 1, -1, -1):
             first = i == 0
-            d = cls[i].hip_bwd(ctx, d, need_dx=(need_dx or not first), dx_res=dxb if first else None)
+            dn = cls[i].hip_bwd(ctx, d, need_dx=(need_dx or not first), dx_res=dxb if first else None)
+            ctx.free(d)
+            d = dn
+        ctx.free(dxb)                  # consumed as the residual of the first conv's input gradient (or unused when not need_dx)
         return d
 
     # ------------------------------------------------------------ decoder flavour (no norm)
@@ -373,7 +418,9 @@ class ResBlock(nn.Module):
         c1, c2 = self.convpath[0], self.convpath[1]
         t1: TS = ctx.saved[(id(c2), "x")]
         dt1 = c2.bwd_from_dy(ctx, dout_pre, mask=t1)
-        return c1.bwd_from_dy(ctx, dt1, dx_res=dout_pre, dx_channels=dx_channels)
+        dx = c1.bwd_from_dy(ctx, dt1, dx_res=dout_pre, dx_channels=dx_channels)
+        ctx.free(dt1)
+        return dx
 
 
 class PixelShuffle_ICNR(nn.Sequential):
@@ -410,14 +457,17 @@ class PixelShuffle_ICNR(nn.Sequential):
         cl: ConvLayer = self[0]
         up_in: TS = ctx.saved[(id(cl), "x")]
         yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
-        dyc = ctx.act(cl, "dy", up_in.N, up_in.H, up_in.W, 4 * self.nf)
+        dyc = ctx.tmp(up_in.N, up_in.H, up_in.W, 4 * self.nf)
         if (2 * up_in.H, 2 * up_in.W) == (d_dst.H, d_dst.W):
             ops.shuffle_blur_bwd(d_dst, yc, dyc, self.blur)
         else:
-            tmp = ctx.act(self, "dup", up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
+            tmp = ctx.tmp(up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
             ops.resize_nearest_bwd(d_dst, tmp)
             ops.shuffle_blur_bwd(tmp, yc, dyc, self.blur)
-        return cl.bwd_from_dy(ctx, dyc, mask=up_in if mask_input else None)
+            ctx.free(tmp)
+        dx = cl.bwd_from_dy(ctx, dyc, mask=up_in if mask_input else None)
+        ctx.free(dyc)
+        return dx
 
 
 def icnr_init(x: torch.Tensor, scale=2, init=nn.init.kaiming_normal_) -> torch.Tensor:
@@ -544,9 +594,9 @@ class SelfAttention(nn.Module):
         qkv, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "O", B, H, W, C_)
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         ops.dot(O, dout, self.gamma.grad, ctx.workspace(ops.colsum_workspace(O.P, C_)))        # dL/dgamma = sum O * dout
-        dO = ctx.act(self, "dO", B, H, W, C_)
+        dO = ctx.tmp(B, H, W, C_)
         ops.affine_act(dout, dO, gvec, zvec)
-        dqkv = ctx.act(self, "dqkv", B, H, W, CQ)
+        dqkv = ctx.tmp(B, H, W, CQ)
         chunks = self._chunks(B, H, W)
         kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
         nbmax = max(c[1] for c in chunks)
@@ -591,8 +641,10 @@ class SelfAttention(nn.Module):
         ops.conv2d_wgrad(x, dqkv, dw, 1, 1, ctx.workspace(n))
         wpd = ctx.vec(self, "wp_d", ops.lib.unet_pack_weights_size(CQ, C_, 1, 1))
         ops.pack_weights(wcat.detach().contiguous(), 1, wpd)
-        dx = ctx.act(self, "dx", B, H, W, C_)
+        dx = ctx.tmp(B, H, W, C_)
         ops.conv2d_dgrad(dqkv, wpd, dx, 1, 1, res=dout)                                           # + identity branch
+        ctx.free(dO)
+        ctx.free(dqkv)
         for seq in (self.query, self.key, self.value):
             seq[0].weight_orig.grad.zero_()
         wcat.backward(dw)                                                                         # spectral-norm backward (torch, tiny)
@@ -648,16 +700,22 @@ class UnetBlock(nn.Module):
         s: TS = ctx.saved[(id(self), "s")]
         X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
         t1: TS = ctx.saved[(id(self.conv2), "x")]
+        own = None
         if self.sa is not None:
             t2 = ctx.act(self.conv2, "a", s.N, s.H, s.W, self.out_channels)
             d_t2 = self.sa.hip_bwd(ctx, dt2_pre)
-            dt2_pre = ctx.act(self, "dt2", s.N, s.H, s.W, self.out_channels)
+            dt2_pre = own = ctx.tmp(s.N, s.H, s.W, self.out_channels)
             ops.relu_mask(d_t2, t2, dt2_pre)
+            ctx.free(d_t2)
         dt1 = self.conv2.bwd_from_dy(ctx, dt2_pre, mask=t1)
+        ctx.free(own)
         dX = self.conv1.bwd_from_dy(ctx, dt1, mask=X)          # relu(cat) backward fused
+        ctx.free(dt1)
         assert not dskip_accumulate
         self.bx.bwd(ctx, dX.sub(self.cu, self.cs), None, s, dskip)
-        return self.shuf.hip_bwd(ctx, dX.sub(0, self.cu), mask_input=self.up_is_relu)
+        d = self.shuf.hip_bwd(ctx, dX.sub(0, self.cu), mask_input=self.up_is_relu)
+        ctx.free(dX)
+        return d
 
 
 def _kaiming_init(*mods):
