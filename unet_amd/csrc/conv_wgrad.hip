@@ -467,24 +467,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         int bq[NTW];
 #pragma unroll
         for (int q = 0; q < NTW; ++q) bq[q] = bfix[q] + ((oy + 2 + brow[q]) % 3) * (HW * LD);   // tap row r reads input row oy - 1 + r
-        // (a full unroll hoists all 96 operand loads and spills; the 42-accumulator form only has room for one step's operands)
-        auto mma_step = [&](int step) {
-            float av[KT], bv[NTW];
+        // Operands are double buffered in registers: the 12 / 13 ds_read_b32 of step s + 1 are issued BEFORE the 35 / 42 MFMAs of
+        // step s and land behind them (a compiler-scheduled loop read them lazily, a few at a time, with an exposed
+        // s_waitcnt lgkmcnt(0) in front of every group of MFMAs).  The sched_barrier pins "loads first"; everything is unrolled
+        // so that both register sets are addressed statically.
+        float av[2][KT], bv[2][NTW];
+        auto ld_ops = [&](int step, float (&a_)[KT], float (&b_)[NTW]) {
 #pragma unroll
-            for (int m = 0; m < KT; ++m) av[m] = dyT[abase + step * 4 * LD + m * 16];
+            for (int m = 0; m < KT; ++m) a_[m] = dyT[abase + step * 4 * LD + m * 16];
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) bv[q] = xh[bq[q] + step * 4 * LD];
+            for (int q = 0; q < NTW; ++q) b_[q] = xh[bq[q] + step * 4 * LD];
+        };
+        ld_ops(0, av[0], bv[0]);
+#pragma unroll
+        for (int step = 0; step < PT / 4; ++step) {
+            if (step + 1 < PT / 4) {
+                ld_ops(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int m = 0; m < KT; ++m)
 #pragma unroll
-                for (int q = 0; q < NTW; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[q], acc[m][q], 0, 0, 0);
-        };
-        if constexpr (KT * NTW > 36) {
-#pragma unroll 1
-            for (int step = 0; step < PT / 4; ++step) mma_step(step);
-        } else {
-#pragma unroll 2
-            for (int step = 0; step < PT / 4; ++step) mma_step(step);
+                for (int q = 0; q < NTW; ++q)
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m], bv[step & 1][q], acc[m][q], 0, 0, 0);
         }
         if (has_next) {
             __syncthreads();                 // everyone is done reading this tile (the new row replaces row oy - 1)

@@ -47,6 +47,7 @@ class Ctx:
         self._pool_all: List[torch.Tensor] = []
         self._pool_key: Dict[int, tuple] = {}
         self._pool_live: set = set()
+        self._pool_flat: Dict[int, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self.saved: Dict[tuple, object] = {}
         # bumped whenever parameter memory is rewritten behind torch's back (HIP Adam step, all-reduce ...):
@@ -69,16 +70,30 @@ class Ctx:
     # allocation and every user of a (N, H, W, C) class writes only real channels or zeros there.
     def tmp(self, N, H, W, C, dtype=None) -> TS:
         dt = self.act_dtype if dtype is None else dtype
-        key = (N, H, W, C, dt)
-        free = self._pool.setdefault(key, [])
-        if free:
-            buf = free.pop()
+        cs = ops.rupv(C, dt)
+        n = N * H * W * cs
+        if cs != C:
+            # padded channel count (rare: 3-band input, class count): exact-geometry class, so that the padding lanes stay zero
+            key = ("exact", N, H, W, C, dt)
+            free = self._pool.setdefault(key, [])
+            flat = free.pop() if free else None
         else:
-            buf = ops.new_act(N, H, W, C, self.device, zero=True, dtype=dt).buf
-            self._pool_all.append(buf)
-            self._pool_key[buf.data_ptr()] = key
-        self._pool_live.add(buf.data_ptr())
-        return TS(buf, 0, C)
+            # best fit by capacity over ALL geometries of this storage type: the pool's size is the peak of simultaneously live
+            # bytes, not the sum of the per-shape peaks
+            key = ("flat", dt)
+            free = self._pool.setdefault(key, [])
+            best = -1
+            for i, b in enumerate(free):
+                if b.numel() >= n and (best < 0 or b.numel() < free[best].numel()):
+                    best = i
+            flat = free.pop(best) if best >= 0 else None
+        if flat is None:
+            flat = torch.zeros(n, dtype=dt, device=self.device)
+            self._pool_all.append(flat)
+            self._pool_key[flat.data_ptr()] = key
+        self._pool_live.add(flat.data_ptr())
+        self._pool_flat[flat.data_ptr()] = flat
+        return TS(flat[:n].view(N, H, W, cs), 0, C)
 
     def free(self, t: Optional[TS]):
         """return a ctx.tmp() buffer (any channel slice of it) to the pool; None and non-pool buffers are ignored"""
@@ -91,7 +106,7 @@ class Ctx:
         if ptr not in self._pool_live:
             raise RuntimeError("backward temporary freed twice")
         self._pool_live.discard(ptr)
-        self._pool[key].append(t.buf)
+        self._pool[key].append(self._pool_flat[ptr])
 
     def vec(self, owner, tag, n, dtype=torch.float32) -> torch.Tensor:
         key = (id(owner), tag, n, dtype)
