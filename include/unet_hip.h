@@ -115,6 +115,8 @@ int unet_pack_weights_strided(const float* w, long long so, long long sr, float*
 /* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32) */
 size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode); /* elements */
 int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream);
+/* bf16 conv: 256-pixel x 128-channel workgroup tile for large layers on/off (default on; results identical, A/B knob) */
+int unet_set_bf16_big_tile(int on);
 
 /* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
  * Replaces the autograd weight-gradient of the same nn.Conv2d modules.

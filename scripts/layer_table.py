@@ -8,7 +8,8 @@ from unet_amd.optimizer import FlatAdam
 from unet_amd.trainer import TrainStep
 
 torch.manual_seed(0)
-m = HipDynamicUnet("xresnet34", 4, 5, (512, 512)); m.train()
+DT = os.environ.get("UNET_DTYPE", "f32")       # f32 | bf16
+m = HipDynamicUnet("xresnet34", 4, 5, (512, 512), act_dtype=DT); m.train()
 st = TrainStep(m, FlatAdam(m, [1e-5, 3e-5, 1e-4]), torch.full((5,), 0.2, device="cuda"))
 g = torch.Generator().manual_seed(1)
 x = (torch.randint(0, 256, (16, 4, 512, 512), generator=g).float() / 255).cuda(); y = torch.randint(0, 5, (16, 512, 512), generator=g).cuda()

@@ -92,6 +92,7 @@ _sig = {
     "unet_set_wgrad_mfma_shape": (i, [i]),
     "unet_set_wgrad_narrow": (i, [i]),
     "unet_set_wgrad_1x1": (i, [i]),
+    "unet_set_bf16_big_tile": (i, [i]),
     "unet_pack_weights_size": (sz, [i, i, i, i]),
     "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
     "unet_pack_weights_strided": (i, [vp, ll, ll, vp, i, i, vp]),

@@ -277,6 +277,15 @@ int launch_cfg(const Plan& p, int y_f32, hipStream_t st) {
 
 template <int TW, int HIT>
 int launch_bn(const Plan& p, int y_f32, hipStream_t st) {
+    if (p.bm == 256) {          // (TW = 32, HIT = 6 by construction of the plan)
+        if constexpr (TW == 32 && HIT == 6) return launch_cfg<32, 4, 2, 2, 2, 6>(p, y_f32, st);
+        unet::set_error("conv bf16: inconsistent plan for the 256-pixel tile");
+        return UNET_E_UNSUPPORTED;
+    }
+    if constexpr (HIT == 6) {
+        unet::set_error("conv bf16: inconsistent plan (halo item count 6 without the 256-pixel tile)");
+        return UNET_E_UNSUPPORTED;
+    } else
     if (p.bm == 64) {
         if (p.bn == 64) return launch_cfg<TW, 1, 1, 2, 2, HIT>(p, y_f32, st);
         return launch_cfg<TW, 1, 2, 2, 2, HIT>(p, y_f32, st);
@@ -297,8 +306,10 @@ int launch_tw(const Plan& p, int y_f32, hipStream_t st) {
     }
 }
 
+int g_big_tile = 1;       // 256-pixel workgroup tile for the large bf16 layers (unet_set_bf16_big_tile)
+
 int plan_bf16(const unet_conv_desc* d, Plan* p) {
-    int rc = unetconv::make_plan(d, p, KCB, 8, 16);
+    int rc = unetconv::make_plan(d, p, KCB, 8, 16, g_big_tile);
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
     UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
@@ -315,6 +326,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     Plan p;
     int rc = plan_bf16(d, &p);
     if (rc != UNET_OK) return rc;
+    if (p.hit == 6) return launch_bn<32, 6>(p, d->y_f32, st);
     return (p.hit == 10) ? launch_tw<10>(p, d->y_f32, st) : launch_tw<4>(p, d->y_f32, st);
 }
 
@@ -322,10 +334,15 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
     Plan p;
     int rc = plan_bf16(d, &p);
     if (rc != UNET_OK) return rc;
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0);
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? 7 : 0);
 }
 
 }  // namespace unetconv
+
+extern "C" int unet_set_bf16_big_tile(int on) {
+    g_big_tile = on ? 1 : 0;
+    return UNET_OK;
+}
 
 extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void gld_b(v4f (&d)[N], unsigned voff, const char* p)
 // it could schedule between a load and its wait.
 template <int N>
 __device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], const void* p, bool fetch) {
-    static_assert(N == 4 || N == 10, "halo items per thread");
+    static_assert(N == 4 || N == 6 || N == 10, "halo items per thread");
     const u64 sb = sgpr_ptr(p);
     const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
     u64 sv;
@@ -79,6 +79,15 @@ __device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], c
                      "s_mov_b64 exec, %[sv]"
                      : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [sv] "=&s"(sv)
                      : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [sb] "s"(sb), [on] "s"(on)
+                     : "scc");   // s_and_saveexec writes SCC
+    } else if constexpr (N == 6) {
+        asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+                     "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
+                     "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
+                     "global_load_dwordx4 %[h4], %[o4], %[sb]\n\tglobal_load_dwordx4 %[h5], %[o5], %[sb]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]), [sv] "=&s"(sv)
+                     : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]), [sb] "s"(sb), [on] "s"(on)
                      : "scc");   // s_and_saveexec writes SCC
     } else {
         asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
@@ -99,16 +108,20 @@ __device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], c
 // that no consumer is scheduled above it
 template <int NB, int NH>
 __device__ __forceinline__ void wait_loads(v4f (&b)[NB], v4f (&h)[NH]) {
-    static_assert((NB == 2 || NB == 4) && (NH == 4 || NH == 10), "register groups");
+    static_assert((NB == 2 || NB == 4) && (NH == 4 || NH == 6 || NH == 10), "register groups");
     // ONE statement (a tied operand's input copy, if the compiler ever made one, must not be able to slip in front of the
     // s_waitcnt of a sibling statement); 14 tied operands = 28 of the 30 asm operands allowed
 #define UNET_H4 "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
+#define UNET_H6 UNET_H4, "+v"(h[4]), "+v"(h[5])
 #define UNET_H10 UNET_H4, "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]), "+v"(h[8]), "+v"(h[9])
-    if constexpr (NB == 2 && NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H4);
+    if constexpr (NB == 4 && NH == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H6);
+    else if constexpr (NB == 2 && NH == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H6);
+    else if constexpr (NB == 2 && NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H4);
     else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), UNET_H10);
     else if constexpr (NH == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H4);
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), UNET_H10);
 #undef UNET_H4
+#undef UNET_H6
 #undef UNET_H10
 }
 
@@ -121,7 +134,8 @@ struct Plan {
 
 // kc: reduction channels per chunk (16 fp32 / 32 bf16 = 64 bytes); vec: channels per 16-byte access (4 fp32 / 8 bf16): channel
 // strides, offsets and the zero-padded channel count of a slice are multiples of vec; mf: MFMA shape of the fp32 kernels (16 | 32)
-static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf) {
+// big_tile: allow the 256-pixel workgroup tile (bf16 kernel: the math is 16x cheaper, so halving the filter-operand loads per MFMA pays)
+static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf, int big_tile = 0) {
     UNET_CHECK_ARG(d != nullptr, "conv: null desc");
     UNET_CHECK_ARG(d->x && d->wp && d->y, "conv: null tensor pointer");
     UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv: ks must be 1 or 3 (got %d)", d->ks);
@@ -234,6 +248,10 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     if (p->bn >= 64 && blocks(128, p->bn) < 400) {
         p->bm = 64;
         if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
+    }
+    if (big_tile && p->bm == 128 && p->bn == 128 && p->tw == 32 && k.S == 1 && p->nparity == 1 && blocks(256, 128) >= 512) {
+        p->bm = 256;          // 8 x 32 pixel patch per workgroup, each wave 128 pixels x 64 channels
+        p->hit = 6;
     }
     const int th = p->bm / p->tw;
     k.tiles_y = unet::cdiv(k.TSH, th);

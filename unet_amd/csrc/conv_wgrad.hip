@@ -467,29 +467,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         int bq[NTW];
 #pragma unroll
         for (int q = 0; q < NTW; ++q) bq[q] = bfix[q] + ((oy + 2 + brow[q]) % 3) * (HW * LD);   // tap row r reads input row oy - 1 + r
-        // Operands are double buffered in registers: the 12 / 13 ds_read_b32 of step s + 1 are issued BEFORE the 35 / 42 MFMAs of
-        // step s and land behind them (a compiler-scheduled loop read them lazily, a few at a time, with an exposed
-        // s_waitcnt lgkmcnt(0) in front of every group of MFMAs).  The sched_barrier pins "loads first"; everything is unrolled
-        // so that both register sets are addressed statically.
-        float av[2][KT], bv[2][NTW];
-        auto ld_ops = [&](int step, float (&a_)[KT], float (&b_)[NTW]) {
+        // (a full unroll hoists all 96 operand loads and spills; the 42-accumulator form only has room for one step's operands)
+        auto mma_step = [&](int step) {
+            float av[KT], bv[NTW];
 #pragma unroll
-            for (int m = 0; m < KT; ++m) a_[m] = dyT[abase + step * 4 * LD + m * 16];
+            for (int m = 0; m < KT; ++m) av[m] = dyT[abase + step * 4 * LD + m * 16];
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) b_[q] = xh[bq[q] + step * 4 * LD];
-        };
-        ld_ops(0, av[0], bv[0]);
-#pragma unroll
-        for (int step = 0; step < PT / 4; ++step) {
-            if (step + 1 < PT / 4) {
-                ld_ops(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int q = 0; q < NTW; ++q) bv[q] = xh[bq[q] + step * 4 * LD];
 #pragma unroll
             for (int m = 0; m < KT; ++m)
 #pragma unroll
-                for (int q = 0; q < NTW; ++q)
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m], bv[step & 1][q], acc[m][q], 0, 0, 0);
+                for (int q = 0; q < NTW; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+        };
+        if constexpr (KT * NTW > 36) {
+#pragma unroll 1
+            for (int step = 0; step < PT / 4; ++step) mma_step(step);
+        } else {
+#pragma unroll 2
+            for (int step = 0; step < PT / 4; ++step) mma_step(step);
         }
         if (has_next) {
             __syncthreads();                 // everyone is done reading this tile (the new row replaces row oy - 1)
@@ -545,9 +540,12 @@ __device__ __forceinline__ bf16x8 ld_tr_pair(const char* p0, const char* p1) {
 
 template <int PTW, int S, int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
-    constexpr int PT = 32, PTH = PT / PTW, PAD = (KS - 1) / 2, T = KS * KS;
+    // pixel tile = PT pixels = KB MFMA k-blocks of 32 (a PTH x PTW patch); the next tile is fetched global -> registers while the
+    // current one is multiplied, and stored to LDS behind it (one barrier pair per KB * T * 4 MFMAs per wave)
+    constexpr int KB = (S == 1) ? 4 : 1, PT = 32 * KB, PTH = PT / PTW, PAD = (KS - 1) / 2, T = KS * KS;     // (stride 2: the halo of 128 pixels would not fit the prefetch registers)
     constexpr int HH = (PTH - 1) * S + KS, HW = (PTW - 1) * S + KS, HPIX = HH * HW;
     constexpr int RSD = 160, RSX = (S == 1) ? 160 : 144;         // LDS row strides in bytes (64 channels = 128 bytes + pad)
+    constexpr int DIT = PT * 8 / 256;                            // 16-byte dy items per thread
     constexpr int XIT = (HPIX * 8 + 255) / 256;                  // 16-byte x items per thread
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smemb[];
@@ -574,7 +572,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
 
     const u16* xg = reinterpret_cast<const u16*>(a.x);
     const u16* dyg = reinterpret_cast<const u16*>(a.dy);
-    auto stage_tile = [&](int tile) {
+    uint4 rd[DIT], rx[XIT];
+    auto load_tile = [&](int tile) {
         int b = tile;
         const int tx = b % a.tiles_x; b /= a.tiles_x;
         const int ty = b % a.tiles_y;
@@ -582,69 +581,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
         const int oy0 = ty * PTH, ox0 = tx * PTW;
         const u16* dyb = dyg + (size_t)img * a.OH * a.OW * a.dy_cs;
         const u16* xb = xg + (size_t)img * a.IH * a.IW * a.x_cs;
-        {   // dy tile: 32 pixels x 8 items of 8 channels = one 16-byte item per thread
-            const int p = tid >> 3, qq = tid & 7;
+#pragma unroll
+        for (int j = 0; j < DIT; ++j) {
+            const int e = tid + j * 256;
+            const int p = e >> 3, qq = e & 7;
             const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
             const bool ok = oy < a.OH && ox < a.OW && (k0 + 8 * qq) < a.Cout4;
-            const uint4 v = ok ? *reinterpret_cast<const uint4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 8 * qq)
-                               : make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(dyT + p * RSD + qq * 16) = v;
+            rd[j] = ok ? *reinterpret_cast<const uint4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 8 * qq) : make_uint4(0u, 0u, 0u, 0u);
         }
         const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-        uint4 r[XIT];
 #pragma unroll
         for (int j = 0; j < XIT; ++j) {
             const int e = tid + j * 256;
             const int p = e >> 3, qq = e & 7;
             const int iy = iy0 + p / HW, ix = ix0 + p % HW;
             const bool ok = (e < HPIX * 8) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 8 * qq) < a.Cin4;
-            r[j] = ok ? *reinterpret_cast<const uint4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 8 * qq) : make_uint4(0u, 0u, 0u, 0u);
+            rx[j] = ok ? *reinterpret_cast<const uint4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 8 * qq) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < DIT; ++j) {
+            const int e = tid + j * 256;
+            *reinterpret_cast<uint4*>(dyT + (e >> 3) * RSD + (e & 7) * 16) = rd[j];
         }
 #pragma unroll
         for (int j = 0; j < XIT; ++j) {
             const int e = tid + j * 256;
-            if (e < HPIX * 8) *reinterpret_cast<uint4*>(xh + (e >> 3) * RSX + (e & 7) * 16) = r[j];
+            if (e < HPIX * 8) *reinterpret_cast<uint4*>(xh + (e >> 3) * RSX + (e & 7) * 16) = rx[j];
         }
     };
 
-    // per-lane transposed-read addresses: this lane supplies pixel row P1 = 4g + q (first read) / P2 = 16 + 4g + q (second), columns 4pp..4pp+3
+    // per-lane transposed-read addresses inside k-block 0: this lane supplies pixel row P1 = 4g + q (first read) / P2 = 16 + 4g + q
+    // (second), columns 4pp..4pp+3; k-block kb adds 32 pixels
     const int P1 = 4 * g + q, P2 = 16 + 4 * g + q;
     const char* a1 = dyT + P1 * RSD + (wk * 32 + 4 * pp) * 2;
     const char* a2 = dyT + P2 * RSD + (wk * 32 + 4 * pp) * 2;
-    const int xr1 = ((P1 / PTW) * S * HW + (P1 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
-    const int xr2 = ((P2 / PTW) * S * HW + (P2 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
+    int xr1[KB], xr2[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int p1 = 32 * kb + P1, p2 = 32 * kb + P2;
+        xr1[kb] = ((p1 / PTW) * S * HW + (p1 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
+        xr2[kb] = ((p2 / PTW) * S * HW + (p2 % PTW) * S) * RSX + (wc * 32 + 4 * pp) * 2;
+    }
     // which of this wave's 2 x 2 tiles hold real channels (wave-uniform)
     const bool mv1 = k0 + wk * 32 + 16 < a.Cout, nv1 = c0 + wc * 32 + 16 < a.Cin;
     const bool mv0 = k0 + wk * 32 < a.Cout, nv0 = c0 + wc * 32 < a.Cin;
 
     const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
     float bsum = 0.f;
+    if (tile_begin < tile_end) {
+        load_tile(tile_begin);
+        store_tile();
+    }
+    __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        stage_tile(tile);
-        __syncthreads();
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) load_tile(tile + 1);
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += __uint_as_float((unsigned)*reinterpret_cast<const u16*>(dyT + p * RSD + tid * 2) << 16);
         }
         if (mv0 && nv0) {
-            const bf16x8 av0 = ld_tr_pair(a1, a2);
-            const bf16x8 av1 = ld_tr_pair(a1 + 32, a2 + 32);
 #pragma unroll
-            for (int r = 0; r < KS; ++r)
+            for (int kb = 0; kb < KB; ++kb) {
+                const bf16x8 av0 = ld_tr_pair(a1 + kb * 32 * RSD, a2 + kb * 32 * RSD);
+                const bf16x8 av1 = ld_tr_pair(a1 + kb * 32 * RSD + 32, a2 + kb * 32 * RSD + 32);
 #pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    const int t = r * KS + s_;
-                    const int off = (r * HW + s_) * RSX;
-                    const bf16x8 bv0 = ld_tr_pair(xh + xr1 + off, xh + xr2 + off);
-                    acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv0, acc[0][0][t], 0, 0, 0);
-                    if (mv1) acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv0, acc[1][0][t], 0, 0, 0);
-                    if (nv1) {
-                        const bf16x8 bv1 = ld_tr_pair(xh + xr1 + off + 32, xh + xr2 + off + 32);
-                        acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv1, acc[0][1][t], 0, 0, 0);
-                        if (mv1) acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv1, acc[1][1][t], 0, 0, 0);
+                for (int r = 0; r < KS; ++r)
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const int t = r * KS + s_;
+                        const int off = (r * HW + s_) * RSX;
+                        const bf16x8 bv0 = ld_tr_pair(xh + xr1[kb] + off, xh + xr2[kb] + off);
+                        acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv0, acc[0][0][t], 0, 0, 0);
+                        if (mv1) acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv0, acc[1][0][t], 0, 0, 0);
+                        if (nv1) {
+                            const bf16x8 bv1 = ld_tr_pair(xh + xr1[kb] + off + 32, xh + xr2[kb] + off + 32);
+                            acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, bv1, acc[0][1][t], 0, 0, 0);
+                            if (mv1) acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, bv1, acc[1][1][t], 0, 0, 0);
+                        }
                     }
-                }
+            }
         }
+        __syncthreads();                  // every wave is done reading this tile
+        if (has_next) store_tile();
         __syncthreads();
     }
 
@@ -927,7 +948,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cout4 = unet::roundup(d->Cout, vec);
     p->T = d->ks * d->ks;
     p->ptw = d->OW >= 32 ? 32 : (d->OW >= 16 ? 16 : 8);
-    const int pt = (d->stride == 1 && !p->bf16) ? 64 : 32;      // bf16: one MFMA k-block of 32 pixels per tile
+    const int pt = p->bf16 ? (d->stride == 1 ? 128 : 32) : (d->stride == 1 ? 64 : 32);   // bf16: four (stride 2: one) MFMA k-blocks of 32 pixels
     const int pth = pt / p->ptw;
     k.tiles_y = unet::cdiv(d->OH, pth);
     k.tiles_x = unet::cdiv(d->OW, p->ptw);
