@@ -77,7 +77,11 @@ with open(dst / f"{tag}_pmc_summary.csv", "w", newline="") as fh:
     w.writeheader()
     for r in rows:
         w.writerow(r)
-json.dump(traffic, open(dst / "pmc_traffic.json", "w"), indent=1)
+# merge: kernels measured by this run replace their entries, other kernels (e.g. the other storage type's run) are kept
+tj = dst / "pmc_traffic.json"
+merged = json.loads(tj.read_text()) if tj.exists() else {}
+merged.update(traffic)
+json.dump(merged, open(tj, "w"), indent=1)
 print(open(dst / f"{tag}_bench.json").read()[-1200:])
 for r in sorted(rows, key=lambda r: -r.get("hbm_bytes_per_launch", 0))[:8]:
     print(r)

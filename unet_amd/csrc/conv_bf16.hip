@@ -23,6 +23,11 @@ namespace {
 using namespace unetconv;
 
 constexpr int KCB = 32;   // reduction channels per chunk (64 bytes of bf16)
+// LDS halo row length in dwords: 64 bytes of channels + 32 bytes pad.  With 96-byte rows the 16 lanes of every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ...: pixel rows r, 16-byte slot (6 r + kq) mod 16) hit 16 different slots -- conflict free; the 80-byte rows of
+// the fp32 kernel are 2-way conflicted on 3 of 16 slots (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5), which that MFMA-bound
+// kernel hides and this one (27 % MFMA busy) does not.
+constexpr int LDKB = 24;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,9 +68,9 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
     const int HPIX = HH * HW;
     float* lds0 = smem + 32;
-    auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDK); };
+    auto halo_buf = [&](int b) -> float* { return lds0 + b * (HPIX * LDKB); };
     const unsigned long long dpack = ts.dpack, wpack = ts.wpack;
-#define TAP_OFF(t_) ({ const unsigned d_ = (unsigned)(dpack >> (4 * (t_))); (int)(((d_ & 3u) * HW + ((d_ >> 2) & 3u)) * LDK); })
+#define TAP_OFF(t_) ({ const unsigned d_ = (unsigned)(dpack >> (4 * (t_))); (int)(((d_ & 3u) * HW + ((d_ >> 2) & 3u)) * LDKB); })
 #define TAP_WIDX(t_) ((int)((unsigned)(wpack >> (4 * (t_))) & 15u))
 
     // halo items: 16 bytes = 8 channels; 4 items per pixel and chunk.  goff = bf16 ELEMENT offset inside the image
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
             const int e_ = tid + it * NTH; \
             if (e_ < HPIX * 4) { \
                 const v4f v_ = HALO_OK(it, c0_) ? hreg[it] : (v4f){0.f, 0.f, 0.f, 0.f}; \
-                *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDK + (e_ & 3) * 4) = v_; \
+                *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDKB + (e_ & 3) * 4) = v_; \
             } } } while (0)
 
     // pixel-operand row bases (dwords) inside the halo tile
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     for (int m = 0; m < M16; ++m) {
         const int pix = (wm * M16 + m) * 16 + l15;
         const int ty = pix / TW, tx = pix % TW;
-        pbase[m] = ((ty * S) * HW + tx * S) * LDK + 4 * kq;
+        pbase[m] = ((ty * S) * HW + tx * S) * LDKB + 4 * kq;
     }
     // 16-wide output-channel tiles dealt round-robin to the WN waves; tiles entirely beyond the produced range are skipped
     int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
@@ -312,6 +317,7 @@ int plan_bf16(const unet_conv_desc* d, Plan* p) {
     int rc = unetconv::make_plan(d, p, KCB, 8, 16, g_big_tile);
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
+    p->lds_bytes = (size_t)(32 + 2 * p->max_hpix * LDKB) * sizeof(float);
     UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
     UNET_CHECK_ARG(unet::aligned16(d->y) && (!d->res || unet::aligned16(d->res)) && (!d->mask || unet::aligned16(d->mask)),
                    "conv bf16: y/res/mask must be 16-byte aligned");

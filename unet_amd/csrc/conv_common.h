@@ -127,7 +127,7 @@ __device__ __forceinline__ void wait_loads(v4f (&b)[NB], v4f (&h)[NH]) {
 
 struct Plan {
     KArgs k;
-    int tw, bm, bn, hit, nparity, mf;
+    int tw, bm, bn, hit, nparity, mf, max_hpix;
     size_t lds_bytes;
     dim3 grid;
 };
@@ -272,6 +272,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
         if (hh * hw > max_hpix) max_hpix = hh * hw;
     }
     UNET_CHECK_ARG(max_hpix * 4 <= p->hit * 256, "conv: halo tile too large (%d pixels)", max_hpix);
+    p->max_hpix = max_hpix;
     // the 16x16x4 kernel keeps no filter slab in LDS (operand B goes global -> VGPR)
     p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + (p->mf == 16 ? 0 : 2 * p->bn * LDK)) * sizeof(float);
     // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
