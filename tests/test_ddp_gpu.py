@@ -142,3 +142,54 @@ def test_tile_sharded_prediction_two_ranks(tmp_path):
         p.join(timeout=120)
     got8, _ = read_tiff(res[0])
     assert np.array_equal(got8, ref8)
+
+
+def _rccl_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from unet_amd.distributed import GradReducer
+    from unet_amd.model import HipDynamicUnet
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    model = HipDynamicUnet("xresnet18", 4, 5, (64, 64), device="cuda:0")
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randint(0, 256, (2, 4, 64, 64), generator=g).float() / 255).cuda()
+    y = torch.randint(0, 5, (2, 64, 64), generator=g).cuda()
+    w = torch.tensor([0.1, 0.2, 0.3, 0.2, 0.2], device="cuda")
+    model.forward_loss_backward(x, y, w)
+    ref_grad, ref_loss = model.flat_grad.clone(), float(model.ctx.vec(model, "loss", 1).item())
+    # the tile-DDP step's collective calls on RCCL itself: bucketed async all-reduce from the backward hooks, the loss
+    # numerator / denominator exchange (world = 1 here, forced through the same code), broadcast, barrier, object gather
+    bounds = [model._decoder_offset] + list(model._enc_child_offset.values())
+    red = GradReducer(model.flat_grad, bounds, 1 << 20)
+    red.world = 2                      # force the collective path with ONE rank: SUM over a world of 1 is the identity
+    model.grad_ready_hook = red.ready_down_to
+    red.reset()
+    loss = model.forward_loss_backward(x, y, w, world=2)
+    red.finish()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(model.flat_grad, ref_grad)) and abs(float(loss.item()) - ref_loss) <= 1e-6 * abs(ref_loss)
+    dist.broadcast(model.flat_param, 0)
+    for b in model.buffers():
+        dist.broadcast(b, 0)
+    dist.barrier()
+    out = [None]
+    dist.all_gather_object(out, {"rank": 0})
+    q.put((ok, len(red.spans) > 4, dist.get_backend(), out[0]["rank"]))
+    dist.destroy_process_group()
+
+
+def test_rccl_api_path_with_one_rank():
+    """RCCL itself (torch.distributed backend "nccl") on the one GPU of the box: the collective calls of the tile-DDP step --
+    async bucketed all-reduce launched from the backward hooks on RCCL's stream, the 2-float loss exchange between the loss
+    kernels, broadcast, barrier, all_gather_object -- run through the real library with a world of one rank, where every SUM is
+    the identity: gradient and loss must be bit-identical to the plain step.  (The multi-rank arithmetic is covered over gloo.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res == (True, True, "nccl", 0), res

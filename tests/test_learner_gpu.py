@@ -233,3 +233,30 @@ def test_augmentation_pipeline_runs_on_the_device():
         assert 64 <= int(holes.sum()) <= 512
         assert int((ya[i] == 0).sum()) == 0                      # mask_fill_value None: the mask keeps its classes
         assert sorted(ya[i].flatten().tolist()) == sorted(y0[i].flatten().tolist())      # a flip permutes the mask, nothing else
+
+
+def test_graphed_steps_with_device_resident_inputs_use_their_own_hyper_parameters():
+    """with inputs already on the device nothing blocks the host, which runs several graph replays ahead of the stream.
+    The Adam hyper-parameters (lr, momentum, de-bias terms: different in EVERY step of a one-cycle schedule) are staged through a ring
+    of pinned blocks guarded by events, so replay k must still read the values of step k: the graphed trajectory equals the eager one."""
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    torch.manual_seed(13)
+    sd = O.DynamicUnet("xresnet18", 4, 5, (64, 64)).state_dict()
+    x, y = O.synthetic_batch(2, 4, 64, 64, 5)
+    xd, yd = x.cuda(), y.cuda()
+    finals = []
+    for use_graph in (False, True):
+        model = HipDynamicUnet("xresnet18", 4, 5, (64, 64))
+        model.load_state_dict(sd)
+        model.train()
+        opt = FlatAdam(model, [1e-4, 3e-4, 1e-3])
+        step = TrainStep(model, opt, None, 1, use_graph=use_graph)
+        for i in range(40):                        # no host synchronisation inside this loop
+            opt.set_lr([1e-4 * (1 + i % 7), 3e-4 * (1 + i % 5), 1e-3 / (1 + i % 3)])
+            opt.mom = 0.95 - 0.002 * i
+            step(xd, yd)
+        torch.cuda.synchronize()
+        finals.append(model.flat_param.clone())
+    assert (finals[0] - finals[1]).abs().max().item() < 1e-6

@@ -531,3 +531,60 @@ def test_self_attention_row_blocks_with_recomputation_match_the_single_chunk():
     gr = torch.cat([torch.cat([q.grad.flatten(), torch.zeros((-q.numel()) % 4)]) for q in ref.parameters()])
     assert gr.numel() == model_grads.numel()
     assert ((model_grads.double() - gr.double()).norm() / gr.double().norm()).item() < 2e-3
+
+
+def _make_bimodal(ref, seed=9):
+    """Every ReLU input far from zero on EITHER side: per channel the BatchNorm bias (encoder) / conv bias (decoder) is +8 / +1 or
+    -8 / -1, so about half the channels are fully dead (mask 0, max-pool windows of all-zero ties) and half fully active (mask 1), and
+    no sign can flip between two fp32 evaluations.  The fused mask paths (UNET_CONV_MASK in the input-gradient epilogue, the ReLU gate
+    of the BatchNorm backward, the shuffle adjoint's gate, max-pool index routing) then see BOTH mask values under strict parity.
+    The final ResBlock and the head stay all-active (their pre-activation adds the raw input, which is not bounded away from 1)."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    last = ref.layers[-2]
+    keep = {id(m) for m in last.modules()} | {id(m) for m in ref.layers[-1].modules()}
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                sign = (torch.rand(m.bias.shape, generator=g) < 0.5).float() * 2 - 1
+                m.bias.copy_(8.0 * sign)
+            elif isinstance(m, nn.Conv2d) and m.bias is not None:
+                m.weight.mul_(0.01)
+                if id(m) in keep:
+                    m.bias.fill_(1.0)
+                else:
+                    m.bias.copy_((torch.rand(m.bias.shape, generator=g) < 0.5).float() * 2 - 1)
+
+
+@pytest.mark.parametrize("arch,n_in,n_out,size,bs", [CASES[1], CASES[3], CASES[4]])
+def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs):
+    """strict per-tensor parity of every gradient on a network whose ReLU masks are a fixed mixture of zeros and ones"""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(3)
+    ref = O.DynamicUnet(arch, n_in, n_out, size)
+    O.randomize_bn_and_zero_gammas(ref, seed=4)
+    _make_bimodal(ref)
+    model = HipDynamicUnet(arch, n_in, n_out, size)
+    model.load_state_dict(ref.state_dict())
+    x, y = O.synthetic_batch(bs, n_in, size[0], size[1], n_out)
+    w = torch.rand(n_out) + 0.5
+    ref.train(); model.train()
+    taps = {}
+    loss_ref = O.CrossEntropyLossFlat(weight=w)(ref(x, taps), y)
+    loss_ref.backward()
+    dead = float((taps["unet1"] == 0).float().mean())
+    assert 0.2 < dead < 0.8, dead                        # the fixture does produce both mask values
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    worst = ("", 0.0)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        s = q.grad.abs().max().item()
+        if s == 0.0:
+            assert p.grad.abs().max().item() == 0.0, n     # a dead channel's parameters get exactly zero
+            continue
+        e = (p.grad.cpu() - q.grad).abs().max().item() / s
+        if e > worst[1]:
+            worst = (n, e)
+    print("mixed-mask worst", worst)
+    assert worst[1] < 2e-3, worst
