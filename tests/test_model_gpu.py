@@ -533,30 +533,39 @@ def test_self_attention_row_blocks_with_recomputation_match_the_single_chunk():
     assert ((model_grads.double() - gr.double()).norm() / gr.double().norm()).item() < 2e-3
 
 
-def _make_bimodal(ref, seed=9):
+def _make_bimodal(ref):
     """Every ReLU input far from zero on EITHER side: per channel the BatchNorm bias (encoder) / conv bias (decoder) is +8 / +1 or
     -8 / -1, so about half the channels are fully dead (mask 0, max-pool windows of all-zero ties) and half fully active (mask 1), and
     no sign can flip between two fp32 evaluations.  The fused mask paths (UNET_CONV_MASK in the input-gradient epilogue, the ReLU gate
     of the BatchNorm backward, the shuffle adjoint's gate, max-pool index routing) then see BOTH mask values under strict parity.
-    The final ResBlock and the head stay all-active (their pre-activation adds the raw input, which is not bounded away from 1)."""
+    The final ResBlock and the head stay all-active."""
     import torch.nn as nn
-    g = torch.Generator().manual_seed(seed)
     last = ref.layers[-2]
     keep = {id(m) for m in last.modules()} | {id(m) for m in ref.layers[-1].modules()}
+
+    def sign(n):
+        # by channel INDEX, the same in every layer: the residual add of a ResBlock then sums biases of one sign (a dead channel's
+        # identity is 0, an active one's is positive) and never lands near zero
+        c = torch.arange(n)
+        return ((c * 7 + 3) % 5 < 3).float() * 2 - 1
     with torch.no_grad():
         for m in ref.modules():
             if isinstance(m, nn.BatchNorm2d):
-                sign = (torch.rand(m.bias.shape, generator=g) < 0.5).float() * 2 - 1
-                m.bias.copy_(8.0 * sign)
+                m.bias.copy_(8.0 * sign(m.bias.numel()))
             elif isinstance(m, nn.Conv2d) and m.bias is not None:
-                m.weight.mul_(0.01)
+                m.weight.mul_(0.1)         # (0.1, not the 0.01 of the all-active fixture: the gradients must stay in the fp32 normal range)
+                # +-8 like the BatchNorm biases: the decoder convs see inputs of magnitude ~8 (BatchNorm'd skips, active channels), so
+                # their 0.1-scaled conv term has a standard deviation of ~0.9 -- a bias of 1 would not keep the sign
                 if id(m) in keep:
-                    m.bias.fill_(1.0)
+                    m.bias.fill_(8.0)
                 else:
-                    m.bias.copy_((torch.rand(m.bias.shape, generator=g) < 0.5).float() * 2 - 1)
+                    m.bias.copy_(8.0 * sign(m.bias.numel()))
 
 
-@pytest.mark.parametrize("arch,n_in,n_out,size,bs", [CASES[1], CASES[3], CASES[4]])
+# (tiles large enough for >= 12 samples per channel at the bottleneck: with the 4-8 samples of a 64 x 64 tile the BatchNorm
+#  backward amplifies the sqrt(K) accumulation-order difference of DESIGN section 4 past the bar on one 1x1 identity conv)
+@pytest.mark.parametrize("arch,n_in,n_out,size,bs", [("xresnet34", 4, 5, (128, 128), 2), ("xresnet18", 3, 2, (96, 64), 2),
+                                                     ("xresnet50", 8, 10, (128, 96), 2)])
 def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs):
     """strict per-tensor parity of every gradient on a network whose ReLU masks are a fixed mixture of zeros and ones"""
     from unet_amd.model import HipDynamicUnet
@@ -568,23 +577,33 @@ def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs)
     model.load_state_dict(ref.state_dict())
     x, y = O.synthetic_batch(bs, n_in, size[0], size[1], n_out)
     w = torch.rand(n_out) + 0.5
-    ref.train(); model.train()
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    ref.train(); model.train(); ref64.train()
     taps = {}
     loss_ref = O.CrossEntropyLossFlat(weight=w)(ref(x, taps), y)
     loss_ref.backward()
+    O.CrossEntropyLossFlat(weight=w.double())(ref64(x.double()), y).backward()
     dead = float((taps["unet1"] == 0).float().mean())
     assert 0.2 < dead < 0.8, dead                        # the fixture does produce both mask values
     loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
-    worst = ("", 0.0)
-    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        s = q.grad.abs().max().item()
+    # BatchNorm biases that feed another BatchNorm have a mathematically zero gradient: their fp64 value is 1e-25 .. 1e-50 and
+    # every fp32 evaluation (the CPU oracle's too) is pure rounding noise there.  The bar applies to every tensor on which the
+    # fp32 CPU oracle itself is well conditioned (within 1e-3 of the fp64 run)
+    worst, n_live = ("", 0.0), 0
+    for (n, p), (_, q), (_, r) in zip(model.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        s = r.grad.abs().max().item()
         if s == 0.0:
-            assert p.grad.abs().max().item() == 0.0, n     # a dead channel's parameters get exactly zero
+            assert p.grad.abs().max().item() == 0.0, n     # a tensor that only feeds dead channels gets exactly zero
             continue
-        e = (p.grad.cpu() - q.grad).abs().max().item() / s
+        if (q.grad.double() - r.grad).abs().max().item() / s > 1e-3 or s < 1e-20:
+            continue        # (the 0.01-scaled decoder shrinks the deepest gradients to 1e-35: products leave the fp32 normal range)
+        n_live += 1
+        e = (p.grad.cpu().double() - r.grad).abs().max().item() / s
         if e > worst[1]:
             worst = (n, e)
-    print("mixed-mask worst", worst)
+    print("mixed-mask worst", worst, "live tensors", n_live)
+    assert n_live > 0.5 * len(list(ref.parameters()))
     assert worst[1] < 2e-3, worst
