@@ -115,6 +115,18 @@ int unet_pack_weights_strided(const float* w, long long so, long long sr, float*
 /* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32) */
 size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode); /* elements */
 int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream);
+/* All filter images of a model in one launch (the parameters change every step, so every image is rebuilt every step).
+ * unet_pack_batch_build fills a HOST table (unet_pack_batch_table_bytes(njobs) bytes) from the job list -- same layouts as
+ * unet_pack_weights (dtype UNET_F32) / unet_pack_weights_bf16 (UNET_BF16) -- and returns the grid size; the caller uploads the table
+ * once (addresses are static) and calls unet_pack_batch_run on it whenever the parameters have changed. */
+typedef struct {
+    const float* w;                      /* master parameter [Cout,Cin,ks,ks] (device) */
+    void* wp;                            /* packed image (device), unet_pack_weights_size[_bf16] elements */
+    int Cout, Cin, ks, mode;             /* mode 0 = forward image, 1 = input-gradient image */
+} unet_pack_job;
+size_t unet_pack_batch_table_bytes(int njobs);
+int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int dtype, void* table_host, unsigned* total_blocks);
+int unet_pack_batch_run(const void* table_dev, int njobs, unsigned total_blocks, int dtype, void* stream);
 /* bf16 conv: 256-pixel x 128-channel workgroup tile for large layers on/off (default on; results identical, A/B knob) */
 int unet_set_bf16_big_tile(int on);
 

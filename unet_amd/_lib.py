@@ -60,6 +60,10 @@ class WgradDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", vp), ("wp", vp), ("Cout", C.c_int), ("Cin", C.c_int), ("ks", C.c_int), ("mode", C.c_int)]
+
+
 def declared_symbols() -> list[str]:
     """Every function name include/unet_hip.h declares (used by the CPU-side ABI test)."""
     txt = HEADER.read_text()
@@ -93,6 +97,9 @@ _sig = {
     "unet_set_wgrad_narrow": (i, [i]),
     "unet_set_wgrad_1x1": (i, [i]),
     "unet_set_bf16_big_tile": (i, [i]),
+    "unet_pack_batch_table_bytes": (sz, [i]),
+    "unet_pack_batch_build": (i, [C.POINTER(PackJob), i, i, vp, C.POINTER(C.c_uint)]),
+    "unet_pack_batch_run": (i, [vp, i, C.c_uint, i, vp]),
     "unet_pack_weights_size": (sz, [i, i, i, i]),
     "unet_pack_weights": (i, [vp, vp, i, i, i, i, vp]),
     "unet_pack_weights_strided": (i, [vp, ll, ll, vp, i, i, vp]),

@@ -84,6 +84,7 @@ class HipDynamicUnet(nn.Module):
         self._post_bx = _BNExec(post_bn)
         self._device = torch.device(device)
         self.ctx: Optional[Ctx] = None
+        self._pack_tables: Dict[tuple, tuple] = {}
         self.flat_param: Optional[torch.Tensor] = None
         self.flat_grad: Optional[torch.Tensor] = None
         self._last: Dict[str, object] = {}
@@ -135,6 +136,44 @@ class HipDynamicUnet(nn.Module):
             if isinstance(cx, _ConvExec):
                 cx.ctx = self.ctx
 
+    # ------------------------------------------------------------------ packed filter images
+    def _pack_all(self, training: bool):
+        """Rebuild every stale packed filter image in ONE launch (unet_pack_batch_run).  The parameters are rewritten by every
+        optimizer step, so in training this runs once per step for all 52 convs x (forward, input-gradient) images."""
+        import ctypes as C
+        from . import _lib as L
+        cxs = [m.cx for m in self.modules() if isinstance(getattr(m, "cx", None), _ConvExec)]
+        stale = []
+        for cx in cxs:
+            cx.ensure_buffers(training)
+            ver = cx.version()
+            if cx._ver_f != ver:
+                stale.append((cx, 0))
+            if training and cx._ver_d != ver:
+                stale.append((cx, 1))
+        if not stale:
+            return
+        key = tuple((id(cx), mode) for cx, mode in stale)
+        ent = self._pack_tables.get(key)
+        if ent is None:
+            jobs = (L.PackJob * len(stale))()
+            for j, (cx, mode) in zip(jobs, stale):
+                w = cx.conv.weight
+                j.w, j.wp = w.data_ptr(), (cx.wp_f if mode == 0 else cx.wp_d).data_ptr()
+                j.Cout, j.Cin, j.ks, j.mode = w.shape[0], w.shape[1], w.shape[2], mode
+            dt = L.BF16 if self.ctx.act_dtype == torch.bfloat16 else L.F32
+            host = torch.zeros(int(L.lib.unet_pack_batch_table_bytes(len(stale))), dtype=torch.uint8)
+            blocks = C.c_uint(0)
+            L.check(L.lib.unet_pack_batch_build(jobs, len(stale), dt, host.data_ptr(), C.byref(blocks)), "pack_batch_build")
+            ent = self._pack_tables[key] = (host.to(self._device), len(stale), int(blocks.value), dt)
+        table, n, blocks, dt = ent
+        L.check(L.lib.unet_pack_batch_run(table.data_ptr(), n, blocks, dt, ops._stream()), "pack_batch_run")
+        for cx, mode in stale:
+            if mode == 0:
+                cx._ver_f = cx.version()
+            else:
+                cx._ver_d = cx.version()
+
     def param_span(self, p: nn.Parameter) -> Tuple[int, int]:
         return self._param_offsets[id(p)]
 
@@ -166,6 +205,7 @@ class HipDynamicUnet(nn.Module):
         x = x.contiguous()
         ctx = self.ctx
         ctx.training = training
+        self._pack_all(training and ctx.need_grad)
         N, _, H, W = x.shape
         L = self.layers
         enc: Encoder = L[0]

@@ -168,6 +168,23 @@ class _ConvExec:
             self._ver_d = ver
         return self.wp_d
 
+    def version(self):
+        w = self.conv.weight
+        return (w._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
+
+    def ensure_buffers(self, with_dgrad: bool):
+        """the persistent packed-image buffers (HipDynamicUnet packs all of them in one launch: unet_pack_batch_run)"""
+        dt = torch.float32 if self.ctx is None else self.ctx.act_dtype
+        w = self.conv.weight
+        Cout, Cin, ks, _ = w.shape
+        size = ops.lib.unet_pack_weights_size_bf16 if dt == torch.bfloat16 else ops.lib.unet_pack_weights_size
+        if self.wp_f is None or self.wp_f.dtype != dt:
+            self.wp_f = torch.empty(size(Cout, Cin, ks, 0), dtype=dt, device=w.device)
+            self._ver_f = None
+        if with_dgrad and (self.wp_d is None or self.wp_d.dtype != dt):
+            self.wp_d = torch.empty(size(Cout, Cin, ks, 1), dtype=dt, device=w.device)
+            self._ver_d = None
+
     def out_hw(self, H, W):
         return ops.conv_out_hw(H, W, self.ks, self.stride)
 
