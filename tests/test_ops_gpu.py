@@ -197,7 +197,7 @@ def test_conv_wgrad(ops, case):
     assert_close(dw.cpu(), 2 * ref, rtol=3e-4, atol=2e-4, what=f"wgrad accumulate {case}")
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 32, 9, 7), (1, 512, 4, 4), (2, 256, 40, 40)])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 32, 9, 7), (1, 512, 4, 4), (2, 256, 40, 40), (1, 512, 2, 2), (16, 64, 128, 128)])
 def test_batchnorm_train_fwd_bwd(ops, shape):
     N, Cc, H, W = shape
     g = torch.Generator().manual_seed(11)

@@ -59,6 +59,22 @@ __device__ __forceinline__ float4 gate4(float4 g, float4 ref) {
     return make_float4(ref.x > 0.f ? g.x : 0.f, ref.y > 0.f ? g.y : 0.f, ref.z > 0.f ? g.z : 0.f, ref.w > 0.f ? g.w : 0.f);
 }
 
+// Grid-stride walk over (pixel, channel-quad) pairs without a 64-bit division per element: the pair is split once, then advanced
+// by the constant stride (these kernels run on tensors of a few MB, where the per-element index arithmetic, not HBM, set the time).
+struct QuadWalk {
+    long long p, dp;
+    int c4, dc, C4;
+    __device__ __forceinline__ QuadWalk(int C4_) : C4(C4_) {
+        const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+        p = i0 / C4_; c4 = (int)(i0 - p * C4_);
+        dp = stride / C4_; dc = (int)(stride - dp * C4_);
+    }
+    __device__ __forceinline__ void next() {
+        p += dp; c4 += dc;
+        if (c4 >= C4) { c4 -= C4; ++p; }
+    }
+};
+
 // --------------------------------------------------------------------------
 // Per-channel reduction over pixels.  F(p, c4) -> two float4 values; result
 // planes out0[rows][Cp], out1[rows][Cp] (one row per workgroup).
@@ -73,7 +89,20 @@ __device__ __forceinline__ void channel_reduce(F f, long long P, int C4, int TC,
         const int c4 = cbase + tx;
         float4 s0 = f4(0.f), s1 = f4(0.f);
         if (c4 < C4) {
-            for (long long p = (long long)blockIdx.x * PY + ty; p < P; p += (long long)gridDim.x * PY) {
+            // four pixels per trip: the (up to three) loads of each pixel are independent, so 12 requests are in flight per thread
+            // instead of 3 (a thread walks 32-64 pixels: one HBM round trip per pixel made these kernels latency bound)
+            const long long step = (long long)gridDim.x * PY;
+            long long p = (long long)blockIdx.x * PY + ty;
+            for (; p + 3 * step < P; p += 4 * step) {
+                float4 a0, b0, a1, b1, a2, b2, a3, b3;
+                f(p, c4, a0, b0);
+                f(p + step, c4, a1, b1);
+                f(p + 2 * step, c4, a2, b2);
+                f(p + 3 * step, c4, a3, b3);
+                s0 = s0 + ((a0 + a1) + (a2 + a3));
+                s1 = s1 + ((b0 + b1) + (b2 + b3));
+            }
+            for (; p < P; p += step) {
                 float4 v0, v1;
                 f(p, c4, v0, v1);
                 s0 = s0 + v0;
@@ -166,7 +195,18 @@ __device__ __forceinline__ void rows_reduce2(const float* __restrict__ p0, const
     const int c = blockIdx.x * 32 + tx;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int r = ty; r < rows; r += 8) {
+        int r = ty;
+        for (; r + 24 < rows; r += 32) {          // four independent loads per plane and trip (the chain of up to 64 dependent loads set the time)
+            const float a0 = p0[(size_t)r * stride + c], a1 = p0[(size_t)(r + 8) * stride + c], a2 = p0[(size_t)(r + 16) * stride + c],
+                        a3 = p0[(size_t)(r + 24) * stride + c];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            if (p1 != nullptr) {
+                const float b0 = p1[(size_t)r * stride + c], b1 = p1[(size_t)(r + 8) * stride + c], b2 = p1[(size_t)(r + 16) * stride + c],
+                            b3 = p1[(size_t)(r + 24) * stride + c];
+                b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+            }
+        }
+        for (; r < rows; r += 8) {
             a += (double)p0[(size_t)r * stride + c];
             if (p1 != nullptr) b += (double)p1[(size_t)r * stride + c];
         }
@@ -228,10 +268,9 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
                                                          const float* __restrict__ shift, const T* __restrict__ x2, int x2_cs,
                                                          int x2_co, const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                          T* __restrict__ y, int y_cs, int y_co, long long P, int C4, int relu) {
-    const long long total = P * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long p = i / C4;
-        const int c = 4 * (int)(i - p * C4);
+    for (QuadWalk w(C4); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 4 * w.c4;
         float4 v = ld4(x + (size_t)p * x_cs + x_co + c);
         if (scale != nullptr) v = v * ld4(scale + c) + ld4(shift + c);
         if (x2 != nullptr) {
@@ -280,10 +319,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, T* __restrict__ dx, int dx_cs, int dx_co,
                                                            T* gout, int g_cs, int g_co, int g_acc, long long P, int C4) {
-    const long long total = P * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long p = i / C4;
-        const int c = 4 * (int)(i - p * C4);
+    for (QuadWalk w(C4); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 4 * w.c4;
         float4 g = ld4(dout + (size_t)p * d_cs + d_co + c);
         if (out != nullptr) g = gate4(g, ld4(out + (size_t)p * o_cs + o_co + c));
         const float4 is = ld4(invstd + c);
@@ -581,10 +619,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void copy_slice_kernel(const T* __restrict__ x, int x_cs, int x_co, T* __restrict__ y, int y_cs,
                                                          int y_co, long long P, int C4, int accumulate) {
-    const long long total = P * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long p = i / C4;
-        const int c = 4 * (int)(i - p * C4);
+    for (QuadWalk w(C4); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 4 * w.c4;
         const float4 v = ld4(x + (size_t)p * x_cs + x_co + c);
         T* o = y + (size_t)p * y_cs + y_co + c;
         st4(o, accumulate ? (ld4(o) + v) : v);
@@ -593,10 +630,9 @@ __global__ __launch_bounds__(256) void copy_slice_kernel(const T* __restrict__ x
 
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ g, int g_cs, int g_co, const float* __restrict__ ref,
                                                         int r_cs, int r_co, float* __restrict__ y, int y_cs, int y_co, long long P, int C4) {
-    const long long total = P * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long p = i / C4;
-        const int c = 4 * (int)(i - p * C4);
+    for (QuadWalk w(C4); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 4 * w.c4;
         st4(y + (size_t)p * y_cs + y_co + c, gate4(ld4(g + (size_t)p * g_cs + g_co + c), ld4(ref + (size_t)p * r_cs + r_co + c)));
     }
 }
