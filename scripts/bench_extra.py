@@ -1,6 +1,7 @@
 """Secondary measurements (not the headline): self-attention on, eval/predict throughput, cfg1 and cfg4 steps."""
-import sys, time, json, torch
+import os, sys, time, json, torch
 sys.path.insert(0, '.')
+DT = os.environ.get("UNET_DTYPE", "f32")        # f32 | bf16 storage
 from unet_amd.model import HipDynamicUnet
 from unet_amd.optimizer import FlatAdam
 from unet_amd.trainer import TrainStep
@@ -13,14 +14,14 @@ def synth(b, c, s, ncls, seed=1):
 
 def train_rate(arch, c, ncls, s, b, sa=False, steps=4, graph=False):
     torch.manual_seed(0)
-    m = HipDynamicUnet(arch, c, ncls, (s, s), self_attention=sa); m.train()
+    m = HipDynamicUnet(arch, c, ncls, (s, s), self_attention=sa, act_dtype=DT); m.train()
     opt = FlatAdam(m, [1e-5, 3e-5, 1e-4]); st = TrainStep(m, opt, torch.full((ncls,), 1.0 / ncls, device='cuda'), use_graph=graph)
     x, y = synth(b, c, s, ncls)
     for _ in range(4): st(x, y)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): st(x, y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    r = {"what": f"train {arch} {c}ch {s}x{s} {ncls}cls B={b} sa={sa} graph={graph}", "ms_per_step": round(dt * 1e3, 2), "tiles_per_s": round(b / dt, 2),
+    r = {"dtype": DT, "what": f"train {arch} {c}ch {s}x{s} {ncls}cls B={b} sa={sa} graph={graph}", "ms_per_step": round(dt * 1e3, 2), "tiles_per_s": round(b / dt, 2),
          "mem_GB": round(m.memory_bytes() / 2**30, 2)}
     print(json.dumps(r), flush=True)
     del m, opt, st
@@ -29,14 +30,14 @@ def train_rate(arch, c, ncls, s, b, sa=False, steps=4, graph=False):
 
 def predict_rate(arch, c, ncls, s, b, steps=5, graph=False):
     torch.manual_seed(0)
-    m = HipDynamicUnet(arch, c, ncls, (s, s)); m.eval()
+    m = HipDynamicUnet(arch, c, ncls, (s, s), act_dtype=DT); m.eval()
     x, _ = synth(b, c, s, ncls)
     f = m.predict_probs_graphed if graph else m.predict_probs
     for _ in range(3): f(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): f(x)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"what": f"predict {arch} {c}ch {s}x{s} B={b} graph={graph} (eval fwd + softmax + argmax)", "ms_per_batch": round(dt * 1e3, 2),
+    print(json.dumps({"dtype": DT, "what": f"predict {arch} {c}ch {s}x{s} B={b} graph={graph} (eval fwd + softmax + argmax)", "ms_per_batch": round(dt * 1e3, 2),
                       "tiles_per_s": round(b / dt, 2), "fwd_TFLOPs": round(b / dt * 255.846 / 1e3, 1) if arch == 'xresnet34' and s == 512 else None}), flush=True)
     del m
     torch.cuda.empty_cache()
@@ -60,7 +61,7 @@ def cfg5_rate(side=20000, size=512, overlap=0.2, b=16):
     batched eval forward + softmax, overlap merge (sum of probabilities + hit counter) and argmax on the device."""
     from unet_amd import ops
     torch.manual_seed(0)
-    m = HipDynamicUnet("xresnet34", 4, 5, (size, size)); m.eval()
+    m = HipDynamicUnet("xresnet34", 4, 5, (size, size), act_dtype=DT); m.eval()
     g = torch.Generator(device="cuda").manual_seed(3)
     raster = torch.randint(0, 256, (4, side, side), dtype=torch.uint8, device="cuda", generator=g)
     step = size - int(size * overlap)
@@ -82,7 +83,7 @@ def cfg5_rate(side=20000, size=512, overlap=0.2, b=16):
             ops.mosaic_accumulate(probs[j], mosaic, count, y, x0)
     ops.mosaic_finalize(mosaic, count, am)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"what": f"cfg5 sliding-window predict {side}x{side}, {len(wins)} windows of {size}, overlap {overlap}, batch {b}, "
+    print(json.dumps({"dtype": DT, "what": f"cfg5 sliding-window predict {side}x{side}, {len(wins)} windows of {size}, overlap {overlap}, batch {b}, "
                               "forward + softmax + device merge + argmax", "seconds": round(dt, 2), "tiles_per_s": round(len(wins) / dt, 1),
                       "covered": bool((count > 0).all().item()), "max_overlap": int(count.max().item())}), flush=True)
 
