@@ -115,3 +115,51 @@ def test_regression_workflow_with_lr_finder(tmp_path):
     mm, meta = read_tiff(merged / "aoi_reg_prediction.tif")
     assert mm.shape == (64, 160) and meta.get("nodata") == -9999.0
     assert np.all(mm[:, 64:96] == -9999) and np.allclose(mm[:, :64], t0.reshape(64, 64), atol=1e-6)
+
+
+def _train_worker(rank, world, port, data, models, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      UNET_DIST_BACKEND="gloo", UNET_FORCE_DEVICE="0")
+    import torch.distributed as dist
+    import train as T
+    from unet_amd import xresnet18
+    torch.manual_seed(500 + rank)                 # different initial weights per rank: train_func must end with identical replicas
+    learn = T.train_func(data, None, models, "ddp", 2, False, False, "weighted", xresnet18, 2, 2e-3, 10, None, None,
+                         "dice_multi", False, ["vali"], ["a", "b", "c"], True, None, True, None, 0.5, "", False)
+    p = learn.model.flat_param.clone()
+    ref = p.clone()
+    dist.broadcast(ref, 0)
+    q.put((rank, bool(torch.equal(p, ref)), learn.world, len(learn.dls.train)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_func_under_two_ranks(tmp_path):
+    """train_func launched once per GPU (here: two ranks sharing the one GPU over gloo): the training tiles are sharded (8 tiles,
+    batch 2 -> 2 steps per epoch and rank instead of 4), replicas end identical, and exactly ONE set of result files exists"""
+    import socket
+    import torch.multiprocessing as mp
+    data = tmp_path / "data"
+    _make_dataset(data, n_train=8, n_val=2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, str(data), str(tmp_path / "models"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res == [(0, True, 2, 2), (1, True, 2, 2)], res
+    out = tmp_path / "models" / "ddp"
+    hist = (out / "ddp_history.csv").read_text().strip().splitlines()
+    assert hist[0] == "epoch,train_loss,valid_loss,dice_multi,time" and len(hist) == 3
+    assert (out / "ddp.pkl").exists() and (out / "ddp_model_summary.txt").exists() and (out / "ddp.json").exists()
+    assert '"world_size": 2' in (out / "ddp.json").read_text()
+    assert not (out / "history.csv").exists()
+    import train as T
+    lr = T.load_learner(out / "ddp.pkl")
+    assert lr.model.n_out == 3

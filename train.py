@@ -103,16 +103,19 @@ def train_unet(class_weights, dls, architecture, epochs, path, lr, encoder_facto
         learn = load_learner(existing_model, device=dls.device)
         learn.dls, learn.loss_func, learn.opt_func, learn.path = dls, loss_func, Adam, path.parent
         learn.cbs = cbs
-    if export_model_summary:
+    if export_model_summary and learn.rank == 0:
         Path(str(path).rsplit(".", 1)[0] + "_model_summary.txt").write_text(
             f"Class_weights: {class_weights}\n{learn.summary()}\n{learn.model}\n")
     if lr_finder is not None:
         lr = find_lr(learn, lr_finder)
-        print(f"Optimized learning rate: {lr}")
+        if learn.rank == 0:
+            print(f"Optimized learning rate: {lr}")
     learn.unfreeze()
     learn.fit_one_cycle(epochs, lr_max=slice(lr / encoder_factor, lr))
     hist = Path(str(path).rsplit(".", 1)[0] + "_history.csv")
-    shutil.move(str(learn.path / learn.csv_logger.fname), str(hist))
+    if learn.rank == 0:                                 # tile-DDP: rank 0 owns the files
+        shutil.move(str(learn.path / learn.csv_logger.fname), str(hist))
+    learn._barrier()
     learn.remove_cb(CSVLogger)
     return learn
 
@@ -120,16 +123,21 @@ def train_unet(class_weights, dls, architecture, epochs, path, lr, encoder_facto
 def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, visualize_data_example, enable_regression,
                CLASS_WEIGHTS, ARCHITECTURE, EPOCHS, LEARNING_RATE, ENCODER_FACTOR, LR_FINDER, loss_func, monitor, self_attention,
                VALID_SCENES, CODES, transforms, split_idx, export_model_summary, aug_pipe, n_transform_imgs, info, class_zero):
+    # one process per GPU under torch.distributed.run (tile-DDP: BASELINE configs[2]); a plain `python train.py ...` is world 1
+    from unet_amd.distributed import init_from_env
+    rank, local_rank, world = init_from_env()
+    device = f"cuda:{local_rank}" if world > 1 else "cuda"
     data_path = Path(data_path)
     dtype = get_datatype(data_path)
     new_path = Path(model_Path) / description
     new_path.mkdir(parents=True, exist_ok=True)
     model_path = new_path / f"{description}.pkl"
-    (new_path / f"{description}.json").write_text(json.dumps({
-        "data_path": str(data_path), "BATCH_SIZE": BATCH_SIZE, "EPOCHS": EPOCHS, "LEARNING_RATE": LEARNING_RATE,
-        "ENCODER_FACTOR": ENCODER_FACTOR, "CLASS_WEIGHTS": CLASS_WEIGHTS if isinstance(CLASS_WEIGHTS, str) else list(CLASS_WEIGHTS),
-        "ARCHITECTURE": _arch_name(ARCHITECTURE), "CODES": list(CODES), "self_attention": self_attention, "monitor": monitor,
-        "VALID_SCENES": VALID_SCENES, "info": info, "class_zero": class_zero, "dtype": dtype}, indent=1, default=str))
+    if rank == 0:
+        (new_path / f"{description}.json").write_text(json.dumps({
+            "data_path": str(data_path), "BATCH_SIZE": BATCH_SIZE, "EPOCHS": EPOCHS, "LEARNING_RATE": LEARNING_RATE,
+            "ENCODER_FACTOR": ENCODER_FACTOR, "CLASS_WEIGHTS": CLASS_WEIGHTS if isinstance(CLASS_WEIGHTS, str) else list(CLASS_WEIGHTS),
+            "ARCHITECTURE": _arch_name(ARCHITECTURE), "CODES": list(CODES), "self_attention": self_attention, "monitor": monitor,
+            "VALID_SCENES": VALID_SCENES, "info": info, "class_zero": class_zero, "dtype": dtype, "world_size": world}, indent=1, default=str))
     tfm = None
     if transforms:
         # aug_pipe: None = the reference's default pipeline HorizontalFlip + VerticalFlip (params_and_main.py:105-115); or a
@@ -145,7 +153,7 @@ def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, v
                 warnings.warn("aug_pipe is not a unet_amd.augment.Compose (albumentations itself is not available on this path); "
                               "using the default flip pipeline")
             tfm = FlipAugment(n_transform_imgs=n_transform_imgs)
-    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, train_tfm=tfm, regression=bool(enable_regression))
+    dls = make_dataloaders(data_path, BATCH_SIZE, CODES, dtype, device=device, train_tfm=tfm, regression=bool(enable_regression))
     if enable_regression:
         CLASS_WEIGHTS = [1]                                           # train.py:334-335
     elif isinstance(CLASS_WEIGHTS, str):
@@ -153,8 +161,9 @@ def train_func(data_path, existing_model, model_Path, description, BATCH_SIZE, v
             CLASS_WEIGHTS = np.ones(len(CODES)) / len(CODES)
         elif CLASS_WEIGHTS == "weighted":
             CLASS_WEIGHTS = get_class_weights(dls.train_ds, len(CODES))
-    print(f"Train files: {len(dls.train_ds)}, Test files: {len(dls.valid_ds)}")
-    print(f"Class weights: {CLASS_WEIGHTS}")
+    if rank == 0:
+        print(f"Train files: {len(dls.train_ds)}, Test files: {len(dls.valid_ds)}" + (f" (sharded over {world} ranks)" if world > 1 else ""))
+        print(f"Class weights: {CLASS_WEIGHTS}")
     learn = train_unet(class_weights=CLASS_WEIGHTS, dls=dls, architecture=ARCHITECTURE, epochs=EPOCHS, path=model_path,
                        lr=LEARNING_RATE, encoder_factor=ENCODER_FACTOR, lr_finder=LR_FINDER, regression=enable_regression,
                        loss_func=loss_func, monitor=monitor, existing_model=existing_model, self_attention=self_attention,
