@@ -1,6 +1,9 @@
-"""kernel accuracy at the bottleneck shapes vs fp64: HIP vs torch-CPU fp32"""
+"""Relative L2 error of the conv forward / input-gradient / weight-gradient kernels against fp64, next to torch-CPU fp32 (oneDNN), at the
+shapes of the network: the sqrt(K) growth of the k-ordered fp32 MFMA chain quoted in DESIGN.md section 4 and tests/test_configs_gpu.py.
+Run on the GPU box: python scripts/accuracy_vs_fp64.py"""
 import sys, torch, torch.nn.functional as F
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from unet_amd import ops
 from tests.util import to_ts, empty_ts, from_ts
 torch.set_num_threads(16)

@@ -77,7 +77,7 @@ def _grad_table(model, ref, ref64):
 # that error differs between the two fp32 implementations for a known reason: a gfx950 fp32 MFMA accumulates its K = 9 Cin products
 # as ONE k-ordered fmaf chain (cdna_hip_programming.md section 3), whose relative error grows like sqrt(K) -- measured against fp64
 # on MI355X: 3.8e-7 at K = 891, 8.4e-7 at K = 4608, 1.1e-6 at K = 9216 for the forward conv, 1.6e-6 for the K = 9216 input gradient --
-# while oneDNN sums in 16-lane blocks and stays at 1.7-2.5e-7 for every K (scratch measurement recorded in DESIGN.md section 4).
+# while oneDNN sums in 16-lane blocks and stays at 1.7-2.5e-7 for every K (scripts/accuracy_vs_fp64.py).
 # Both are far inside north_star's 1e-3 logit bar; the gradient inherits the ratio: measured e_hip / e_cpu32 is ~2 in the decoder
 # and 4-9 in the deep encoder (K up to 9216 and few pixels per channel).  Hence: decoder tail absolute bar; everywhere else the HIP
 # gradient may be at most ENC_FACTOR x as far from fp64 as the fp32 CPU oracle is on the same tensor, and never beyond ENC_CAP.
