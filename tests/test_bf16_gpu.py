@@ -106,6 +106,30 @@ def test_conv_forward_dgrad_wgrad_bf16(case):
     assert (db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max().item() <= 5e-5 * dy.double().sum((0, 2, 3)).abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("Cout", [100, 112, 97])
+def test_conv_bf16_big_tile_shared_odd_tile(Cout):
+    """2 x 256 x 256 pixels = 512 blocks of 256 x 128: the 8-pixel-tile wave (variant 321287, the dominant kernel of the bf16 step) with
+    7 live output tiles -- the odd one shared between the two waves of a pixel row, 4 pixel tiles each."""
+    from unet_amd import ops
+    N, H, W, Cin = 2, 256, 256, 100
+    g = torch.Generator().manual_seed(Cout)
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = _bf(torch.randn(N, Cout, H, W, generator=g))
+    ref = F.relu(F.conv2d(x, _bf(w), b, padding=1) + r)
+    xt, rt = _ts(x), _ts(r, cs=144, co=16)
+    yt = _empty(N, H, W, Cout, cs=160, co=32)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    assert ops.conv2d_variant(xt, wp, yt, 3, 1) == 321287
+    ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True)
+    got = _back(yt)
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-5
+    assert (got - ref).norm().item() <= 3e-3 * ref.norm().item()
+    full = yt.buf.float().cpu()
+    assert bool((full[..., :32] == 7.25).all()) and bool((full[..., 32 + ops.rupv(Cout, torch.bfloat16):] == 7.25).all()), "wrote outside the slice"
+
+
 def test_conv_epilogue_slices_residual_relu_mask_bf16():
     """channel-sliced operands (concat elimination), bias + residual + ReLU forward epilogue, residual + ReLU-mask dgrad epilogue"""
     from unet_amd import ops

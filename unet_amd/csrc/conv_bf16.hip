@@ -101,23 +101,38 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
                 *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDKB + (e_ & 3) * 4) = v_; \
             } } } while (0)
 
+    // 16-wide output-channel tiles dealt round-robin to the WN waves; tiles entirely beyond the produced range are skipped
+    int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
+    nvalid = (a.n_end - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    // An ODD number of live tiles (Cout = 100: 7 of the block's 8) would leave the wn = 0 waves one tile more than the wn = 1 waves.  The
+    // odd last tile is SHARED instead: both waves of a pixel row load it (wave wn = 1 reads its last tile one KiB lower), and each
+    // multiplies it with the first half of ITS pixel tiles -- wave wn = 1 numbers its pixel tiles rotated by half, so the two halves
+    // are covered by the same code.  Every output element keeps its k-ordered accumulation chain: results do not change.
+    // Measured (scripts/conv_sweep.py, 16 x 512^2): the step is MFMA-throughput bound per CU, not per wave -- the balance alone is
+    // worth ~2 %; what the 100-channel layers lose against 96 / 128 channels is the padding of 6.25 tiles to 7.
+    int nsplit = -1;
+    if constexpr (WN == 2 && (M16 & 1) == 0) {
+        if ((a.n_end - n0 + 15) / 16 == 2 * N16 - 1) { nsplit = N16 - 1; nvalid = N16; }
+    }
+    const int nfull = nsplit >= 0 ? nsplit : nvalid;
+    // the wn = 1 wave numbers its pixel tiles rotated by half, so that "pixel tiles 0..M16/2-1" of the shared tile are the other half
+    const int mrot = (nsplit >= 0 && wn != 0) ? M16 / 2 : 0;
     // pixel-operand row bases (dwords) inside the halo tile
     int pbase[M16];
 #pragma unroll
     for (int m = 0; m < M16; ++m) {
-        const int pix = (wm * M16 + m) * 16 + l15;
+        const int pix = (wm * M16 + (m ^ mrot)) * 16 + l15;
         const int ty = pix / TW, tx = pix % TW;
         pbase[m] = ((ty * S) * HW + tx * S) * LDKB + 4 * kq;
     }
-    // 16-wide output-channel tiles dealt round-robin to the WN waves; tiles entirely beyond the produced range are skipped
-    int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
-    nvalid = (a.n_end - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+#define TILE_COL(n_) (((n_) == nsplit ? (n_) * WN : (n_) * WN + wn) * 16)
     const unsigned lane_b = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
+    const unsigned lane_b_last = lane_b - (unsigned)((nsplit >= 0 ? wn : 0) * 16 * 64);     // the shared tile: one tile (1 KiB) lower for wn = 1
     const char* wbase = reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2;
     const size_t slab_b = (size_t)a.coutPad * KCB * 2;
     constexpr int TSTR = WN * 16 * 64;     // bytes between two of this wave's filter tiles
     v4f b0[N16], b1[N16];
-#define LOAD_B(dst_, widx_, chunk_) gld_b<TSTR, N16>((dst_), lane_b, wbase + (size_t)((widx_) * a.nchunks + (chunk_)) * slab_b)
+#define LOAD_B(dst_, widx_, chunk_) gld_bl<TSTR, N16>((dst_), lane_b, lane_b_last, wbase + (size_t)((widx_) * a.nchunks + (chunk_)) * slab_b)
 
     f32x4 acc[M16][N16];
 #pragma unroll
@@ -138,17 +153,29 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     const float* hb = halo_buf(0);
     // stage = (chunk, tap): the next stage's filter tiles (and, during the first tap of a chunk, the next chunk's halo items) are
     // issued at the top and waited for behind the stage's MFMAs; ONE wait asm per stage redefines every register a load writes
+    constexpr int MH = M16 / 2;
+    constexpr bool HALF_LOADS = M16 > 4;
 #define STAGE_BODY(bu_, bl_) do { \
         LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks); \
         LOAD_B(bl_, has_next_ ? TAP_WIDX(tn_) : 0, has_next_ ? cn_ : 0); \
         const float* ha_ = hb + TAP_OFF(t); \
-        bf16x8 pv_[M16]; \
-        _Pragma("unroll") for (int m = 0; m < M16; ++m) pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(ha_ + pbase[m])); \
-        _Pragma("unroll") for (int n = 0; n < N16; ++n) { \
-            if (n < nvalid) { \
-                const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
-                _Pragma("unroll") for (int m = 0; m < M16; ++m) \
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, pv_[m], acc[m][n], 0, 0, 0); \
+        /* pixel tiles in two halves (the shared odd filter tile takes the first only); the 8-tile wave also reads them from LDS per half: \
+           16 operand registers live instead of 32 */ \
+        bf16x8 pv_[HALF_LOADS ? MH : M16]; \
+        if (!HALF_LOADS) { \
+            _Pragma("unroll") for (int m = 0; m < M16; ++m) pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(ha_ + pbase[m])); \
+        } \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
+            if (HALF_LOADS) { \
+                _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                    pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(ha_ + pbase[h * MH + m])); \
+            } \
+            _Pragma("unroll") for (int n = 0; n < N16; ++n) { \
+                if (n < nfull || (h == 0 && n == nsplit)) { \
+                    const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
+                    _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                        acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, pv_[HALF_LOADS ? m : h * MH + m], acc[h * MH + m][n], 0, 0, 0); \
+                } \
             } \
         } \
         wait_loads(bl_, hreg); \
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     bool pval[M16];
 #pragma unroll
     for (int m = 0; m < M16; ++m) {
-        const int pix = (wm * M16 + m) * 16 + l15;
+        const int pix = (wm * M16 + (m ^ mrot)) * 16 + l15;
         const int ty = pix / TW, tx = pix % TW;
         const int oyt = oy0 + ty, oxt = ox0 + tx;
         const int oy = oyt * OS + ts.py, ox = oxt * OS + ts.px;
@@ -201,7 +228,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
 #pragma unroll
     for (int n = 0; n < N16; ++n) {
         if (n >= nvalid) continue;
-        const int c4 = n0 + (n * WN + wn) * 16 + 4 * kq;
+        const int c4 = n0 + TILE_COL(n) + 4 * kq;
+        const int m_hi = (n == nsplit) ? M16 / 2 : M16;   // this wave's share of tile n
         const bool cvalid = c4 < a.n_end;       // channels c4..c4+3 beyond Cout (Cout % 4 != 0) are zero filters: zeros land in pad lanes
         const int cc = cvalid ? c4 : 0;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -238,14 +266,15 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
             float* yb = a.y + img_pix * a.y_cs + a.y_co;
 #pragma unroll
             for (int m = 0; m < M16; ++m)
-                if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
+                if (cvalid && pval[m] && m < m_hi) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
         } else {
             u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
 #pragma unroll
             for (int m = 0; m < M16; ++m)
-                if (cvalid && pval[m]) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
+                if (cvalid && pval[m] && m < m_hi) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
         }
     }
+#undef TILE_COL
 }
 
 // packed filter image wp[tap][chunk][o][32] (bf16) from the fp32 master parameter [Cout,Cin,ks,ks]

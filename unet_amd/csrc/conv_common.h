@@ -62,6 +62,22 @@ __device__ __forceinline__ void gld_b(v4f (&d)[N], unsigned voff, const char* p)
                      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(voff), "s"(s0), "s"(s1), "n"(TSTR));
     }
 }
+// The same with a lane offset of its own for the LAST tile: the kernels that share an odd last output tile between the two waves of a
+// pixel row (see `nsplit` in conv_igemm16_kernel) address that tile out of the regular stride.
+template <int TSTR, int N>
+__device__ __forceinline__ void gld_bl(v4f (&d)[N], unsigned voff, unsigned voff_last, const char* p) {
+    static_assert(N == 2 || N == 4, "operand-B tiles per wave");
+    const u64 s0 = sgpr_ptr(p);
+    if constexpr (N == 2) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:%5"
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(voff), "v"(voff_last), "s"(s0), "n"(TSTR));
+    } else {
+        const u64 s1 = sgpr_ptr(p + 2 * TSTR);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:%8\n\t"
+                     "global_load_dwordx4 %2, %4, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:%8"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(voff), "v"(voff_last), "s"(s0), "s"(s1), "n"(TSTR));
+    }
+}
 // The halo items of one chunk: one base, one lane offset per item.  Executed in EVERY stage with `on` = all ones (fetch) or
 // 0 (EXEC is cleared around the loads: nothing is fetched, the registers keep their values).  For the compiler the halo
 // registers are thus one unbroken chain of tied asm operands -- no conditional definition, no phi, hence no register copy

@@ -3,7 +3,9 @@
 The 16x16x4 conv kernel issues its main-loop global loads from inline asm and waits for them with its own
 ``s_waitcnt vmcnt(0)`` (see the comment above ``gld_b`` in csrc/conv_igemm.hip).  Between such a load and that wait the
 destination registers are "in flight": the compiler believes they already hold their values, so a register copy, spill
-or reuse scheduled into that window would silently read or destroy garbage.  This module compiles the file to assembly
+or reuse scheduled into that window would silently read or destroy garbage.  The analysis tracks the AGE of every outstanding load (how many asm loads
+were issued after it), so a partial wait ``s_waitcnt vmcnt(N)`` -- the kernel's own or one the compiler places for its loads --
+retires exactly the registers the hardware guarantees.  This module compiles the file to assembly
 and proves, per kernel, that no instruction between an asm load group and the following asm wait touches a destination
 register of an outstanding asm load.
 
@@ -100,21 +102,33 @@ def _check_function(name: str, body) -> Tuple[int, List[str]]:
     nloads = 0
     bad: List[str] = []
 
-    def transfer(i: int, inflight: Set[int], report: bool) -> Set[int]:
+    # State: {register: age}, age = number of asm loads issued AFTER the load that writes the register, minimised over all paths
+    # (the youngest the load can be).  Loads return in issue order, so `s_waitcnt vmcnt(N)` retires every register of age >= N.
+    # Vector-memory instructions the compiler issues itself are not counted: they only make the hardware retire MORE than modelled.
+    _VMCNT = re.compile(r"vmcnt\((\d+)\)")
+
+    def transfer(i: int, inflight: Dict[int, int], report: bool) -> Dict[int, int]:
         nonlocal nloads
-        cur = set(inflight)
+        cur = dict(inflight)
         for ln, code, in_asm in blocks[i]:
             if in_asm and code.startswith("global_load"):
                 ops = code.split(None, 1)[1].split(",")
                 dst = _regs(ops[0])
                 if report:
                     nloads += 1
-                    if _regs(",".join(ops[1:])) & cur:
+                    if _regs(",".join(ops[1:])) & cur.keys():
                         bad.append(f"{name}:{ln}: load address uses an in-flight register: {code}")
-                cur |= dst
+                    if dst & cur.keys():
+                        bad.append(f"{name}:{ln}: load overwrites an in-flight register: {code}")
+                cur = {r: a + 1 for r, a in cur.items()}
+                for r in dst:
+                    cur[r] = 0
                 continue
-            if code.startswith("s_waitcnt") and "vmcnt(0)" in code:
-                cur = set()           # the kernel's own wait asm, or a compiler-placed full drain
+            if code.startswith("s_waitcnt"):
+                m = _VMCNT.search(code)
+                if m:                 # the kernel's own wait asm, or a compiler-placed one
+                    keep = int(m.group(1))
+                    cur = {r: a for r, a in cur.items() if a < keep}
                 continue
             if in_asm:
                 continue
@@ -123,19 +137,23 @@ def _check_function(name: str, body) -> Tuple[int, List[str]]:
                     bad.append(f"{name}:{ln}: kernel ends with asm loads in flight")
                 continue
             if cur and report:
-                hit = _regs(code) & cur
+                hit = _regs(code) & cur.keys()
                 if hit:
                     bad.append(f"{name}:{ln}: touches in-flight v{sorted(hit)[0]}: {code}")
         return cur
 
-    ins: List[Set[int]] = [set() for _ in blocks]
+    ins: List[Dict[int, int]] = [dict() for _ in blocks]
     work = list(range(len(blocks)))
     while work:
         i = work.pop()
         out = transfer(i, ins[i], False)
         for j in succ[i]:
-            if not out <= ins[j]:
-                ins[j] |= out
+            changed = False
+            for r, a in out.items():
+                if ins[j].get(r, 1 << 30) > a:
+                    ins[j][r] = a
+                    changed = True
+            if changed:
                 work.append(j)
     for i in range(len(blocks)):
         transfer(i, ins[i], True)

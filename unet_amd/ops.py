@@ -226,6 +226,11 @@ def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, 
     _launch_conv(d, "conv2d", 2.0 * y.P * x.C * y.C * ks * ks)
 
 
+def conv2d_variant(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, kind: int = 0) -> int:
+    """id of the kernel instantiation the planner picks for this launch (unet_conv2d_variant; scripts/layer_table.py, tests)"""
+    return int(lib.unet_conv2d_variant(C.byref(_conv_desc(x, wp, y, ks, stride, kind))))
+
+
 def conv2d_dgrad(dy: TS, wp_dgrad: torch.Tensor, dx: TS, ks: int, stride: int = 1, res=None, mask=None, colsum=None):
     """dx = conv^T(dy); optional residual add, ReLU-backward mask, column sums of the result."""
     d = _conv_desc(dy, wp_dgrad, dx, ks, stride, L.CONV_DGRAD, None, res, mask, False, colsum, None)
