@@ -59,6 +59,12 @@ CASES = [
     (2, 32, 32, 100, 5, 1, 1),        # head
     (1, 24, 40, 96, 192, 3, 1),       # 128 + 64 produced channels: two channel-range launches
     (1, 32, 32, 64, 392, 1, 1),
+    # reduction tails of 1..8 channels run tap-folded (4 taps per MFMA; conv_common.h bf16_fold_tail)
+    (1, 24, 40, 36, 100, 3, 1),       # fold, two chunks; its dgrad reduces over 100: fold again
+    (2, 20, 24, 104, 40, 3, 1),       # tail of exactly 8
+    (1, 20, 24, 105, 33, 3, 1),       # tail of 9: not folded; dgrad tail of 1: folded
+    (2, 26, 26, 64, 100, 3, 2),       # stride-2 dgrad over 100 channels: four tap sets, reads the UNfolded tail of the same image
+    (1, 18, 18, 7, 24, 3, 1),         # everything is tail
 ]
 
 

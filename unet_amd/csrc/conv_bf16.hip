@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     const size_t slab_b = (size_t)a.coutPad * KCB * 2;
     constexpr int TSTR = WN * 16 * 64;     // bytes between two of this wave's filter tiles
     v4f b0[N16], b1[N16];
-#define LOAD_B(dst_, widx_, chunk_) gld_bl<TSTR, N16>((dst_), lane_b, lane_b_last, wbase + (size_t)((widx_) * a.nchunks + (chunk_)) * slab_b)
+#define LOAD_B(dst_, slab_) gld_bl<TSTR, N16>((dst_), lane_b, lane_b_last, wbase + (size_t)(slab_) * slab_b)
 
     f32x4 acc[M16][N16];
 #pragma unroll
@@ -143,8 +143,11 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     const int ntaps = ts.n;
 #pragma unroll
     for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // reduction tail folded over the taps (conv_common.h, bf16_fold_tail): the last chunk runs ntail stages of four taps each
+    const int fold = a.fold, last = a.nchunks - 1, ntail = (ntaps + 3) >> 2;
+    const int fold_slab0 = 9 * a.nchunks;
     LOAD_HALO(0, true);
-    LOAD_B(b0, ts.widx[0], 0);
+    LOAD_B(b0, (fold && last == 0) ? fold_slab0 : ts.widx[0] * a.nchunks);
     wait_loads(b0, hreg);
     STORE_HALO(halo_buf(0), 0);
     __syncthreads();
@@ -157,8 +160,14 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     constexpr bool HALF_LOADS = M16 > 4;
 #define STAGE_BODY(bu_, bl_) do { \
         LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks); \
-        LOAD_B(bl_, has_next_ ? TAP_WIDX(tn_) : 0, has_next_ ? cn_ : 0); \
-        const float* ha_ = hb + TAP_OFF(t); \
+        LOAD_B(bl_, has_next_ ? ((fold && cn_ == last) ? fold_slab0 + tn_ : TAP_WIDX(tn_) * a.nchunks + cn_) : 0); \
+        int aoff_; \
+        if (fold && chunk == last) {   /* lane group kq reads channel group 0 of the tail chunk at ITS tap, 4 t + kq */ \
+            int tl_ = 4 * t + kq; \
+            tl_ = tl_ < ntaps ? tl_ : 0;        /* (beyond the taps the fold slab holds zeros) */ \
+            aoff_ = TAP_OFF(tl_) - 4 * kq; \
+        } else aoff_ = TAP_OFF(t); \
+        const float* ha_ = hb + aoff_; \
         /* pixel tiles in two halves (the shared odd filter tile takes the first only); the 8-tile wave also reads them from LDS per half: \
            16 operand registers live instead of 32 */ \
         bf16x8 pv_[HALF_LOADS ? MH : M16]; \
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     } while (0)
 #define STAGE(bu_, bl_) do { \
         int tn_ = t + 1, cn_ = chunk; \
-        if (tn_ == ntaps) { tn_ = 0; cn_ = chunk + 1; } \
+        if (tn_ == ((fold && chunk == last) ? ntail : ntaps)) { tn_ = 0; cn_ = chunk + 1; } \
         const bool has_next_ = cn_ < a.nchunks; \
         STAGE_BODY(bu_, bl_); \
         if (tn_ == 0 && has_next_) { \
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
         t = tn_; chunk = cn_; \
     } while (0)
 
-    const int total = a.nchunks * ntaps;
+    const int total = fold ? last * ntaps + ntail : a.nchunks * ntaps;
     for (int s = 0; s + 1 < total; s += 2) {
         STAGE(b0, b1);
         STAGE(b1, b0);
@@ -277,25 +286,12 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
 #undef TILE_COL
 }
 
-// packed filter image wp[tap][chunk][o][32] (bf16) from the fp32 master parameter [Cout,Cin,ks,ks]
+// packed filter image (bf16; layout: conv_common.h, bf16_image_value) from the fp32 master parameter [Cout,Cin,ks,ks]
 //   mode 0: o = cout, reduction r = cin;  mode 1 (input gradient): o = cin, reduction r = cout
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin, int T, int mode, int nchunks,
                                          int outPad, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int rr = (int)(i & 31);
-        size_t j = i >> 5;
-        const int o = (int)(j % outPad); j /= outPad;
-        const int chunk = (int)(j % nchunks);
-        const int tap = (int)(j / nchunks);
-        const int r = chunk * 32 + rr;
-        float v = 0.f;
-        if (mode == 0) {
-            if (o < Cout && r < Cin) v = w[((size_t)o * Cin + r) * T + tap];
-        } else {
-            if (o < Cin && r < Cout) v = w[((size_t)r * Cin + o) * T + tap];
-        }
-        wp[i] = __builtin_bit_cast(u16, (__bf16)v);
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wp[i] = __builtin_bit_cast(u16, (__bf16)bf16_image_value(w, Cout, Cin, T, mode, nchunks, outPad, i));
 }
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
@@ -347,6 +343,7 @@ int plan_bf16(const unet_conv_desc* d, Plan* p) {
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
     p->lds_bytes = (size_t)(32 + 2 * p->max_hpix * LDKB) * sizeof(float);
+    p->k.fold = (p->nparity == 1 && bf16_fold_tail(d->Cin, d->ks * d->ks)) ? 1 : 0;
     UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
     UNET_CHECK_ARG(unet::aligned16(d->y) && (!d->res || unet::aligned16(d->res)) && (!d->mask || unet::aligned16(d->mask)),
                    "conv bf16: y/res/mask must be 16-byte aligned");
@@ -382,7 +379,7 @@ extern "C" int unet_set_bf16_big_tile(int on) {
 extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;
     const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
-    return (size_t)T * unet::cdiv(red, KCB) * unet::roundup(out, 128) * KCB;
+    return bf16_image_elems(red, unet::roundup(out, 128), T);
 }
 
 extern "C" int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream) {
@@ -391,7 +388,7 @@ extern "C" int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, i
     const int T = ks * ks;
     const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
     const int nchunks = unet::cdiv(red, KCB), outPad = unet::roundup(out, 128);
-    const size_t total = (size_t)T * nchunks * outPad * KCB;
+    const size_t total = bf16_image_elems(red, outPad, T);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout,
                        Cin, T, mode, nchunks, outPad, total);
     UNET_CHECK_LAUNCH();

@@ -29,9 +29,41 @@ struct KArgs {
     int S, OS, TSH, TSW, tiles_y, tiles_x, ntn;
     int nchunks, coutPad, flags, mtiles;
     int n_base, n_end;   // produced-channel range of this launch (unet_conv_desc.cout_begin / cout_count); n_end <= Cout
+    int fold;            // bf16 kernel: the reduction tail runs tap-folded (bf16_fold_tail below)
     long long wp_stride; // floats between the packed filter images of consecutive batch images (0: one image for all)
     TapSet taps[4];
 };
+
+// ---- the bf16 packed filter image ------------------------------------------------------------------------------
+// wp[tap][chunk32][outPad][32], and for a 3x3 filter whose reduction leaves a tail of 1..8 channels (100 = 3 * 32 + 4) three more
+// slabs fold[j][outPad][32]: k-slot (kq, c) of fold slab j = tail channel c of filter tap 4 j + kq.  One 16x16x32 MFMA then
+// multiplies the tail channels of FOUR taps (each 8-channel lane group reads its own tap's pixel): the tail chunk costs 3 stages
+// instead of 9 (30 instead of 36 for 100 channels).  Only single-tap-set launches use it (everything but the stride-2 input
+// gradient, which reads the unfolded tail chunk that is still part of the image).
+__host__ __device__ inline bool bf16_fold_tail(int red, int T) { return T == 9 && (red & 31) != 0 && (red & 31) <= 8; }
+__host__ __device__ inline size_t bf16_image_elems(int red, int out_pad, int T) {
+    return (size_t)(T * ((red + 31) / 32) + (bf16_fold_tail(red, T) ? 3 : 0)) * out_pad * 32;
+}
+// element i of the image of the fp32 master parameter w[Cout][Cin][T]; mode 0: out = cout, reduction = cin; mode 1: the reverse
+__device__ inline float bf16_image_value(const float* __restrict__ w, int Cout, int Cin, int T, int mode, int nchunks, int outPad, size_t i) {
+    const int rr = (int)(i & 31);
+    size_t j = i >> 5;
+    const int o = (int)(j % outPad);
+    const int slab = (int)(j / outPad);
+    const int red = mode == 0 ? Cin : Cout;
+    int tap, r;
+    if (slab < T * nchunks) {
+        tap = slab / nchunks;
+        r = (slab % nchunks) * 32 + rr;
+    } else {
+        tap = 4 * (slab - T * nchunks) + (rr >> 3);
+        r = (nchunks - 1) * 32 + (rr & 7);
+        if (tap >= T) return 0.f;
+    }
+    if (r >= red) return 0.f;
+    if (mode == 0) return o < Cout ? w[((size_t)o * Cin + r) * T + tap] : 0.f;
+    return o < Cin ? w[((size_t)r * Cin + o) * T + tap] : 0.f;
+}
 
 // ---- explicitly scheduled global loads for the 16x16x4 kernel -------------------------------------------------
 // The compiler's s_waitcnt insertion merges the wait state of conditional loads conservatively (it drained vmcnt to 0 in

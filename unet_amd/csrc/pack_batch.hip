@@ -6,9 +6,9 @@
 // parameters live in one flat buffer, the packed images are persistent).
 //
 // Layouts are those of unet_pack_weights (fp32: wp[tap][chunk16][outPad][16], a reduction tail stored channel-transposed) and
-// unet_pack_weights_bf16 (wp[tap][chunk32][outPad][32]); see conv_igemm.hip / conv_bf16.hip.
+// unet_pack_weights_bf16 (wp[tap][chunk32][outPad][32] + the tap-folded tail slabs, conv_common.h); see conv_igemm.hip / conv_bf16.hip.
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -31,33 +31,32 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
     }
     const Job j = jobs[lo];
     const int KC = bf16 ? 32 : 16, sh = bf16 ? 5 : 4;
-    const size_t total = (size_t)j.T * j.nchunks * j.outPad * KC;
-    const size_t base = (size_t)(blockIdx.x - j.block_begin) * ELEMS_PER_BLOCK;
     const int red = j.mode == 0 ? j.Cin : j.Cout;
+    const size_t total = bf16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : (size_t)j.T * j.nchunks * j.outPad * KC;
+    const size_t base = (size_t)(blockIdx.x - j.block_begin) * ELEMS_PER_BLOCK;
 #pragma unroll
     for (int k = 0; k < ELEMS_PER_BLOCK / 256; ++k) {
         const size_t i = base + threadIdx.x + k * 256;
         if (i >= total) break;
+        if (bf16) {
+            reinterpret_cast<unsigned short*>(j.wp)[i] =
+                __builtin_bit_cast(unsigned short, (__bf16)unetconv::bf16_image_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, j.outPad, i));
+            continue;
+        }
         const int rr = (int)(i & (KC - 1));
         size_t q = i >> sh;
         const int o = (int)(q % j.outPad); q /= j.outPad;
         const int chunk = (int)(q % j.nchunks);
         const int tap = (int)(q / j.nchunks);
-        int r;
-        if (bf16) {
-            r = chunk * 32 + rr;
-        } else {
-            const bool tail = (red & 15) != 0 && chunk == j.nchunks - 1;
-            r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
-        }
+        const bool tail = (red & 15) != 0 && chunk == j.nchunks - 1;
+        const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         float v = 0.f;
         if (j.mode == 0) {
             if (o < j.Cout && r < j.Cin) v = j.w[((size_t)o * j.Cin + r) * j.T + tap];
         } else {
             if (o < j.Cin && r < j.Cout) v = j.w[((size_t)r * j.Cin + o) * j.T + tap];
         }
-        if (bf16) reinterpret_cast<unsigned short*>(j.wp)[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
-        else reinterpret_cast<float*>(j.wp)[i] = v;
+        reinterpret_cast<float*>(j.wp)[i] = v;
     }
 }
 
@@ -80,7 +79,7 @@ extern "C" int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int d
         j.w = s.w; j.wp = s.wp; j.Cout = s.Cout; j.Cin = s.Cin; j.T = s.ks * s.ks; j.mode = s.mode;
         j.nchunks = unet::cdiv(red, KC); j.outPad = unet::roundup(out, 128);
         j.block_begin = (unsigned)blocks; j.pad_ = 0;
-        const size_t total = (size_t)j.T * j.nchunks * j.outPad * KC;
+        const size_t total = dtype == UNET_BF16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : (size_t)j.T * j.nchunks * j.outPad * KC;
         blocks += (total + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK;
         UNET_CHECK_ARG(blocks < (1ull << 31), "pack_batch_build: too many blocks");
     }
