@@ -168,7 +168,10 @@ class SelfAttention(nn.Module):
 # vision/models/xresnet.py restatement (body only: create_body cuts at the pool)
 # --------------------------------------------------------------------------
 
-XRESNET_LAYERS = {"xresnet18": (1, [2, 2, 2, 2]), "xresnet34": (1, [3, 4, 6, 3]), "xresnet50": (4, [3, 4, 6, 3])}
+# every constructor the reference imports (params_and_main.py:12): expansion, blocks per stage.  fastai XResNet: stage widths
+# [64, 128, 256, 512] + [256] * (len(layers) - 4), every stage after the first has stride 2 (xresnet34_deep: two more halvings)
+XRESNET_LAYERS = {"xresnet18": (1, [2, 2, 2, 2]), "xresnet34": (1, [3, 4, 6, 3]), "xresnet50": (4, [3, 4, 6, 3]),
+                  "xresnet101": (4, [3, 4, 23, 3]), "xresnet34_deep": (1, [3, 4, 6, 3, 1, 1])}
 
 
 def init_cnn(m: nn.Module):
@@ -181,14 +184,14 @@ def init_cnn(m: nn.Module):
 
 
 def xresnet_body(arch: str, c_in: int) -> nn.Sequential:
-    """Children 0..7 of fastai's XResNet: 3 stem ConvLayers (32,32,64; first is
-    stride 2), MaxPool2d(3,2,1), 4 stages of ResBlocks.  The reference replaces
+    """Children of fastai's XResNet up to the pooling layer: 3 stem ConvLayers (32,32,64; first is
+    stride 2), MaxPool2d(3,2,1), the 4 (xresnet34_deep: 6) stages of ResBlocks.  The reference replaces
     the first conv by a fresh ``nn.Conv2d(c_in, 32, 3, 2, 1, bias=False)`` with
     PyTorch's default init (train.py:130-135), reproduced here."""
     expansion, layers = XRESNET_LAYERS[arch]
     stem_szs = [3, 32, 32, 64]
     stem = [ConvLayer(stem_szs[i], stem_szs[i + 1], 3, stride=2 if i == 0 else 1) for i in range(3)]
-    block_szs = [64 // expansion, 64, 128, 256, 512]
+    block_szs = [64 // expansion, 64, 128, 256, 512] + [256] * (len(layers) - 4)
     stages = []
     for i, nb in enumerate(layers):
         ni, nf = block_szs[i], block_szs[i + 1]

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import time
 
-from unet_amd import xresnet18, xresnet34, xresnet50  # noqa: F401
+from unet_amd import xresnet18, xresnet34, xresnet34_deep, xresnet50, xresnet101  # noqa: F401
 
 # ----------------------------------------------------------------------------------- switches (params_and_main.py:22-24)
 Create_tiles = True

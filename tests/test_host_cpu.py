@@ -49,20 +49,23 @@ def test_product_path_has_no_cpu_fallback():
         assert "oracle" not in f.read_text().replace("selfcheck", "") or f.name == "selfcheck.py", f"{f} must not import the oracle"
 
 
-@pytest.mark.parametrize("arch,n_in,n_out", [("xresnet18", 3, 2), ("xresnet34", 4, 5), ("xresnet50", 8, 10)])
+@pytest.mark.parametrize("arch,n_in,n_out", [("xresnet18", 3, 2), ("xresnet34", 4, 5), ("xresnet50", 8, 10), ("xresnet101", 3, 4),
+                                             ("xresnet34_deep", 4, 3)])      # every constructor the reference imports (params_and_main.py:12)
 def test_module_tree_matches_oracle_state_dict(arch, n_in, n_out):
     from oracle import unet_oracle as O
     from unet_amd.model import HipDynamicUnet
     from unet_amd.optimizer import norm_bias_params, xresnet_split
-    m = HipDynamicUnet(arch, n_in, n_out, (64, 64), device="cpu")
-    r = O.DynamicUnet(arch, n_in, n_out, (64, 64))
+    size = (256, 256) if arch == "xresnet34_deep" else (64, 64)      # six stages: /128
+    m = HipDynamicUnet(arch, n_in, n_out, size, device="cpu")
+    r = O.DynamicUnet(arch, n_in, n_out, size)
+    assert list(m.sz_chg_idxs) == list(r.sz_chg_idxs)
     sm, sr = m.state_dict(), r.state_dict()
     assert list(sm.keys()) == list(sr.keys())
     assert all(a.shape == b.shape for a, b in zip(sm.values(), sr.values()))
     assert [sum(p.numel() for p in g) for g in xresnet_split(m)] == [sum(p.numel() for p in g) for g in O.xresnet_split(r)]
     assert sum(p.numel() for p in norm_bias_params(m)) == sum(p.numel() for p in O.bn_bias_params(r))
     # fastai indexing contract (train.py:78-80)
-    assert len(m[0][:3]) == 3 and len(m[0][3:]) == 5 and len(m[1:]) == len(m.layers) - 1
+    assert len(m[0][:3]) == 3 and len(m[0][3:]) == len(r.layers[0]) - 3 and len(m[1:]) == len(m.layers) - 1
 
 
 def test_bucket_spans_cover_everything_in_backward_order():

@@ -8,4 +8,6 @@ def _arch(name):
     return f
 
 
+# the constructors the reference imports (params_and_main.py:12)
 xresnet18, xresnet34, xresnet50 = _arch("xresnet18"), _arch("xresnet34"), _arch("xresnet50")
+xresnet101, xresnet34_deep = _arch("xresnet101"), _arch("xresnet34_deep")

@@ -55,7 +55,7 @@ class HipDynamicUnet(nn.Module):
         self.img_size = tuple(img_size)
         enc = Encoder(arch, n_in)
         # DynamicUnet.__init__: encoder children whose output size differs from the next child's are the skips
-        self.sz_chg_idxs = [6, 5, 4, 2]
+        self.sz_chg_idxs = sorted(enc.skip_channels, reverse=True)      # xresnet18/34/50/101: [6, 5, 4, 2]; xresnet34_deep: [8, 7, 6, 5, 4, 2]
         ni = enc.out_channels
         post_bn = nn.BatchNorm2d(ni, eps=BN_EPS, momentum=BN_MOM)
         with torch.no_grad():
@@ -81,6 +81,12 @@ class HipDynamicUnet(nn.Module):
         _kaiming_init(layers[3], layers[-2])
         self.layers = nn.ModuleList(layers)
         self.cat_c = xc
+        # every concat inside a UnetBlock is two channel slices of one buffer: the second starts at a multiple of the vector width
+        vec = 8 if act_dtype == "bf16" else 4
+        ragged = [b.cu for b in layers[4:4 + len(self.sz_chg_idxs)] if b.cu % vec] + ([self.up_c] if act_dtype == "bf16" and self.up_c % vec else [])
+        if ragged:
+            raise ValueError(f"{arch}: decoder widths {ragged} are not multiples of {vec} channels"
+                             + (" (bf16 storage): use act_dtype='f32' for this encoder" if act_dtype == "bf16" else ""))
         self._post_bx = _BNExec(post_bn)
         self._device = torch.device(device)
         self.ctx: Optional[Ctx] = None
@@ -245,7 +251,7 @@ class HipDynamicUnet(nn.Module):
         nb = 4 + len(self.sz_chg_idxs)
         X = ctx.act(self, "xcat", N, H, W, self.cat_c, zero=True)
         L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
-        ops.nchw_to_nhwc(x, X.sub(self.up_c, self.n_in))
+        ops.nchw_to_nhwc(x, X, at=self.up_c)        # after the shuffle: a ragged up_c leaves its pad lanes inside these channels
         o = L[nb + 3].hip_fwd(ctx, X)
         z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True, dtype=torch.float32)      # logits are fp32 in both modes
         head: ConvLayer = L[nb + 4]

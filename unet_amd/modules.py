@@ -760,7 +760,10 @@ def _kaiming_init(*mods):
                         l.bias.fill_(0.0)
 
 
-XRESNET_LAYERS = {"xresnet18": (1, [2, 2, 2, 2]), "xresnet34": (1, [3, 4, 6, 3]), "xresnet50": (4, [3, 4, 6, 3])}
+# the constructors the reference imports (params_and_main.py:12): expansion, blocks per stage; stage widths of fastai's XResNet are
+# [64, 128, 256, 512] + [256] * (len(layers) - 4), every stage after the first halves the resolution
+XRESNET_LAYERS = {"xresnet18": (1, [2, 2, 2, 2]), "xresnet34": (1, [3, 4, 6, 3]), "xresnet50": (4, [3, 4, 6, 3]),
+                  "xresnet101": (4, [3, 4, 23, 3]), "xresnet34_deep": (1, [3, 4, 6, 3, 1, 1])}
 
 
 def _init_cnn(m: nn.Module):
@@ -781,7 +784,7 @@ class Stage(nn.Sequential):
 
 
 class Encoder(nn.Sequential):
-    """children 0..7 of fastai XResNet (create_body cut at the pooling layer) with the reference's stem swap."""
+    """children of fastai XResNet up to the pooling layer (create_body: 3 stem convs, max-pool, 4 or 6 stages) with the reference's stem swap."""
     forward = _no_forward
 
     def __getitem__(self, idx):
@@ -793,7 +796,7 @@ class Encoder(nn.Sequential):
         expansion, layers = XRESNET_LAYERS[arch]
         stem_szs = [3, 32, 32, 64]
         stem = [ConvLayer(stem_szs[i], stem_szs[i + 1], 3, stride=2 if i == 0 else 1) for i in range(3)]
-        block_szs = [64 // expansion, 64, 128, 256, 512]
+        block_szs = [64 // expansion, 64, 128, 256, 512] + [256] * (len(layers) - 4)
         stages = []
         for i, nb in enumerate(layers):
             ni, nf = block_szs[i], block_szs[i + 1]
@@ -806,4 +809,7 @@ class Encoder(nn.Sequential):
         self[0][0] = new_conv
         self[0].cx = _ConvExec(new_conv)
         self.out_channels = block_szs[-1] * expansion
-        self.skip_channels = {2: 64, 4: 64 * expansion, 5: 128 * expansion, 6: 256 * expansion}
+        # DynamicUnet hooks the children whose output is larger than the next child's: the last stem conv (before the max-pool) and
+        # every stage but the last (each later stage starts with a stride-2 block)
+        self.skip_channels = {2: 64}
+        self.skip_channels.update({4 + i: block_szs[i + 1] * expansion for i in range(len(layers) - 1)})

@@ -361,10 +361,17 @@ def resize_nearest_bwd(dy: TS, dx: TS):
           "resize_nearest_bwd")
 
 
-def nchw_to_nhwc(x: torch.Tensor, y: TS):
+def nchw_to_nhwc(x: torch.Tensor, y: TS, at: Optional[int] = None):
+    """NCHW fp32 -> the channels of the NHWC slice `y`; with `at`, into channels [at, at + C) of y's buffer instead -- the one writer
+    that may start at ANY channel (scalar stores): the network-input half of the final concat sits behind an up-sampling path whose
+    width need not be a multiple of the vector width (xresnet34_deep: 102)."""
     N, C_, H, W = x.shape
-    assert x.is_contiguous() and y.C == C_
-    check(_fn("nchw_to_nhwc", y)(x.data_ptr(), y.ptr, y.cs, y.co, N, C_, H, W, _stream()), "nchw_to_nhwc")
+    if at is None:
+        assert x.is_contiguous() and y.C == C_
+        check(_fn("nchw_to_nhwc", y)(x.data_ptr(), y.ptr, y.cs, y.co, N, C_, H, W, _stream()), "nchw_to_nhwc")
+    else:
+        assert x.is_contiguous() and y.co == 0 and at + C_ <= y.cs
+        check(_fn("nchw_to_nhwc", y)(x.data_ptr(), y.ptr, y.cs, at, N, C_, H, W, _stream()), "nchw_to_nhwc")
 
 
 def nhwc_to_nchw(x: TS, y: torch.Tensor):
