@@ -36,6 +36,7 @@ struct WArgs {
     int tiles_y, tiles_x, total_tiles, tiles_per_block;
     int kt, ct;  // number of k / c block tiles
     int cw, nnb; // narrow-output kernel: input-channel chunk width, column blocks per chunk
+    int xcd_map; // bf16 kernel: grid.y is a multiple of 8 and the channel blocks of ONE pixel split are dealt to ONE XCD
 };
 
 template <int PTW, int S, int KS>
@@ -555,12 +556,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = l15 & 3;
-    const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
+    // The kt x ct channel blocks of one pixel split stream the same x and dy rows.  Workgroups are dealt round-robin to the 8 XCDs in
+    // launch order, so with the plain (x = block, y = split) numbering every XCD's L2 fetched every slab for itself: 0.82 GB per launch
+    // for 0.27 GB of operands at 4.3 TB/s -- the kernel ran at the L2-miss bandwidth, not at the MFMA rate (profiles/r02_b_bf16).  With
+    // xcd_map the blocks of split s all land on XCD s % 8 (linear ids 8 apart): one fetch per slab and XCD.
+    int bx = blockIdx.x, split = blockIdx.y;
+    if (a.xcd_map) {
+        const int cols = gridDim.x, lin = blockIdx.x + cols * blockIdx.y;
+        const int qq = lin >> 3;
+        bx = qq % cols;
+        split = (lin & 7) + 8 * (qq / cols);
+    }
+    const int kblk = bx / a.ct, cblk = bx % a.ct;
     const int k0 = kblk * BK, c0 = cblk * BC;
-    const int split = blockIdx.y;
     const int tile_begin = split * a.tiles_per_block;
     int tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    if (tile_begin >= a.total_tiles) return;          // padding of the split count to a multiple of 8 (uniform per workgroup)
 
     f32x4 acc[2][2][T];
 #pragma unroll
@@ -1000,7 +1012,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     }
     // aim for ~512 workgroups (256 CUs x 2 resident); at least 4 tiles per block
     int want = 512 / cols;
-    if (p->narrow && want >= 8) want &= ~7;      // the XCD-aware mapping pads the split count to a multiple of 8: stay within 512
+    if ((p->narrow || p->bf16) && want >= 8) want &= ~7;      // the XCD-aware mapping pads the split count to a multiple of 8: stay within 512
     if (want < 1) want = 1;
     int tpb = unet::cdiv(k.total_tiles, want);
     if (tpb < 4) tpb = 4;
@@ -1048,7 +1060,9 @@ int launch_wb(const WPlan& p, hipStream_t st) {
     if (unet::first_use_on_device(&configured)) {
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, p.splits), dim3(256), p.lds_bytes, st, p.k);
+    WArgs k = p.k;
+    k.xcd_map = p.splits >= 8 ? 1 : 0;           // fewer splits than XCDs: plain numbering
+    hipLaunchKernelGGL(kern, dim3(p.k.kt * p.k.ct, k.xcd_map ? unet::roundup(p.splits, 8) : p.splits), dim3(256), p.lds_bytes, st, k);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
