@@ -112,7 +112,9 @@ int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int 
 /* 1x1 "weights" that are themselves activations (self-attention operands): element (out o, reduction r) = w[o*so + r*sr];
  * produces the same packed image as mode 0 with ks = 1 (size unet_pack_weights_size(O, R, 1, 0)). */
 int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream);
-/* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32) */
+/* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32);
+ * a 3x3 filter whose reduction leaves a tail of 1..8 channels gets three more slabs fold[j][outPad][32] (k-slot (kq, c) = tail
+ * channel c of tap 4 j + kq) that single-tap-set launches read instead of the nine tail chunks.  The size function includes them. */
 size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode); /* elements */
 int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream);
 /* All filter images of a model in one launch (the parameters change every step, so every image is rebuilt every step).
