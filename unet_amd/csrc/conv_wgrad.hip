@@ -69,9 +69,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Stage one pixel tile: global -> registers -> LDS in batches of 4 float4 per thread (the
-    // accumulators own most of the register file; the co-resident workgroup hides this phase).
-    auto stage_tile = [&](int tile) {
+    // One pixel tile: global -> registers (load_tile) -> LDS (store_tile).  The NEXT tile is fetched while the current one is
+    // multiplied and stored behind it: the loads of a tile are a full L2 / HBM round trip that only the co-resident workgroup used to
+    // cover (MFMA pipe busy 81 %).
+    float4 rd[DIT], rx[XIT];
+    auto load_tile = [&](int tile) {
         int b = tile;
         const int tx = b % a.tiles_x; b /= a.tiles_x;
         const int ty = b % a.tiles_y;
@@ -79,42 +81,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         const int oy0 = ty * PTH, ox0 = tx * PTW;
         const float* dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
         const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
-        {
-            float4 r[DIT];
 #pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int e = tid + it * 256;
-                const int p = e >> 4, q = e & 15;
-                const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
-                const bool ok = (e < PT * 16) && oy < a.OH && ox < a.OW && (k0 + 4 * q) < a.Cout4;
-                r[it] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int e = tid + it * 256;
-                if (e < PT * 16) *reinterpret_cast<float4*>(dyT + e * 4) = r[it];
-            }
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + it * 256;
+            const int p = e >> 4, q = e & 15;
+            const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
+            const bool ok = (e < PT * 16) && oy < a.OH && ox < a.OW && (k0 + 4 * q) < a.Cout4;
+            rd[it] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-        constexpr int XB = 4;
 #pragma unroll
-        for (int base = 0; base < XIT; base += XB) {
-            float4 r[XB];
+        for (int j = 0; j < XIT; ++j) {
+            const int e = tid + j * 256;
+            const int p = e >> 4, q = e & 15;
+            const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+            const bool ok = (e < HPIX * 16) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
+            rx[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
 #pragma unroll
-            for (int j = 0; j < XB; ++j) {
-                const int e = tid + (base + j) * 256;
-                const int p = e >> 4, q = e & 15;
-                const int iy = iy0 + p / HW, ix = ix0 + p % HW;
-                const bool ok = (e < HPIX * 16) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
-                r[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + it * 256;
+            if (e < PT * 16) *reinterpret_cast<float4*>(dyT + e * 4) = rd[it];
+        }
 #pragma unroll
-            for (int j = 0; j < XB; ++j) {
-                const int e = tid + (base + j) * 256;
-                if (e < HPIX * 16) *reinterpret_cast<float4*>(xh + e * 4) = r[j];
-            }
+        for (int j = 0; j < XIT; ++j) {
+            const int e = tid + j * 256;
+            if (e < HPIX * 16) *reinterpret_cast<float4*>(xh + e * 4) = rx[j];
         }
     };
 
@@ -125,14 +121,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     // bias gradient: threads 0..63 of the first channel-block column sum the staged dy tile (pads are zero)
     const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
     float bsum = 0.f;
+    if (tile_begin < tile_end) {
+        load_tile(tile_begin);
+        store_tile();
+    }
+    __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        stage_tile(tile);
-        __syncthreads();
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) load_tile(tile + 1);
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * BK + tid];
         }
-#pragma unroll
+        // (a full unroll hoists operand reads until the register file is full; the prefetched tile needs DIT + XIT float4 of it)
+#pragma unroll 4
         for (int step = 0; step < PT / 2; ++step) {
             // pixel 2*step + h ; 2*step is even and PTW is even, so px = (2*step % PTW) + h, py = 2*step / PTW
             const int py = (2 * step) / PTW, px = (2 * step) % PTW;
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
                     acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KS + s], 0, 0, 0);
                 }
         }
+        __syncthreads();                  // every wave is done reading this tile
+        if (has_next) store_tile();
         __syncthreads();
     }
 
