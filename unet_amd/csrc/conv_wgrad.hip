@@ -452,10 +452,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         }
     };
 
+    // Prefetch inside a column strip: the next tile is ONE ROW further down, so every item's address is the previous tile's plus a
+    // row stride and its column / channel validity does not change.  The per-item offsets are set up once per strip; the in-loop
+    // prefetch then costs a few adds per item instead of re-deriving (pixel, channel quad) from the thread index -- measured by
+    // switching the in-loop loads off: 7.53 -> 6.60 ms per 100->100 launch, i.e. their ADDRESS ARITHMETIC, not their bytes, cost 12 %.
+    int dyo[DIT], xo[RIT];          // element offsets inside the image row block (dy: row oy, x: row iy), -1 = never valid
+    auto strip_setup = [&](const TilePos& t) {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + it * 256;
+            const int p = e / Q, q = e - p * Q;
+            const bool ok = (e < PT * Q) && (t.ox0 + p) < a.OW && 4 * q < a.Cout4;
+            dyo[it] = ok ? (t.ox0 + p) * a.dy_cs + 4 * q : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < RIT; ++j) {
+            const int e = tid + j * 256;
+            const int hx = e / Q, q = e - hx * Q;
+            const int ix = t.ox0 - 1 + hx;
+            const bool ok = (e < HW * Q) && ix >= 0 && ix < a.IW && 4 * q < cw4;
+            xo[j] = ok ? ix * a.x_cs + 4 * q : -1;
+        }
+    };
+    // the tile one row below `t` (same strip): dy row t.oy + 1 ... = nx.oy, input row nx.oy + 1
+    auto prefetch_rolling = [&](const TilePos& nx, float4 (&rdy)[DIT], float4 (&rxr)[RIT]) {
+        const float* dyrow = nx.dyb;                                            // already points at image row nx.oy
+        const int iy = nx.oy + 1;
+        const float* xrow = nx.xb + (size_t)iy * a.IW * a.x_cs;
+        const bool rowok = iy < a.IH;                                           // (iy >= 0 always: nx.oy >= 1)
+        // unconditional loads from a clamped address + select: a conditional load is a branch around it (8 exec-mask branches per tile)
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const bool ok = dyo[it] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(dyrow + (ok ? dyo[it] : 0));
+            rdy[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < RIT; ++j) {
+            const bool ok = rowok && xo[j] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(ok ? xrow + xo[j] : nx.xb);       // nx.xb: first pixel of the image, always mapped
+            rxr[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
     // bias gradient: the first workgroup column sums the staged dy tile (one thread per output channel)
     const bool do_bias = a.bpart != nullptr && bx == 0 && tid < a.Cout;
     float bsum = 0.f;
-    if (tile_begin < tile_end) stage_rows(tile_pos(tile_begin), 0);
+    if (tile_begin < tile_end) {
+        const TilePos t0 = tile_pos(tile_begin);
+        stage_rows(t0, 0);
+        if (PF) strip_setup(t0);
+    }
     __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int oy = tile % a.OH;
@@ -464,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         TilePos nx;
         float4 pd[DIT], px[RIT];
         if (has_next) nx = tile_pos(tile + 1);
-        if (PF && rolling) { load_dy(nx, pd); load_row(nx, 2, px); }
+        if (PF && rolling) prefetch_rolling(nx, pd, px);
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
@@ -494,7 +541,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         if (has_next) {
             __syncthreads();                 // everyone is done reading this tile (the new row replaces row oy - 1)
             if (PF && rolling) { store_dy(pd); store_row(nx, 2, px); }
-            else stage_rows(nx, rolling ? 2 : 0);
+            else {
+                stage_rows(nx, rolling ? 2 : 0);
+                if (PF) strip_setup(nx);          // a new column strip begins
+            }
             __syncthreads();
         }
     }
