@@ -5,7 +5,7 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 counts a 128
 (MI355X_MICROARCH.md, HBM / rocprofv3 section); the two counters come from SEPARATE passes.
 usage: python scripts/summarize_profiles.py <tag>
 """
-import collections, csv, glob, json, re, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 from pathlib import Path
 
 tag = sys.argv[1]
@@ -23,7 +23,7 @@ def short(name: str) -> str:
 
 def pmc(dirname):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    f = glob.glob(str(src / dirname / "*" / "*_counter_collection.csv"))
+    f = sorted(glob.glob(str(src / dirname / "*" / "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)   # newest run first
     if not f:
         return out
     for r in csv.DictReader(open(f[0])):
@@ -33,7 +33,7 @@ def pmc(dirname):
 
 def durations(dirname):
     out = collections.defaultdict(list)
-    f = glob.glob(str(src / dirname / "*" / "*_kernel_trace.csv"))
+    f = sorted(glob.glob(str(src / dirname / "*" / "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
     if f:
         for r in csv.DictReader(open(f[0])):
             out[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -41,7 +41,7 @@ def durations(dirname):
 
 
 shutil.copy(src / "bench.json", dst / f"{tag}_bench.json")
-stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))[0]
+stats = sorted(glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)[0]
 shutil.copy(stats, dst / f"{tag}_bench_kernel_stats.csv")
 
 fetch, write, sq, sqdur, lds = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), durations("pmc_sq"), pmc("pmc_lds")
