@@ -17,8 +17,10 @@ dst = root / "profiles"
 def short(name: str) -> str:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    name = name.split("(")[0]
-    return name.replace(" ", "")
+    name = name.split("(")[0].replace(" ", "")
+    # conv_igemm16_kernel<..., SLV>: the sliver instantiation (the 3 launches per step with a 16 n + 4 output width) is the same kernel
+    # template as the plain one; the PMC summary and pmc_traffic.json aggregate both under the name without the flag
+    return re.sub(r"^(conv_igemm16_kernel<[0-9,]+),(?:true|false)>$", r"\1>", name)
 
 
 def pmc(dirname):

@@ -25,7 +25,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(L.lib, s), s
     assert L.lib.unet_abi_version() == 2
     # pure host-side queries work without a GPU
-    assert L.lib.unet_pack_weights_size(100, 100, 3, 0) == 9 * 7 * 128 * 16
+    assert L.lib.unet_pack_weights_size(96, 100, 3, 0) == 9 * 7 * 128 * 16
+    # 100 output channels = 6 tiles of 16 + a 4-channel sliver image [tap][chunk][4][16] behind the main one
+    assert L.lib.unet_pack_weights_size(100, 100, 3, 0) == 9 * 7 * 128 * 16 + 9 * 7 * 64
     assert L.lib.unet_bn_stats_rows(10) == 1 and L.lib.unet_bn_stats_rows(1 << 30) == 512
 
 

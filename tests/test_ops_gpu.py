@@ -95,6 +95,44 @@ def test_conv_channel_range_launch(ops):
     assert L.lib.unet_conv2d(L.C.byref(d3), ops._stream()) != 0
 
 
+@pytest.mark.parametrize("Cin,Cout", [(100, 100), (96, 97), (36, 99), (100, 116), (20, 228)])
+def test_conv_sliver_last_channels_on_mfma4x4(ops, Cin, Cout):
+    """Output widths of 16 n + (1..4): in the 128 x 128 tile the last channels run on v_mfma_f32_4x4x1 (conv_igemm16_kernel `sliver`,
+    filters from the sliver image behind the packed one).  Forward with bias + residual + ReLU into a channel slice, ragged pixel
+    tiles; then the input-gradient form (residual + ReLU mask) of a conv whose INPUT width is such a count."""
+    N, H, W = 2, 150, 170                      # 400+ blocks of 128 pixels: the planner keeps the 128 x 128 tile
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    cs_out = (Cout + 3) // 4 * 4 + 8
+    xt, rt = to_ts(x), to_ts(r, cs=cs_out + 4, co=4)
+    yt = empty_ts(N, H, W, Cout, cs=cs_out, co=4)
+    wp = ops.pack_weights(w.cuda(), 0)
+    assert ops.conv2d_variant(xt, wp, yt, 3, 1) == 321280
+    ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x, w, b, padding=1) + r)
+    assert_close(from_ts(yt), ref, rtol=2e-4, what="sliver fwd")
+    assert outside_untouched(yt)
+    # column sums switch the sliver off: same launch, all channels on 16-wide tiles -- the results agree to summation order
+    y2 = empty_ts(N, H, W, Cout)
+    rows = ops.conv_colsum_rows(xt, wp, y2, 3, 1, 0)
+    ops.conv2d(xt, wp, y2, 3, 1, bias=b.cuda(), res=rt, relu=True, colsum=torch.zeros(rows, Cout, device="cuda"))
+    assert_close(from_ts(y2), from_ts(yt), rtol=2e-5, what="sliver vs tiles")
+    assert torch.equal(from_ts(y2)[:, :Cout // 16 * 16], from_ts(yt)[:, :Cout // 16 * 16]), "the full tiles are the same program"
+    # input gradient of a conv Cout -> Cin: produces Cout channels
+    dy = torch.randn(N, Cin, H, W, generator=g)
+    wd = torch.randn(Cin, Cout, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    m = torch.randn(N, Cout, H, W, generator=g)
+    dxt = empty_ts(N, H, W, Cout)
+    ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(wd.cuda(), 1), dxt, 3, 1, res=rt, mask=to_ts(m))
+    torch.cuda.synchronize()
+    dref = (torch.nn.grad.conv2d_input((N, Cout, H, W), wd, dy, padding=1) + r) * (m > 0)
+    assert_close(from_ts(dxt), dref, rtol=2e-4, what="sliver dgrad")
+
+
 def test_conv_fwd_slices_relu_res_colsum(ops):
     """Channel-sliced input/output (concat elimination), bias+residual+ReLU epilogue, column sums."""
     N, H, W, Cin, Cout = 2, 24, 40, 36, 100

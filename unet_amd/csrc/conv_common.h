@@ -30,9 +30,35 @@ struct KArgs {
     int nchunks, coutPad, flags, mtiles;
     int n_base, n_end;   // produced-channel range of this launch (unet_conv_desc.cout_begin / cout_count); n_end <= Cout
     int fold;            // bf16 kernel: the reduction tail runs tap-folded (bf16_fold_tail below)
+    int sliver;          // fp32 16x16x4 kernel: the last 1..4 output channels run on v_mfma_f32_4x4x1 (f32_sliver below)
+    const float* wsl;    // its filter image [tap][chunk16][4][16]
     long long wp_stride; // floats between the packed filter images of consecutive batch images (0: one image for all)
     TapSet taps[4];
 };
+
+// ---- the fp32 packed filter image --------------------------------------------------------------------------------
+// wp[tap][chunk16][outPad][16] (a reduction tail stored channel-transposed, see pack_weights_kernel), and for an output width that
+// leaves 1..4 channels beyond a multiple of 16 (100 = 6 * 16 + 4) a SLIVER image behind it: wsl[tap][chunk16][4][16] holds the
+// filters of those channels, position p of a 16-float row = reduction channel p of the chunk (tail chunk: the same transposition
+// as the main image, channel 4 (p % 4) + p / 4).  conv_igemm16_kernel<.,2,2,2,2,4> multiplies them with v_mfma_f32_4x4x1_16B_f32
+// (64 pixels x 4 channels per instruction at the FLOP rate of the 16x16x4 form) instead of paying a seventh 16-wide tile for 4 of
+// its 16 columns.
+__host__ __device__ inline bool f32_sliver(int out) { return out >= 16 && (out & 15) != 0 && (out & 15) <= 4; }
+__host__ __device__ inline size_t f32_image_elems(int red, int out, int T) {
+    const int nchunks = (red + 15) / 16, outPad = (out + 127) / 128 * 128;
+    return (size_t)T * nchunks * outPad * 16 + (f32_sliver(out) ? (size_t)T * nchunks * 64 : 0);
+}
+// element i of the sliver image (i counted from its start); same (w, Cout, Cin, T, mode) convention as bf16_image_value
+__device__ inline float f32_sliver_value(const float* __restrict__ w, int Cout, int Cin, int T, int mode, int nchunks, size_t i) {
+    const int pos = (int)(i & 15), j = (int)((i >> 4) & 3);
+    const int chunk = (int)((i >> 6) % nchunks), tap = (int)((i >> 6) / nchunks);
+    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const bool tail = (red & 15) != 0 && chunk == nchunks - 1;
+    const int r = chunk * 16 + (tail ? (4 * (pos & 3) + (pos >> 2)) : pos);
+    const int o = (out & ~15) + j;
+    if (r >= red || o >= out) return 0.f;
+    return mode == 0 ? w[((size_t)o * Cin + r) * T + tap] : w[((size_t)r * Cin + o) * T + tap];
+}
 
 // ---- the bf16 packed filter image ------------------------------------------------------------------------------
 // wp[tap][chunk32][outPad][32], and for a 3x3 filter whose reduction leaves a tail of 1..8 channels (100 = 3 * 32 + 4) three more
@@ -151,6 +177,28 @@ __device__ __forceinline__ void gld_halo(v4f (&h)[N], const unsigned (&vo)[N], c
                        [o6] "v"(vo[6]), [o7] "v"(vo[7]), [o8] "v"(vo[8]), [o9] "v"(vo[9]), [sb] "s"(sb), [on] "s"(on)
                      : "scc");   // s_and_saveexec writes SCC
     }
+}
+// The four halo items of a chunk plus ONE item of the chunk's sliver filters (base of its own; lanes selected by `msl`, which is zero
+// outside sliver launches).  Same contract as gld_halo: executed in every stage, EXEC-masked.
+__device__ __forceinline__ void gld_halo4_sl(v4f (&h)[4], const unsigned (&vo)[4], const void* p, bool fetch, v4f& sl, unsigned vosl,
+                                             const void* psl, u64 msl) {
+    const u64 sb = sgpr_ptr(p), sbl = sgpr_ptr(psl);
+    const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
+    const u64 ms = sgpr_ptr(reinterpret_cast<const void*>(msl));
+    u64 sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+                 "global_load_dwordx4 %[h0], %[o0], %[sb]\n\tglobal_load_dwordx4 %[h1], %[o1], %[sb]\n\t"
+                 "global_load_dwordx4 %[h2], %[o2], %[sb]\n\tglobal_load_dwordx4 %[h3], %[o3], %[sb]\n\t"
+                 "s_and_b64 exec, exec, %[ms]\n\ts_nop 0\n\t"
+                 "global_load_dwordx4 %[sl], %[osl], %[sbl]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [sl] "+v"(sl), [sv] "=&s"(sv)
+                 : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [osl] "v"(vosl), [sb] "s"(sb), [sbl] "s"(sbl),
+                   [on] "s"(on), [ms] "s"(ms)
+                 : "scc");
+}
+__device__ __forceinline__ void wait_loads_sl(v4f (&b)[4], v4f (&h)[4], v4f& sl) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(sl));
 }
 // s_waitcnt vmcnt(0) that also "defines" every register the outstanding loads write (operand-B tiles and halo items), so
 // that no consumer is scheduled above it
@@ -323,6 +371,15 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     p->max_hpix = max_hpix;
     // the 16x16x4 kernel keeps no filter slab in LDS (operand B goes global -> VGPR)
     p->lds_bytes = (size_t)(32 + 2 * max_hpix * LDK + (p->mf == 16 ? 0 : 2 * p->bn * LDK)) * sizeof(float);
+    // fp32 sliver (kc == 16 only): the 128 x 128 tile of the 16x16x4 kernel, single tap set, the launch that produces the last channels,
+    // one filter image for all batch images, no column sums
+    k.sliver = 0; k.wsl = nullptr;
+    if (kc == 16 && p->mf == 16 && p->bm == 128 && p->bn == 128 && p->hit == 4 && p->nparity == 1 && f32_sliver(d->Cout) && k.n_end == d->Cout &&
+        d->wp_img_stride == 0 && d->colsum == nullptr && d->colsumsq == nullptr) {
+        k.sliver = 1;
+        k.wsl = d->wp + (size_t)T * k.nchunks * k.coutPad * 16;
+        p->lds_bytes += (size_t)2 * T * 64 * sizeof(float);
+    }
     // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
     p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), 1, (unsigned)p->nparity);
     UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");

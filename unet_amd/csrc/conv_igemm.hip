@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm_kern
 //   * output-channel tiles that lie entirely beyond Cout are SKIPPED per wave (uniform branch): produced
 //     channel counts are padded to 16 instead of 32/64/128 (Cout = 96 exact, 100 -> 112, 192 exact);
 //   * a reduction tail of r < 16 channels costs ceil(r/4) MFMA steps (ds_read_b32 operands) instead of 4.
-template <int TW, int MT, int NT, int WM, int WN, int HIT>
+template <int TW, int MT, int NT, int WM, int WN, int HIT, bool SLV = false>
 __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_kernel(const KArgs a) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, NTH = WM * WN * 64;
     constexpr int M16 = 2 * MT, N16 = 2 * NT;
@@ -358,13 +358,32 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
 
     v4f hreg[HIT];
     const bool has_tail = (a.Cin & 15) != 0;
+    // Sliver (conv_common.h, f32_sliver): in the 128 x 128 tile the block that ends the output range computes its last 1..4
+    // channels with v_mfma_f32_4x4x1_16B_f32 instead of a whole 16-wide tile: lane l = 4 blk + i supplies A = x[pixel l][k],
+    // lane 4 blk + j supplies B = w[k][channel j], and lane 4 blk + j receives D[r] = pixel 4 blk + r, channel j (16 blocks of 4 x 4).
+    // The wave with fewer full tiles (wn = 1) multiplies it: 16 instructions of 8 cycles per stage next to 48 of 32.
+    // (SLV: an instantiation of its own, so that launches without a sliver run exactly the code they ran before)
+    constexpr bool SL = SLV;
+    static_assert(!SLV || (MT == 2 && NT == 2 && WM == 2 && WN == 2 && HIT == 4), "sliver: the 128 x 128 tile only");
+    const bool sliver = SL && a.sliver != 0 && nt == a.ntn - 1;
+    const bool slw = sliver && wn == 1;
+    v4f slreg = {0.f, 0.f, 0.f, 0.f};                        // this thread's item of the chunk's sliver filters
+    const int sl_items = ts.n * 16;                          // float4 items per chunk: [tap][4 channels][16 k]
+    const u64 sl_mask = sliver ? __ballot(tid < sl_items) : 0ull;
+    // byte offset of this thread's item inside the sliver image at chunk 0: tap tid >> 4 (its filter tap), float4 (tid & 15) of the [4][16] block
+    const unsigned vosl0 = (unsigned)((TAP_WIDX((tid >> 4) < ts.n ? (tid >> 4) : 0) * a.nchunks * 64 + (tid & 15) * 4) * 4);
+    float* sl0 = lds0 + 2 * HPIX * LDK;
+    auto sl_buf = [&](int b) -> float* { return sl0 + b * (9 * 64); };
 
     // halo items: always HIT loads; an item outside the image / beyond the channels loads offset 0 and is zeroed at the store
 #define HALO_OK(it_, c0_) (goff[it_] >= 0 && ((c0_) + 4 * ((tid + (it_) * NTH) & 3)) < a.Cin4)
 #define LOAD_HALO(chunk_, on_) do { const int c0_ = (chunk_) * KC; unsigned vo_[HIT]; \
         if (on_) { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = HALO_OK(it, c0_) ? (unsigned)(goff[it] + c0_) * 4u : 0u; } \
         else { _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = 0u; } \
-        gld_halo<HIT>(hreg, vo_, xb, (on_)); } while (0)
+        if constexpr (SL) { \
+            gld_halo4_sl(hreg, vo_, xb, (on_), slreg, vosl0 + (unsigned)(chunk_) * 256u, a.wsl != nullptr ? (const void*)a.wsl : (const void*)a.wp, sl_mask); \
+        } else gld_halo<HIT>(hreg, vo_, xb, (on_)); } while (0)
+#define WAIT_LOADS(b_) do { if constexpr (SL) wait_loads_sl(b_, hreg, slreg); else wait_loads(b_, hreg); } while (0)
 #define STORE_HALO(dst_, chunk_) do { const int c0_ = (chunk_) * KC; const bool tail_ = has_tail && (chunk_) == a.nchunks - 1; \
         _Pragma("unroll") for (int it = 0; it < HIT; ++it) { \
             const int e_ = tid + it * NTH; \
@@ -372,7 +391,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
                 const v4f v_ = HALO_OK(it, c0_) ? hreg[it] : (v4f){0.f, 0.f, 0.f, 0.f}; \
                 if (tail_) { float* row_ = (dst_) + (e_ >> 2) * LDK + (e_ & 3); row_[0] = v_.x; row_[4] = v_.y; row_[8] = v_.z; row_[12] = v_.w; } \
                 else *reinterpret_cast<v4f*>((dst_) + (e_ >> 2) * LDK + (e_ & 3) * 4) = v_; \
-            } } } while (0)
+            } } \
+        if (SL && sliver && tid < sl_items) *reinterpret_cast<v4f*>(sl_buf((chunk_) & 1) + tid * 4) = slreg; } while (0)
 
     // A-operand row bases (floats) inside the halo tile
     int abase[M16];
@@ -385,8 +405,28 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     // 16-wide output-channel tiles are dealt round-robin to the WN waves (tile n of this wave = block tile n*WN + wn), so the
     // tiles that survive the Cout cut-off are balanced between the waves' MFMA pipes
     // number of this wave's tiles that contain a real channel: tiles n with (n*WN + wn)*16 < Cout - n0
-    int nvalid = ((a.n_end - n0 + 15) / 16 - wn + WN - 1) / WN;
-    nvalid = (a.n_end - n0 <= wn * 16) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    const int ntile_blk = sliver ? (a.n_end - n0) / 16 : (a.n_end - n0 + 15) / 16;        // 16-wide tiles of this block (sliver: full ones only)
+    int nvalid = (ntile_blk - wn + WN - 1) / WN;
+    nvalid = (ntile_blk <= wn) ? 0 : (nvalid > N16 ? N16 : nvalid);
+    // sliver operands: this lane's pixel (wave pixel index = lane) inside the halo tile, its channel's filter row, two accumulators
+    // (even / odd k: two independent chains of 8)
+    int sl_abase = 0;
+    {
+        const int pix = wm * (M16 * 16) + lane;
+        sl_abase = (((pix / TW) * S) * HW + (pix % TW) * S) * LDK;
+    }
+    f32x4 sacc0 = {0.f, 0.f, 0.f, 0.f}, sacc1 = {0.f, 0.f, 0.f, 0.f};
+#define SLIVER_STAGE() do { if (SL && slw) { \
+        const float* sa_ = hb + TAP_OFF(t) + sl_abase; \
+        const float* sb_ = sl_buf(chunk & 1) + t * 64 + (lane & 3) * 16; \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { \
+            const float4 xa_ = *reinterpret_cast<const float4*>(sa_ + 4 * q_); \
+            const float4 wb_ = *reinterpret_cast<const float4*>(sb_ + 4 * q_); \
+            sacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa_.x, wb_.x, sacc0, 0, 0, 0); \
+            sacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa_.y, wb_.y, sacc1, 0, 0, 0); \
+            sacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa_.z, wb_.z, sacc0, 0, 0, 0); \
+            sacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa_.w, wb_.w, sacc1, 0, 0, 0); \
+        } } } while (0)
     // operand B: uniform slab pointer + one 32-bit per-lane byte offset (tile n is n * WN * 16 columns = n * WN KiB further),
     // loaded unconditionally (the packed image is padded to the block's 128 columns) so every stage issues exactly N16 loads
     const unsigned lane_b = (unsigned)(((wn * 16 + l15) * KC + 4 * kq) * sizeof(float));
@@ -407,7 +447,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
     LOAD_HALO(0, true);
     LOAD_B(b0, ts.widx[0], 0);
-    wait_loads(b0, hreg);
+    WAIT_LOADS(b0);
     STORE_HALO(halo_buf(0), 0);
     __syncthreads();
 
@@ -450,7 +490,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
                 } \
             } \
         } \
-        wait_loads(bl_, hreg); \
+        SLIVER_STAGE(); \
+        WAIT_LOADS(bl_); \
     } while (0)
 #define STAGE(bu_, bl_, FULL_) do { \
         int tn_ = t + 1, cn_ = chunk; \
@@ -480,6 +521,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
         if (s + 1 < total) STAGE(b1, b0, false);
     }
 #undef STAGE_BODY
+#undef SLIVER_STAGE
+#undef WAIT_LOADS
 #undef TAP_OFF
 #undef TAP_WIDX
 #undef STAGE
@@ -573,6 +616,27 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
         }
     }
     // tiles skipped by this wave still owe zeros to the column-sum rows (their channels are >= Cout: nothing to write)
+    if (SL && slw) {
+        // sliver results: lane l = 4 blk + j holds pixels 4 blk + r (r = 0..3) of this wave's 64, channel j beyond the full tiles
+        const int cout = n0 + ntile_blk * 16 + (lane & 3);
+        const bool cvalid = cout < a.n_end;
+        const int cc = cvalid ? cout : 0;
+        const float bvv = (a.bias != nullptr && cvalid) ? a.bias[cout] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pix = wm * (M16 * 16) + (lane & ~3) + r;
+            const int ty = pix / TW, tx = pix % TW;
+            const int oyt = oy0 + ty, oxt = ox0 + tx;
+            const int oy = oyt * OS + ts.py, ox = oxt * OS + ts.px;
+            const bool pv = oyt < a.TSH && oxt < a.TSW && oy < a.OH && ox < a.OW;
+            const int pi = pv ? (oy * a.OW + ox) : 0;
+            float v = sacc0[r] + sacc1[r] + bvv;
+            if (resb != nullptr) v += resb[pi * a.res_cs + cc];
+            if (relu) v = fmaxf(v, 0.f);
+            if (maskb != nullptr) v = maskb[pi * a.mask_cs + cc] > 0.f ? v : 0.f;
+            if (cvalid && pv) yb[pi * a.y_cs + cout] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ packing
@@ -596,6 +660,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
             if (o < Cin && r < Cout) v = w[((size_t)r * Cin + o) * T + tap];
         }
         wp[i] = v;
+    }
+    // the sliver image behind it (conv_common.h, f32_sliver)
+    const int out_ = mode == 0 ? Cout : Cin;
+    if (unetconv::f32_sliver(out_)) {
+        const size_t nsl = (size_t)T * nchunks * 64;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nsl; i += (size_t)gridDim.x * blockDim.x)
+            wp[total + i] = unetconv::f32_sliver_value(w, Cout, Cin, T, mode, nchunks, i);
     }
 }
 
@@ -624,6 +695,17 @@ static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_p
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
 int launch_cfg(const Plan& p, hipStream_t st) {
+    if constexpr (MT == 2 && NT == 2 && WM == 2 && WN == 2 && HIT == 4) {
+        if (p.mf == 16 && p.k.sliver) {
+            auto kern = conv_igemm16_kernel<TW, MT, NT, WM, WN, HIT, true>;
+            static unsigned long long configured = 0;  // per instantiation, one bit per device
+            if (unet::first_use_on_device(&configured))
+                UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(kern, p.grid, dim3(WM * WN * 64), p.lds_bytes, st, p.k);
+            UNET_CHECK_LAUNCH();
+            return UNET_OK;
+        }
+    }
     if (p.mf == 16) {
         auto kern = conv_igemm16_kernel<TW, MT, NT, WM, WN, HIT>;
         static unsigned long long configured = 0;  // per instantiation, one bit per device
@@ -701,7 +783,7 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
 extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;
     const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
-    return (size_t)T * unet::cdiv(red, KC) * unet::roundup(out, 128) * KC;
+    return unetconv::f32_image_elems(red, out, T);
 }
 
 extern "C" int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream) {

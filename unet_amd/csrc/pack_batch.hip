@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
     const Job j = jobs[lo];
     const int KC = bf16 ? 32 : 16, sh = bf16 ? 5 : 4;
     const int red = j.mode == 0 ? j.Cin : j.Cout;
-    const size_t total = bf16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : (size_t)j.T * j.nchunks * j.outPad * KC;
+    const int out = j.mode == 0 ? j.Cout : j.Cin;
+    const size_t main_f32 = (size_t)j.T * j.nchunks * j.outPad * KC;
+    const size_t total = bf16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : unetconv::f32_image_elems(red, out, j.T);
     const size_t base = (size_t)(blockIdx.x - j.block_begin) * ELEMS_PER_BLOCK;
 #pragma unroll
     for (int k = 0; k < ELEMS_PER_BLOCK / 256; ++k) {
@@ -41,6 +43,10 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
         if (bf16) {
             reinterpret_cast<unsigned short*>(j.wp)[i] =
                 __builtin_bit_cast(unsigned short, (__bf16)unetconv::bf16_image_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, j.outPad, i));
+            continue;
+        }
+        if (i >= main_f32) {          // the fp32 sliver image behind the main one
+            reinterpret_cast<float*>(j.wp)[i] = unetconv::f32_sliver_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, i - main_f32);
             continue;
         }
         const int rr = (int)(i & (KC - 1));
@@ -79,7 +85,7 @@ extern "C" int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int d
         j.w = s.w; j.wp = s.wp; j.Cout = s.Cout; j.Cin = s.Cin; j.T = s.ks * s.ks; j.mode = s.mode;
         j.nchunks = unet::cdiv(red, KC); j.outPad = unet::roundup(out, 128);
         j.block_begin = (unsigned)blocks; j.pad_ = 0;
-        const size_t total = dtype == UNET_BF16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : (size_t)j.T * j.nchunks * j.outPad * KC;
+        const size_t total = dtype == UNET_BF16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : unetconv::f32_image_elems(red, out, j.T);
         blocks += (total + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK;
         UNET_CHECK_ARG(blocks < (1ull << 31), "pack_batch_build: too many blocks");
     }
