@@ -207,8 +207,8 @@ def main():
         if args.dtype == "f32":
             achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
-                                                   "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> = 42 "
-                                                   "launches / step and <...,true> = the 3 launches / step whose last 4 of 100 output channels "
+                                                   "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> = 41 "
+                                                   "launches / step and <...,true> = the 4 launches / step whose last 4 of 100 output channels "
                                                    "run on v_mfma_4x4x1)",
                         "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_F32_TFLOPS, 4),
