@@ -18,10 +18,18 @@
 // (reference train.py:247-250 -> loss.backward()).
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -73,33 +81,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     // multiplied and stored behind it: the loads of a tile are a full L2 / HBM round trip that only the co-resident workgroup used to
     // cover (MFMA pipe busy 81 %).
     float4 rd[DIT], rx[XIT];
-    auto load_tile = [&](int tile) {
+    // tile position (uniform) and ONE item of it (compile-time index): the in-loop prefetch issues its DIT + XIT loads one by one
+    // between groups of MFMA steps instead of as a block in front of them -- measured by switching the in-loop loads off, the block
+    // cost 10-12 % (256 -> 256 at 16 x 128^2: 2.64 ms, 2.33 without), although the data has a whole tile's MFMAs to arrive: a wave
+    // issues in order, and thirteen address computations + vector-memory issues in a row are thirteen gaps in its MFMA stream.
+    struct TPos { int oy0, ox0; const float* dyb; const float* xb; };
+    auto tile_pos = [&](int tile) {
         int b = tile;
+        TPos t;
         const int tx = b % a.tiles_x; b /= a.tiles_x;
         const int ty = b % a.tiles_y;
         const int img = b / a.tiles_y;
-        const int oy0 = ty * PTH, ox0 = tx * PTW;
-        const float* dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
-        const float* xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
-#pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            const int e = tid + it * 256;
+        t.oy0 = ty * PTH; t.ox0 = tx * PTW;
+        t.dyb = a.dy + (size_t)img * a.OH * a.OW * a.dy_cs;
+        t.xb = a.x + (size_t)img * a.IH * a.IW * a.x_cs;
+        return t;
+    };
+    auto load_item = [&](const TPos& t, auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < DIT) {
+            const int e = tid + I * 256;
             const int p = e >> 4, q = e & 15;
-            const int oy = oy0 + p / PTW, ox = ox0 + p % PTW;
+            const int oy = t.oy0 + p / PTW, ox = t.ox0 + p % PTW;
             const bool ok = (e < PT * 16) && oy < a.OH && ox < a.OW && (k0 + 4 * q) < a.Cout4;
-            rd[it] = ok ? *reinterpret_cast<const float4*>(dyb + ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-#pragma unroll
-        for (int j = 0; j < XIT; ++j) {
-            const int e = tid + j * 256;
+            // (unconditional load from a clamped address + select: a conditional load is an exec-mask branch around it)
+            const float4 v = *reinterpret_cast<const float4*>(t.dyb + (ok ? ((size_t)oy * a.OW + ox) * a.dy_cs + a.dy_co + k0 + 4 * q : (size_t)0));
+            rd[I] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if constexpr (I < DIT + XIT) {
+            constexpr int J = I - DIT;
+            const int e = tid + J * 256;
             const int p = e >> 4, q = e & 15;
-            const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+            const int iy = t.oy0 * S - PAD + p / HW, ix = t.ox0 * S - PAD + p % HW;
             const bool ok = (e < HPIX * 16) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && (c0 + 4 * q) < a.Cin4;
-            rx[j] = ok ? *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4*>(t.xb + (ok ? ((size_t)iy * a.IW + ix) * a.x_cs + a.x_co + c0 + 4 * q : (size_t)0));
+            rx[J] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto load_tile = [&](int tile) {          // all items at once (the first tile of the workgroup)
+        const TPos t = tile_pos(tile);
+        static_for<DIT + XIT>([&](auto i) { load_item(t, i); });
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -128,25 +148,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
-        if (has_next) load_tile(tile + 1);
+        const TPos nx = tile_pos(has_next ? tile + 1 : tile);
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < PT; ++p) bsum += dyT[p * BK + tid];
         }
-        // (a full unroll hoists operand reads until the register file is full; the prefetched tile needs DIT + XIT float4 of it)
-#pragma unroll 4
-        for (int step = 0; step < PT / 2; ++step) {
-            // pixel 2*step + h ; 2*step is even and PTW is even, so px = (2*step % PTW) + h, py = 2*step / PTW
-            const int py = (2 * step) / PTW, px = (2 * step) % PTW;
-            const float av = abase[(2 * step) * BK];
+        // PT / 2 MFMA steps in groups of GS; in front of group g the prefetch items g * IPG .. are issued (scheduling barriers keep the
+        // groups apart: a full unroll would otherwise hoist operand reads until the register file is full)
+        constexpr int NG = 8, GS = (PT / 2) / NG, NIT = DIT + XIT, IPG = (NIT + NG - 1) / NG;
+        static_assert((PT / 2) % NG == 0, "step groups");
+        static_for<NG>([&](auto g) {
+            constexpr int G = decltype(g)::value;
+            if (has_next) static_for<IPG>([&](auto kk) { load_item(nx, std::integral_constant<int, G * IPG + decltype(kk)::value>{}); });
 #pragma unroll
-            for (int r = 0; r < KS; ++r)
+            for (int sg = 0; sg < GS; ++sg) {
+                const int step = G * GS + sg;
+                // pixel 2*step + h ; 2*step is even and PTW is even, so px = (2*step % PTW) + h, py = 2*step / PTW
+                const int py = (2 * step) / PTW, px = (2 * step) % PTW;
+                const float av = abase[(2 * step) * BK];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const float bv = bbase[((py * S + r) * HW + px * S + s) * BC];
-                    acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KS + s], 0, 0, 0);
-                }
-        }
+                for (int r = 0; r < KS; ++r)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float bv = bbase[((py * S + r) * HW + px * S + s) * BC];
+                        acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KS + s], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         __syncthreads();                  // every wave is done reading this tile
         if (has_next) store_tile();
         __syncthreads();
