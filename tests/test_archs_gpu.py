@@ -75,3 +75,4 @@ def test_train_step_gradients_smooth(arch, n_in, n_out, size, bs):
             worst = (n, e)
     print("smooth worst", worst)
     assert worst[1] < 2e-3, worst
+

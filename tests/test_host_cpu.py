@@ -210,3 +210,12 @@ def test_bench_starts_its_own_ranks_and_rejects_a_mismatched_world(tmp_path, mon
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], env=dict(__import__("os").environ, WORLD_SIZE="2"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+def test_deep_encoder_with_self_attention_is_refused_loudly():
+    """fastai would put SelfAttention(432) on UnetBlock 3 of xresnet34_deep; the device program needs a multiple of 32 channels
+    (the fused QKV buffer is cut into channel slices) and says so at construction instead of computing something else."""
+    from unet_amd.model import HipDynamicUnet
+    with pytest.raises(ValueError, match="divisible by 32"):
+        HipDynamicUnet("xresnet34_deep", 3, 3, (256, 256), self_attention=True, device="cpu")
+    HipDynamicUnet("xresnet34", 3, 3, (64, 64), self_attention=True, device="cpu")        # the shipped configuration is fine

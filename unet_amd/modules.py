@@ -541,7 +541,9 @@ class SelfAttention(nn.Module):
         self.value = nn.Sequential(nn.utils.spectral_norm(nn.Conv1d(n_channels, n_channels, 1, bias=False)))
         self.gamma = nn.Parameter(torch.tensor([0.0]))
         self.C, self.c8 = n_channels, c8
-        assert c8 % 4 == 0, "self-attention needs n_channels divisible by 32"
+        if c8 % 4 != 0:      # the query / key slices of the fused QKV buffer are channel slices: multiples of the 4-channel vector
+            raise ValueError(f"self-attention on {n_channels} channels: the device program needs n_channels divisible by 32 "
+                             f"(xresnet18/34/50/101 decoders: 384 / 1536; xresnet34_deep's attention block has 432)")
 
     @staticmethod
     def _normed_weight(seq: nn.Sequential) -> torch.Tensor:
