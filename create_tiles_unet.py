@@ -14,22 +14,16 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
+from unet_amd.mosaic import window_offsets
 from unet_amd.tiffio import read_tiff, write_tiff
 
 
-def _offsets(length: int, size: int, step: int) -> List[int]:
-    offs = list(range(0, length - size + 1, step))
-    if offs[-1] + size < length:
-        offs.append(length - size)
-    return offs
-
-
 def compute_windows(height: int, width: int, patch_size: int, patch_overlap: float) -> List[Tuple[int, int, int, int]]:
-    """[(x, y, w, h)] windows over a height x width raster."""
+    """[(x, y, w, h)] windows over a height x width raster (the rule itself: unet_amd.mosaic.sliding_windows, shared with predict_raster)."""
     if patch_overlap > 1:
         raise ValueError(f"Patch overlap {patch_overlap} must be between 0 - 1")
     step = patch_size - int(patch_size * patch_overlap)
-    return [(x, y, patch_size, patch_size) for y in _offsets(height, patch_size, step) for x in _offsets(width, patch_size, step)]
+    return [(x, y, patch_size, patch_size) for y in window_offsets(height, patch_size, step) for x in window_offsets(width, patch_size, step)]
 
 
 def create_train_test_split(path, split=None, seed: Optional[int] = None):

@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 2
+#define UNET_ABI_VERSION 3
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -284,6 +284,40 @@ int unet_adam_step_dev(float* p, const float* g, float* m, float* v, const uint8
 int unet_mosaic_accumulate(const float* probs_nchw, int C, int th, int tw, float* mosaic /*[C,MH,MW]*/,
                            int32_t* count /*[MH,MW]*/, int MH, int MW, int y0, int x0, void* stream);
 int unet_mosaic_finalize(float* mosaic, const int32_t* count, int C, int MH, int MW, uint8_t* argmax, void* stream);
+
+/* --------------------------------------- sliding-window predict over a raster --
+ * BASELINE.json configs[4]: the raster stays in HBM as the integers it was read as; windows are cut, scaled and merged on the device.
+ * Replaces, with identical results, the host round trip create_tiles_unet.split_raster (create_tiles_unet.py:252-434) -> tile files
+ * -> predict.save_predictions(merge=True) (predict.py:191-222, 257-334).
+ * A source is band-sequential: sample (band c, row y, column x) of source s is src[s * src_stride + c * band_stride + y * row_stride + x].
+ * A window table is int32 [n][4] on the device: {y0, x0, source index, unused}. */
+#define UNET_RASTER_U8 0
+#define UNET_RASTER_U16 1
+#define UNET_RASTER_I16 2
+#define UNET_RASTER_I32 3
+#define UNET_RASTER_F32 4          /* cast through int32 like every tile the reference opens (data.py:24) */
+/* create_tiles_unet.py:344-352: every band of a pixel becomes 0 where ANY band equals the raster's nodata value (in place) */
+int unet_raster_nodata_zero(void* raster, int rtype, int bands, long long pixels, double nodata, void* stream);
+/* create_tiles_unet.py:379: counts[j] = number of non-zero samples (all bands) of window j; the host drops windows with
+ * counts[j] < bands * th * tw * (1 - max_empty) */
+int unet_window_nonzero(const void* raster, int rtype, int bands, long long band_stride, int row_stride, const int32_t* windows, int n,
+                        int th, int tw, unsigned long long* counts, void* stream);
+/* x[j, y, x, x_co + c] = float(int32(sample)) / 255 (and / 255 once more when div255_twice: the reference's int16 rasters, utils.py:248-249
+ * + IntToFloatTensor); x is an NHWC activation buffer [n, th, tw, x_cs] of storage type dtype (UNET_F32 | UNET_BF16).  Equals
+ * open_npy + the transform + unet_nchw_to_nhwc of the same window bit for bit. */
+int unet_window_gather(const void* src, int rtype, int bands, long long src_stride, long long band_stride, int row_stride,
+                       const int32_t* windows, int n, int th, int tw, int div255_twice, void* x, int x_cs, int x_co, int dtype, void* stream);
+/* predict.py:193-203 + 284-292 for a batch: window j's softmax probabilities (mode 0; the arithmetic of unet_softmax_argmax) or raw
+ * values (mode 1, regression) of the fp32 NHWC logits z [n, th, tw, z_cs] are added to mosaic [C, MH, MW] at (y0 - origin_y,
+ * x0 - origin_x) and the hit counter is incremented; only mosaic rows [row_lo, row_hi) are touched.  Contributions to one pixel are
+ * added in window order (stream order across calls), so the result equals n successive unet_mosaic_accumulate calls bit for bit. */
+int unet_mosaic_accumulate_windows(const float* z, int z_cs, int z_co, int C, int th, int tw, const int32_t* windows, int n, int origin_y,
+                                   int origin_x, int mode, float* mosaic, int32_t* count, int MH, int MW, int row_lo, int row_hi,
+                                   void* stream);
+/* predict.py:306-334 on rows [row0, row0 + nrows): mosaic /= count where count > 0 (in place); argmax (uint8 [nrows, MW], may be NULL);
+ * fill_host != NULL: pixels without a hit become *fill_host (regression nodata -9999, predict.py:312-315) */
+int unet_mosaic_finalize_rows(float* mosaic, const int32_t* count, int C, int MH, int MW, int row0, int nrows, uint8_t* argmax,
+                              const float* fill_host, void* stream);
 
 /* ---------------------------------------------------- bf16-storage twins --
  * The HBM-bound kernels of the step with bf16 activation / gradient tensors (per-channel vectors, statistics, indices, losses stay

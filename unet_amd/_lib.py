@@ -142,6 +142,11 @@ _sig = {
     "unet_adam_step_dev": (i, [vp, vp, vp, vp, vp, ll, vp, vp]),
     "unet_mosaic_accumulate": (i, [vp, i, i, i, vp, vp, i, i, i, i, vp]),
     "unet_mosaic_finalize": (i, [vp, vp, i, i, i, vp, vp]),
+    "unet_raster_nodata_zero": (i, [vp, i, i, ll, C.c_double, vp]),
+    "unet_window_nonzero": (i, [vp, i, i, ll, i, vp, i, i, i, vp, vp]),
+    "unet_window_gather": (i, [vp, i, i, ll, ll, i, vp, i, i, i, i, vp, i, i, i, vp]),
+    "unet_mosaic_accumulate_windows": (i, [vp, i, i, i, i, i, vp, i, i, i, i, vp, vp, i, i, i, i, vp]),
+    "unet_mosaic_finalize_rows": (i, [vp, vp, i, i, i, i, i, vp, c_float_p, vp]),
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
@@ -159,7 +164,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 2:
+if lib.unet_abi_version() != 3:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 

@@ -762,7 +762,8 @@ class Learner:
         meta = {"arch": m.arch, "n_in": m.n_in, "n_out": m.n_out, "img_size": list(m.img_size), "vocab": self.dls.vocab,
                 "dtype": self.dls.train_ds.dtype if self.dls is not None else "int8",
                 "class_weights": None if w is None else [float(v) for v in torch.as_tensor(w).cpu()],
-                "regression": self.loss_func.kind if self.regression else None}
+                "regression": self.loss_func.kind if self.regression else None,
+                "self_attention": bool(getattr(m, "self_attention", False)), "act_dtype": getattr(m, "act_dtype", "f32")}
         p = Path(fname)
         p = p if p.is_absolute() else self.path / p
         if self.rank == 0:
@@ -783,10 +784,16 @@ class Learner_adjust(Learner):
     """train.py:87-95: the regression Learner (predict returns the 2-tuple); the behaviour lives in Learner.predict."""
 
 
-def load_learner(fname, device="cuda") -> Learner:
+def load_learner(fname, device="cuda", act_dtype: Optional[str] = None) -> Learner:
+    """learner of an exported model file.  act_dtype None = the storage mode the model was exported with ("f32" for files written before
+    the mode was recorded); self-attention is rebuilt when the file says so or, for such older files, when the state dict holds its keys."""
     d = torch.load(fname, map_location="cpu")
     meta = d["meta"]
-    model = HipDynamicUnet(meta["arch"], meta["n_in"], meta["n_out"], tuple(meta["img_size"]), device=device)
+    sa = meta.get("self_attention")
+    if sa is None:
+        sa = any(".query." in k for k in d["model"])
+    model = HipDynamicUnet(meta["arch"], meta["n_in"], meta["n_out"], tuple(meta["img_size"]), self_attention=bool(sa), device=device,
+                           act_dtype=act_dtype or meta.get("act_dtype", "f32"))
     model.load_state_dict(d["model"])
     empty = TileDataset([], None, meta.get("dtype", "int8"))
     dls = DataLoaders(empty, None, 1, device=device, vocab=meta.get("vocab"))

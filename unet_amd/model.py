@@ -51,6 +51,7 @@ class HipDynamicUnet(nn.Module):
         if act_dtype == "bf16" and self_attention:
             raise ValueError("self-attention is only available on the fp32 path")
         self.act_dtype = act_dtype
+        self.self_attention = bool(self_attention)
         self.arch, self.n_in, self.n_out = arch, n_in, n_out
         self.img_size = tuple(img_size)
         enc = Encoder(arch, n_in)
@@ -205,18 +206,24 @@ class HipDynamicUnet(nn.Module):
     # ------------------------------------------------------------------ programs
     def _hip_forward(self, x: torch.Tensor, training: bool) -> TS:
         """x: [B, n_in, H, W] fp32 (device).  Returns the logits slice (NHWC)."""
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.n_in, x.shape
-        if self.act_dtype == "bf16" and (x.shape[2] % 32 or x.shape[3] % 32):
+        if isinstance(x, ops.WindowBatch):      # windows of an integer raster / staged tiles: cut + scaled on the device (predict_raster)
+            assert x.src.C == self.n_in, (x.src.C, self.n_in)
+            N, H, W = x.n, x.th, x.tw
+            put = x.write
+        else:
+            assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.n_in, x.shape
+            x = x.contiguous()
+            N, _, H, W = x.shape
+            put = lambda buf, at, _x=x: ops.nchw_to_nhwc(_x, ops.TS(buf, 0, buf.shape[3]), at=at)
+        if self.act_dtype == "bf16" and (H % 32 or W % 32):
             raise ValueError("bf16 storage mode needs tile sides divisible by 32 (no nearest-resize kernels in bf16)")
-        x = x.contiguous()
         ctx = self.ctx
         ctx.training = training
         self._pack_all(training and ctx.need_grad)
-        N, _, H, W = x.shape
         L = self.layers
         enc: Encoder = L[0]
         x0 = ctx.act(self, "x0", N, H, W, self.n_in, zero=True)
-        ops.nchw_to_nhwc(x, x0)
+        put(x0.buf, 0)
         skips: Dict[int, TS] = {}
         h = x0
         for i, child in enumerate(enc):
@@ -251,7 +258,7 @@ class HipDynamicUnet(nn.Module):
         nb = 4 + len(self.sz_chg_idxs)
         X = ctx.act(self, "xcat", N, H, W, self.cat_c, zero=True)
         L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
-        ops.nchw_to_nhwc(x, X, at=self.up_c)        # after the shuffle: a ragged up_c leaves its pad lanes inside these channels
+        put(X.buf, self.up_c)                       # after the shuffle: a ragged up_c leaves its pad lanes inside these channels
         o = L[nb + 3].hip_fwd(ctx, X)
         z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True, dtype=torch.float32)      # logits are fp32 in both modes
         head: ConvLayer = L[nb + 4]
@@ -440,6 +447,11 @@ class HipDynamicUnet(nn.Module):
         amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=self._device) if want_argmax else None
         ops.softmax_argmax(z, probs, amax)
         return probs, amax
+
+    @torch.no_grad()
+    def forward_windows(self, wb: "ops.WindowBatch") -> TS:
+        """eval-mode forward of a batch of raster windows; returns the fp32 NHWC logits slice (valid until the next forward)"""
+        return self._hip_forward(wb, False)
 
     def memory_bytes(self) -> int:
         return self.ctx.bytes_allocated() + 2 * self.flat_param.numel() * 4

@@ -463,3 +463,87 @@ def mosaic_accumulate(probs: torch.Tensor, mosaic: torch.Tensor, count: torch.Te
 def mosaic_finalize(mosaic: torch.Tensor, count: torch.Tensor, amax: Optional[torch.Tensor]):
     Cc, MH, MW = mosaic.shape
     check(lib.unet_mosaic_finalize(mosaic.data_ptr(), count.data_ptr(), Cc, MH, MW, _p(amax), _stream()), "mosaic_finalize")
+
+
+# ------------------------------------------------------------------ sliding-window predict over an integer raster (csrc/raster.hip)
+
+RASTER_TYPES = {torch.uint8: 0, torch.uint16: 1, torch.int16: 2, torch.int32: 3, torch.float32: 4}
+
+
+class WindowSource:
+    """Band-sequential integer (or float) samples on the device that windows are cut from: ONE raster [C, H, W] (``src_stride`` 0) or a
+    batch of staged tiles [n, C, h, w].  Sample (source s, band c, row y, column x) = data[s, c, y, x]."""
+
+    def __init__(self, data: torch.Tensor, div255_twice: bool = False):
+        assert data.is_cuda and data.is_contiguous() and data.dim() in (3, 4) and data.dtype in RASTER_TYPES, (data.shape, data.dtype)
+        self.data, self.rtype, self.div2 = data, RASTER_TYPES[data.dtype], int(bool(div255_twice))
+        self.C, self.H, self.W = data.shape[-3:]
+        self.src_stride = 0 if data.dim() == 3 else self.C * self.H * self.W
+
+
+def window_table(rows, device) -> torch.Tensor:
+    """int32 [n, 4] device table of (y0, x0, source index, 0)"""
+    t = torch.zeros((len(rows), 4), dtype=torch.int32)
+    if len(rows):
+        a = torch.as_tensor(rows, dtype=torch.int32)
+        t[:, :a.shape[1]] = a
+    return t.to(device)
+
+
+@dataclass
+class WindowBatch:
+    """windows [first, first + n) of a device window table over a WindowSource: an input batch of the network that is never
+    materialised as an NCHW fp32 tensor -- HipDynamicUnet writes it straight into its NHWC input buffers (window_gather)"""
+    src: WindowSource
+    table: torch.Tensor
+    first: int
+    n: int
+    th: int
+    tw: int
+
+    def write(self, dst_buf: torch.Tensor, at: int):
+        window_gather(self.src, self.table, self.first, self.n, self.th, self.tw, dst_buf, at)
+
+
+def raster_nodata_zero(src: WindowSource, nodata: float):
+    assert src.data.dim() == 3
+    check(lib.unet_raster_nodata_zero(src.data.data_ptr(), src.rtype, src.C, src.H * src.W, float(nodata), _stream()), "raster_nodata_zero")
+
+
+def window_nonzero(src: WindowSource, table: torch.Tensor, th: int, tw: int) -> torch.Tensor:
+    """int64 [n]: non-zero samples of every window (all bands)"""
+    n = table.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=table.device)
+    if n:
+        check(lib.unet_window_nonzero(src.data.data_ptr(), src.rtype, src.C, src.H * src.W, src.W, table.data_ptr(), n, th, tw,
+                                      out.data_ptr(), _stream()), "window_nonzero")
+    return out
+
+
+def window_gather(src: WindowSource, table: torch.Tensor, first: int, n: int, th: int, tw: int, dst_buf: torch.Tensor, at: int):
+    """windows [first, first + n) of the table -> channels [at, at + C) of the NHWC buffer dst_buf [>= n, th, tw, cs], scaled"""
+    assert dst_buf.dim() == 4 and dst_buf.shape[0] >= n and tuple(dst_buf.shape[1:3]) == (th, tw) and dst_buf.is_contiguous()
+    assert 0 <= first and first + n <= table.shape[0]
+    dt = L.BF16 if dst_buf.dtype == torch.bfloat16 else L.F32
+    check(lib.unet_window_gather(src.data.data_ptr(), src.rtype, src.C, src.src_stride, src.H * src.W, src.W,
+                                 table.data_ptr() + 16 * first, n, th, tw, src.div2, dst_buf.data_ptr(), dst_buf.shape[3], at, dt,
+                                 _stream()), "window_gather")
+
+
+def mosaic_accumulate_windows(z: TS, table: torch.Tensor, first: int, n: int, origin, mosaic: torch.Tensor, count: torch.Tensor,
+                              row_lo: int, row_hi: int, raw: bool = False):
+    """softmax (or, raw=True, the values themselves) of the fp32 NHWC logits of windows [first, first + n) added into mosaic / count"""
+    _need_f32("mosaic_accumulate_windows", z)
+    Cc, MH, MW = mosaic.shape
+    assert z.N >= n and Cc == z.C and count.shape == (MH, MW) and count.dtype == torch.int32 and mosaic.dtype == torch.float32
+    check(lib.unet_mosaic_accumulate_windows(z.ptr, z.cs, z.co, z.C, z.H, z.W, table.data_ptr() + 16 * first, n, int(origin[0]),
+                                             int(origin[1]), int(raw), mosaic.data_ptr(), count.data_ptr(), MH, MW, int(row_lo), int(row_hi),
+                                             _stream()), "mosaic_accumulate_windows")
+
+
+def mosaic_finalize_rows(mosaic: torch.Tensor, count: torch.Tensor, row0: int, nrows: int, amax: Optional[torch.Tensor], fill=None):
+    Cc, MH, MW = mosaic.shape
+    assert amax is None or (amax.dtype == torch.uint8 and amax.numel() >= nrows * MW)
+    fp = None if fill is None else C.byref(C.c_float(float(fill)))
+    check(lib.unet_mosaic_finalize_rows(mosaic.data_ptr(), count.data_ptr(), Cc, MH, MW, row0, nrows, _p(amax),
+                                        None if fp is None else C.cast(fp, L.c_float_p), _stream()), "mosaic_finalize_rows")
