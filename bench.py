@@ -8,7 +8,10 @@ Prints ONE JSON line on rank 0.  `value` = tiles processed by all ranks / wall t
 ranks), inputs resident in HBM.  `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv,
 all launches of its main instantiation: forward and input-gradient of every wide layer): summed algorithmic FLOPs /
 summed launch durations measured with events on the launch stream inside the timed region.  `cpu_baseline` = the torch-CPU oracle of the same step
-on this host's cores, on a bounded sample (rank 0, N=1 only).
+on this host's cores, on a bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`: the other BASELINE configurations measured
+in the same process after the headline -- the bf16-storage variant of configs[1] (with its own roofline object), predict at batch 16 / 1,
+configs[0] (cfg1) and configs[4] (cfg5: predict.predict_raster over a 20000 x 20000 raster) in fp32 and bf16 storage.  Every rank reports its own
+clock and the time its compute stream waited for the gradient all-reduce in `devices`.
 """
 from __future__ import annotations
 
@@ -25,7 +28,9 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 GFLOP_PER_TILE_FWD_BWD = 767.388      # BASELINE.md section 2 (conv MACs x 2, cfg2)
+GFLOP_PER_TILE_FWD = 255.846          # forward only (predict, cfg5)
 PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 matrix == vector peak
+PEAK_BF16_TFLOPS = 2500.0             # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 TB/s achievable by a streaming copy)
 ARCH, N_IN, N_CLS, SIZE = "xresnet34", 4, 5, 512
 
@@ -112,6 +117,130 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world, dev, log, probe=True, use_graph=False):
+    """K timed fwd + weighted-CE + bwd + fastai-Adam steps on `batch` synthetic tiles per GPU.  Returns the measurements of this rank
+    (wall time of the K steps bracketed by barrier + synchronize, dominant-kernel probe, time the compute stream waited for the gradient
+    all-reduce)."""
+    from unet_amd import ops as _ops
+    from unet_amd.distributed import broadcast_parameters
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    import torch.distributed as dist
+    torch.manual_seed(0)
+    model = HipDynamicUnet(arch, n_in, n_cls, (size, size), device=dev, act_dtype=dtype)
+    broadcast_parameters(model.flat_param, list(model.buffers()))
+    model.mark_weights_dirty()
+    model.train()
+    lr, enc_factor = 1e-4, 10.0        # params_and_main.py:53,84 defaults
+    opt = FlatAdam(model, [lr / enc_factor, lr / enc_factor ** 0.5, lr])
+    weights = torch.full((n_cls,), 1.0 / n_cls, device=dev)   # CLASS_WEIGHTS "even" (train.py:338-339)
+    step = TrainStep(model, opt, weights, world, use_graph=use_graph)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = (torch.randint(0, 256, (batch, n_in, size, size), generator=g).float() / 255).to(dev)
+    y = torch.randint(0, n_cls, (batch, size, size), generator=g).to(dev)
+    log(f"{arch} {n_in}x{size}x{size} -> {n_cls} classes, {dtype}: {sum(p.numel() for p in model.parameters())} params, batch {batch}/gpu, world {world}")
+    for i in range(warmup):
+        step(x, y)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # fp32: conv_igemm16_kernel<32,2,2,2,2,4> (all wide 3x3 / 1x1 convs, fwd and dgrad); bf16: conv_bf16_kernel<32,4,2,2,2,6> (the 256-pixel tile)
+    pr = None
+    if probe:
+        _ops.CONV_PROBE = pr = _ops.ConvProbe(32 * 10000 + 128 * 10 + (0 if dtype == "f32" else 7))
+    step.comm_events = [] if world > 1 else None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, y)
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _ops.CONV_PROBE = None
+    wait_ms = None
+    if step.comm_events:
+        wait_ms = sum(a.elapsed_time(b) for a, b in step.comm_events) / steps
+    out = {"dt": dt, "t_local": t_local, "loss": float(loss.item()), "probe": None if pr is None else pr.summary(),
+           "mem": model.memory_bytes(), "allreduce_wait_ms": wait_ms}
+    del step, opt, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline_of(ps, dtype, dt, steps, pmc):
+    """dominant kernel over ALL its launches in the timed region: algorithmic FLOPs (fp32: MFMA roofline) or algorithmic bytes (bf16
+    storage: HBM roofline) / summed launch durations (events on the launch stream)"""
+    common = {"launches_per_step": ps["launches"] // max(1, steps), "avg_launch_ms": round(ps["avg_ms"], 4),
+              "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
+              "avg_launch_alg_bytes": int(ps["bytes"] / max(1, ps["launches"])),
+              "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)}
+    if dtype == "f32":
+        achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
+                                           "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> and "
+                                           "<...,true> = the launches whose last 4 of 100 output channels run on v_mfma_4x4x1)",
+                "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
+                "traffic": pmc.get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"), **common}
+    achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "conv_bf16_kernel<32,4,2,2,2,6> (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM: every wide "
+                                      "3x3/1x1 conv, forward and input-gradient); algorithmic bytes = every operand tensor once in, the "
+                                      "result once out, the packed filter once",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
+            "traffic": pmc.get("conv_bf16_kernel<32,4,2,2,2,6>", {}).get("hbm_bytes_per_launch"),
+            "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1),
+            "mfma_frac_of_bf16_peak": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), **common}
+
+
+def predict_bench(dtype, batch, dev, iters=6):
+    """eval forward + softmax + argmax (what learn.predict computes per tile, predict.py:193-203,232) on `batch` cfg2 tiles"""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(0)
+    m = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=dtype)
+    m.eval()
+    x, _ = synth(batch, 1, dev)
+    for _ in range(3):
+        m.predict_probs(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        m.predict_probs(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    del m
+    torch.cuda.empty_cache()
+    return {"value": round(batch / dt, 1), "unit": "tiles/s", "ms_per_batch": round(dt * 1e3, 3), "dtype": dtype, "batch": batch,
+            "fwd_tflops": round(batch / dt * GFLOP_PER_TILE_FWD / 1e3, 1)}
+
+
+def cfg5_bench(dtype, dev, side=20000, size=512, overlap=0.2, batch=16):
+    """BASELINE configs[4] on this GPU through the product entry point predict.predict_raster: uint8 raster resident in HBM, windows
+    cut + scaled on the device, batched forward, softmax + overlap merge in window order, argmax; only the uint8 mask reaches the host"""
+    import predict as P
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(0)
+    m = HipDynamicUnet(ARCH, N_IN, N_CLS, (size, size), device=dev, act_dtype=dtype)
+    m.eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    raster = torch.randint(1, 256, (N_IN, side, side), dtype=torch.uint8, device=dev, generator=g)
+    P.predict_raster(m, raster[:, :2 * size, :4 * size].contiguous(), size, overlap, batch_size=batch)      # warm-up: buffers, packed filters
+    tm = {}
+    out = P.predict_raster(m, raster, size, overlap, batch_size=batch, timing=tm)
+    r = {"value": round(tm["windows"] / tm["seconds"], 1), "unit": "tiles/s", "seconds": round(tm["seconds"], 3), "windows": tm["windows"],
+         "dtype": dtype, "raster": [N_IN, side, side], "window": size, "overlap": overlap, "batch": batch,
+         "hits_min": tm["hits_min"], "hits_max": tm["hits_max"], "mask_shape": list(out.shape),
+         "fwd_tflops": round(tm["windows"] / tm["seconds"] * GFLOP_PER_TILE_FWD / 1e3, 1),
+         "what": "predict.predict_raster end to end incl. the 400 MB uint8 mask device -> host"}
+    del m, raster, out
+    torch.cuda.empty_cache()
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +248,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (bf16 step, predict, cfg1, cfg5) of the N=1 run")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (default): the parity path, the headline.  bf16: bf16 storage / fp32 accumulate variant of configs[1]")
     args = ap.parse_args()
@@ -130,64 +260,33 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or run "
                          f"`python bench.py --gpus {args.gpus}` without WORLD_SIZE set and let it start the ranks itself")
-    from unet_amd.distributed import broadcast_parameters, init_from_env
+    from unet_amd.distributed import init_from_env
     rank, local_rank, world = init_from_env()
     if os.environ.get("UNET_FORCE_DEVICE") is not None:      # rehearsal of the N>1 path on a single GPU (with UNET_DIST_BACKEND=gloo)
         local_rank = int(os.environ["UNET_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-
-    from unet_amd.model import HipDynamicUnet
-    from unet_amd.optimizer import FlatAdam
-    from unet_amd.trainer import TrainStep
     import torch.distributed as dist
-
-    torch.manual_seed(0)
-    model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=args.dtype)
-    broadcast_parameters(model.flat_param, list(model.buffers()))
-    model.mark_weights_dirty()
-    model.train()
-    lr, enc_factor = 1e-4, 10.0        # params_and_main.py:53,84 defaults
-    lrs = [lr / enc_factor, lr / enc_factor ** 0.5, lr]
-    opt = FlatAdam(model, lrs)
-    weights = torch.full((N_CLS,), 1.0 / N_CLS, device=dev)   # CLASS_WEIGHTS "even" (train.py:338-339)
-    step = TrainStep(model, opt, weights, world)
-    x, y = synth(args.batch, 1234 + rank, dev)
 
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    from unet_amd import ops as _ops
-    # fp32: conv_igemm16_kernel<32,2,2,2,2,4> (all wide 3x3 / 1x1 convs, fwd and dgrad); bf16: conv_bf16_kernel<32,4,2,2,2,6> (the 256-pixel tile)
-    DOMINANT = 32 * 10000 + 128 * 10 + (0 if args.dtype == "f32" else 7)
-    log(f"model ready: {sum(p.numel() for p in model.parameters())} params, batch {args.batch}/gpu, world {world}")
-    for i in range(args.warmup):
-        step(x, y)
-        torch.cuda.synchronize()
-        log(f"warm-up step {i} done")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _ops.CONV_PROBE = probe = _ops.ConvProbe(DOMINANT)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    res = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, args.dtype, args.steps, args.warmup, rank, world, dev, log)
+    dt = res["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    _ops.CONV_PROBE = None
-    ps = probe.summary()
+    ps = res["probe"]
     props = torch.cuda.get_device_properties(dev)
     me = {"rank": rank, "device": f"cuda:{local_rank}", "name": props.name,
-          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+          # this rank's own clock over the K steps (before the closing barrier) and the time per step its compute stream spent waiting
+          # for gradient buckets that were still in flight when the backward ended: what a scaling curve needs to explain itself
+          "ms_per_step_local": round(res["t_local"] / args.steps * 1e3, 3),
+          "allreduce_wait_ms_per_step": None if res["allreduce_wait_ms"] is None else round(res["allreduce_wait_ms"], 3),
+          "dominant_kernel_avg_ms": round(ps["avg_ms"], 4)}
     devices = [me]
     if world > 1:
         devices = [None] * world
@@ -196,31 +295,8 @@ def main():
     if rank == 0:
         tiles = args.batch * world * args.steps
         value = tiles / dt
-        # dominant kernel over ALL its launches in the timed region: algorithmic FLOPs (fp32: MFMA roofline) or algorithmic bytes
-        # (bf16 storage: HBM roofline) / summed launch durations
         pmc = ROOT / "profiles" / "pmc_traffic.json"      # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
         pmc = json.loads(pmc.read_text()) if pmc.exists() else {}
-        common = {"launches_per_step": ps["launches"] // max(1, args.steps), "avg_launch_ms": round(ps["avg_ms"], 4),
-                  "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
-                  "avg_launch_alg_bytes": int(ps["bytes"] / max(1, ps["launches"])),
-                  "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)}
-        if args.dtype == "f32":
-            achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
-                                                   "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> = 41 "
-                                                   "launches / step and <...,true> = the 4 launches / step whose last 4 of 100 output channels "
-                                                   "run on v_mfma_4x4x1)",
-                        "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_F32_TFLOPS, 4),
-                        "traffic": pmc.get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"), **common}
-        else:
-            achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "conv_bf16_kernel<32,4,2,2,2,6> (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM: every wide "
-                                                  "3x3/1x1 conv, forward and input-gradient); algorithmic bytes = every operand tensor once in, the "
-                                                  "result once out, the packed filter once",
-                        "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-                        "traffic": pmc.get("conv_bf16_kernel<32,4,2,2,2,6>", {}).get("hbm_bytes_per_launch"),
-                        "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1), **common}
         out = {
             "metric": "512x512 tiles/sec fwd+bwd (4-ch->5-class U-Net)", "value": round(value, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -230,16 +306,40 @@ def main():
                                    "; bf16 storage of activations / gradients / packed filters, fp32 accumulate, fp32 master weights + Adam"),
                        "tiles_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"tile-dp{world}", "self_attention": False},
-            "loss": round(float(loss.item()), 5),
+            "loss": round(res["loss"], 5),
             "step_tflops": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
             "step_frac_of_f32_peak": round(value * GFLOP_PER_TILE_FWD_BWD / 1e3 / (PEAK_F32_TFLOPS * world), 4),
-            "roofline": roofline,
-            "hbm_bytes_allocated": model.memory_bytes(),
+            "roofline": roofline_of(ps, args.dtype, dt, args.steps, pmc),
+            "hbm_bytes_allocated": res["mem"],
             # world size the collective library itself reports (1 = no process group) and the device every rank ran on
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "devices": devices,
         }
+        if world == 1 and not args.no_secondary and args.dtype == "f32":
+            # measured in this same process, after the headline: the other BASELINE configurations and the bf16-storage variant of configs[1]
+            sec = {}
+            log("secondary: bf16-storage step")
+            rb = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", args.steps, args.warmup, 0, 1, dev, log)
+            vb = args.batch * args.steps / rb["dt"]
+            sec["bf16"] = {"value": round(vb, 3), "unit": "tiles/s", "ms_per_step": round(rb["dt"] / args.steps * 1e3, 3), "steps": args.steps,
+                           "dtype": "bf16", "workload": "cfg2 (BASELINE configs[1] wording): same step, bf16 storage of activations / gradients / "
+                           "packed filters, fp32 accumulate, fp32 master weights + Adam", "loss": round(rb["loss"], 5),
+                           "step_tflops": round(vb * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
+                           "step_frac_of_bf16_peak": round(vb * GFLOP_PER_TILE_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS, 4),
+                           "roofline": roofline_of(rb["probe"], "bf16", rb["dt"], args.steps, pmc), "hbm_bytes_allocated": rb["mem"]}
+            log("secondary: predict (eval forward + softmax + argmax)")
+            sec["predict_b16"] = {"f32": predict_bench("f32", 16, dev), "bf16": predict_bench("bf16", 16, dev)}
+            sec["predict_b1"] = {"f32": predict_bench("f32", 1, dev, iters=20), "bf16": predict_bench("bf16", 1, dev, iters=20)}
+            log("secondary: cfg1 (BASELINE configs[0]: xresnet18 3->2, 256x256, batch 2)")
+            r1 = step_bench("xresnet18", 3, 2, 256, 2, "f32", 30, 5, 0, 1, dev, log, probe=False)
+            sec["cfg1"] = {"value": round(2 * 30 / r1["dt"], 2), "unit": "256x256 tiles/s", "ms_per_step": round(r1["dt"] / 30 * 1e3, 3), "dtype": "f32",
+                           "step_tflops": round(2 * 30 / r1["dt"] * 175.805 / 1e3, 2)}
+            log("secondary: cfg5 (BASELINE configs[4]: 20000x20000 sliding-window predict) fp32")
+            sec["cfg5"] = {"f32": cfg5_bench("f32", dev)}
+            log("secondary: cfg5 bf16")
+            sec["cfg5"]["bf16"] = cfg5_bench("bf16", dev)
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -31,6 +31,8 @@ class TrainStep:
         self._calls = 0
         self._xs = self._ys = self._loss = None
         self.reducer: Optional[GradReducer] = None
+        # bench.py: a list here collects (start, end) events around the point where the compute stream waits for the gradient buckets
+        self.comm_events: Optional[list] = None
         if world > 1:
             bounds = [model._decoder_offset] + list(model._enc_child_offset.values())
             self.reducer = GradReducer(model.flat_grad, bounds, max_bucket_elems)
@@ -76,6 +78,13 @@ class TrainStep:
         loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta,
                                                 world=self.world)
         if self.reducer is not None:
+            ev = self.comm_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.reducer.finish()
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
         self.opt.step()
         return loss
