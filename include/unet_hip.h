@@ -110,7 +110,8 @@ int unet_set_wgrad_narrow(int on);   /* narrow-output (Cout <= 112) weight-gradi
 size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode); /* floats */
 int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream);
 /* 1x1 "weights" that are themselves activations (self-attention operands): element (out o, reduction r) = w[o*so + r*sr];
- * produces the same packed image as mode 0 with ks = 1 (size unet_pack_weights_size(O, R, 1, 0)). */
+ * produces the same packed image as mode 0 with ks = 1 (size unet_pack_weights_size(O, R, 1, 0), the sliver block of a 16 n + 1..4 wide
+ * output included). */
 int unet_pack_weights_strided(const float* w, long long so, long long sr, float* wp, int O, int R, void* stream);
 /* bf16 images from the fp32 master parameter: wp[tap][chunk][outPad][32] with chunk = 32 reduction channels (64 bytes, as in fp32);
  * a 3x3 filter whose reduction leaves a tail of 1..8 channels gets three more slabs fold[j][outPad][32] (k-slot (kq, c) = tail
@@ -238,6 +239,11 @@ int unet_dot(const float* x, int x_cs, int x_co, const float* y, int y_cs, int y
 size_t unet_ce_workspace(long long P);   /* floats */
 int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
                 float* loss /*[1]*/, float* denom /*[1]*/, float* workspace, void* stream);
+/* the same sums, not divided: numden[0] = sum w[y] * nll, numden[1] = sum w[y].  Tile-DDP all-reduces these two floats between the loss
+ * forward and backward kernels (one cross-entropy over the global batch); a rank whose tiles carry only zero-weight classes contributes
+ * 0 and 0 instead of a 0/0 quotient. */
+int unet_ce_fwd_parts(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                      float* numden /*[2]*/, float* workspace, void* stream);
 /* dz = gscale * w[y] * (softmax(z) - onehot(y)) / denom ; gscale multiplies (loss scaling / DDP averaging) */
 int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
                 const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream);

@@ -156,7 +156,18 @@ def _ce_worker(rank, world, port, q):
     ref = O.DiceMulti()
     ref.accumulate(torch.cat(zs).cpu(), torch.cat(ys).cpu())
     ok_dice = abs(dm.value - ref.value) < 1e-12
-    q.put((rank, bool(ok_loss), bool(ok_dz), bool(ok_dice)))
+    # a rank whose tiles carry only zero-weight classes has denominator 0 -- the ranks exchange numerator and denominator
+    # themselves (unet_ce_fwd_parts), so the global loss stays the finite single-process value instead of turning NaN through a 0/0
+    w0 = torch.tensor([0.0, 0.1, 0.2, 0.3, 1.5], device="cuda")
+    y0 = torch.zeros_like(y) if rank == 1 else y
+    loss0 = model.forward_loss_backward(x, y0, w0, world=world)
+    z0 = model.logits_ts().view().permute(0, 3, 1, 2).contiguous()
+    zs0, ys0 = [torch.empty_like(z0) for _ in range(world)], [torch.empty_like(y0) for _ in range(world)]
+    dist.all_gather(zs0, z0); dist.all_gather(ys0, y0)
+    l0 = O.CrossEntropyLossFlat(weight=w0.cpu().double())(torch.cat(zs0).cpu().double(), torch.cat(ys0).cpu())
+    ok_zero = bool(torch.isfinite(loss0).all().item()) and abs(loss0.item() - l0.item()) <= 2e-6 * abs(l0.item())
+    ok_zero = ok_zero and bool(torch.isfinite(model.flat_grad).all().item())
+    q.put((rank, bool(ok_loss), bool(ok_dz), bool(ok_dice and ok_zero)))
     dist.destroy_process_group()
 
 
@@ -212,6 +223,57 @@ def test_learner_tile_ddp_two_ranks(tmp_path):
     hist = (tmp_path / "history.csv").read_text().strip().splitlines()
     assert hist[0] == "epoch,train_loss,valid_loss,dice_multi,time" and len(hist) == 3
     assert (tmp_path / "models" / "best-model.pth").exists()
+
+
+def _empty_shard_worker(rank, world, port, root, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from pathlib import Path
+    from unet_amd.distributed import init_from_env
+    from unet_amd.learner import DataLoaders, Rmse, TileDataset, load_learner
+    init_from_env(backend="gloo")
+    torch.manual_seed(7)                                  # identical replicas: the single-process value is the reference
+    learn = _tiny_learner(Path(root))
+    vd = learn.dls.valid_ds
+    # ONE validation tile over two ranks: rank 1's shard is empty and must still take part in the (single) collective
+    one = DataLoaders(learn.dls.train_ds, TileDataset(vd.imgs[:1], vd.masks[:1], "int8"), 2, vocab=list("abc"))
+    learn.dls = one                                       # the setter shards: the fine-tune branch of train_unet assigns dls like this
+    sharded = (learn.dls.train.world, learn.dls.valid.world, len(learn.dls.train), len(learn.dls.valid))
+    v1 = learn.validate()
+    v2 = learn.validate()                                 # a second pass pairs its collectives correctly too
+    # fine-tune path (reference train.py:225-229): load_learner on an exported file, then learn.dls = dls
+    if rank == 0:
+        learn.export(Path(root) / "ft.pkl")
+    dist.barrier()
+    ft = load_learner(Path(root) / "ft.pkl", device="cuda:0")
+    ft.dls = one
+    q.put((rank, sharded, [float(v) for v in v1], [float(v) for v in v2], (ft.world, ft.dls.train.world, len(ft.dls.train))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_with_an_empty_rank_shard_and_finetune_sharding(tmp_path):
+    """(a) len(valid) < world leaves a rank without validation tiles -- metric counters and loss sums travel in ONE
+    all-reduce that every rank joins, values equal the single-process ones; (b) `learn.dls = dls` after load_learner shards the loaders"""
+    torch.manual_seed(7)
+    single = _tiny_learner(tmp_path / "single")
+    from unet_amd.learner import DataLoaders, TileDataset
+    vd = single.dls.valid_ds
+    single.dls = DataLoaders(single.dls.train_ds, TileDataset(vd.imgs[:1], vd.masks[:1], "int8"), 2, vocab=list("abc"))
+    ref = [float(v) for v in single.validate()]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == (2, 2, 1, 1 if r[0] == 0 else 0), r            # 4 train tiles / 2 ranks / bs 2 = 1 step; the valid tile sits on rank 0
+        assert r[2] == r[3] and np.allclose(r[2], ref, rtol=1e-6, atol=0), (r, ref)
+        assert r[4] == (2, 2, 1), r
 
 
 def test_augmentation_pipeline_runs_on_the_device():

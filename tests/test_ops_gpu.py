@@ -575,6 +575,23 @@ def test_row_softmax_and_strided_pack(ops):
     ops.conv2d(to_ts(xin), wp, out, 1)
     torch.cuda.synchronize()
     assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv")
+    # an output width of 16 n + 1..4 with ONE image for the whole batch (wp_img_stride 0) at a size where the planner picks the 128 x 128
+    # tile: that launch reads the 4x4x1 sliver block behind the image, which the strided packer must write too
+    O_, R = 100, 40
+    act = torch.randn(R, 120, generator=g)
+    w = act[:, 12:12 + O_].t().contiguous()
+    xin = torch.randn(4, R, 128, 128, generator=g)
+    ref = F.conv2d(xin, w.view(O_, R, 1, 1))
+    actd = act.cuda()
+    wp = torch.full((ops.lib.unet_pack_weights_size(O_, R, 1, 0),), float("nan"), device="cuda")
+    ops.pack_weights_strided(actd.data_ptr() + 12 * 4, 1, 120, O_, R, wp)
+    assert not bool(torch.isnan(wp).any())                # every element of the image, sliver included, is written
+    wp_ref = ops.pack_weights(w.view(O_, R, 1, 1).contiguous().cuda(), 0)
+    assert torch.equal(wp, wp_ref)                        # "the same packed image as mode 0 with ks = 1"
+    out = empty_ts(4, 128, 128, O_)
+    ops.conv2d(to_ts(xin), wp, out, 1)
+    torch.cuda.synchronize()
+    assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv, sliver width")
 
 
 @pytest.mark.parametrize("narrow", [1, 0])

@@ -10,6 +10,7 @@ steep / minimum, utils.py:150-167) are available.  Out of scope here (SURVEY.md 
 from __future__ import annotations
 
 import json
+import os
 import shutil
 import warnings
 from pathlib import Path
@@ -63,7 +64,9 @@ def unet_learner_MS(dls, arch, pretrained=True, loss_func=None, norm_type=None, 
     x0, _ = dls.train_ds[0]
     n_in, size = x0.shape[0], tuple(x0.shape[-2:])
     n_out = 1 if regression else len(dls.vocab)                      # train.py:137-140
-    model = HipDynamicUnet(_arch_name(arch), n_in, n_out, size, self_attention=self_attention, device=dls.device)
+    # UNET_ACT_DTYPE=bf16 selects the bf16-storage variant (BASELINE configs[1]); the reference has no such switch and computes in fp32
+    model = HipDynamicUnet(_arch_name(arch), n_in, n_out, size, self_attention=self_attention, device=dls.device,
+                           act_dtype=os.environ.get("UNET_ACT_DTYPE", "f32"))
     cls = Learner_adjust if regression else Learner                   # train.py:148
     return cls(dls=dls, model=model, loss_func=loss_func, opt_func=opt_func, lr=lr, splitter=splitter, cbs=cbs, metrics=metrics,
                    path=path, model_dir=model_dir, wd=wd, wd_bn_bias=wd_bn_bias, train_bn=train_bn, moms=moms)

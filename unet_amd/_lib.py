@@ -132,6 +132,7 @@ _sig = {
     "unet_dot": (i, [vp, i, i, vp, i, i, ll, i, vp, vp, vp]),
     "unet_ce_workspace": (sz, [ll]),
     "unet_ce_fwd": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp, vp]),
+    "unet_ce_fwd_parts": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp]),
     "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),
     "unet_regloss_fwd": (i, [vp, i, i, vp, ll, i, f, vp, vp, vp]),
     "unet_regloss_bwd": (i, [vp, i, i, vp, ll, i, f, f, vp, i, i, vp]),

@@ -378,7 +378,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
         d->wp_img_stride == 0 && d->colsum == nullptr && d->colsumsq == nullptr) {
         k.sliver = 1;
         k.wsl = d->wp + (size_t)T * k.nchunks * k.coutPad * 16;
-        p->lds_bytes += (size_t)2 * T * 64 * sizeof(float);
+        p->lds_bytes += (size_t)2 * 9 * 64 * sizeof(float);      // two chunk buffers at the kernel's fixed stride of 9 taps (a 1x1 filter uses one tap of each)
     }
     // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
     p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), 1, (unsigned)p->nparity);

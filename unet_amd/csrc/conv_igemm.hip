@@ -683,6 +683,18 @@ __global__ void pack_weights_strided_kernel(const float* __restrict__ w, long lo
         const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         wp[i] = (o < O && r < R) ? w[(long long)o * so + (long long)r * sr] : 0.f;
     }
+    // the sliver image behind it, as pack_weights_kernel writes it (conv_common.h, f32_sliver): a launch with wp_img_stride == 0 at such
+    // a width reads it whatever packer made the image
+    if (unetconv::f32_sliver(O)) {
+        const size_t nsl = (size_t)nchunks * 64;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nsl; i += (size_t)gridDim.x * blockDim.x) {
+            const int pos = (int)(i & 15), j = (int)((i >> 4) & 3), chunk = (int)(i >> 6);
+            const bool tail = (R & 15) != 0 && chunk == nchunks - 1;
+            const int r = chunk * 16 + (tail ? (4 * (pos & 3) + (pos >> 2)) : pos);
+            const int o = (O & ~15) + j;
+            wp[total + i] = (o < O && r < R) ? w[(long long)o * so + (long long)r * sr] : 0.f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ host side

@@ -671,12 +671,20 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z
     }
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ part, int rows, float* loss, float* denom) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wavefront: 64 lanes sum the partial rows in fp64, shuffle reduction; numden (optional) receives the numerator and the
+// denominator themselves -- what the ranks of a tile-DDP step all-reduce (a rank whose tiles carry only zero-weight classes has
+// den = 0: its 0/0 quotient must not reach the global loss)
+__global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ part, int rows, float* loss, float* denom, float* numden) {
     double n = 0.0, d = 0.0;
-    for (int r = 0; r < rows; ++r) { n += (double)part[2 * r]; d += (double)part[2 * r + 1]; }
-    *loss = (float)(n / d);
-    *denom = (float)d;
+    for (int r = threadIdx.x; r < rows; r += 64) { n += (double)part[2 * r]; d += (double)part[2 * r + 1]; }
+    for (int o = 32; o > 0; o >>= 1) {
+        n += __shfl_down(n, o);
+        d += __shfl_down(d, o);
+    }
+    if (threadIdx.x != 0) return;
+    if (loss) *loss = (float)(n / d);
+    if (denom) *denom = (float)d;
+    if (numden) { numden[0] = (float)n; numden[1] = (float)d; }
 }
 
 template <typename T>
@@ -1200,7 +1208,19 @@ extern "C" int unet_ce_fwd(const float* z, int z_cs, int z_co, const int64_t* ta
     const int rows = ce_rows(P);
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, workspace);
     UNET_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, loss, denom);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, loss, denom, (float*)nullptr);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_ce_fwd_parts(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
+                                 float* numden, float* workspace, void* stream) {
+    UNET_CHECK_ARG(z && target && numden && workspace && P > 0 && C > 0 && C <= CE_MAXC, "ce_fwd_parts: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs, "ce_fwd_parts: bad slice");
+    const int rows = ce_rows(P);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, workspace);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, (float*)nullptr, (float*)nullptr, numden);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

@@ -130,12 +130,13 @@ class Rmse:
         self.n += d.numel()
         self._dev = pred.device
 
-    def all_reduce(self):
-        import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size() > 1 and self.n:
-            t = torch.tensor([self.se, float(self.n)], dtype=torch.float64, device=self._dev)
-            dist.all_reduce(t)
-            self.se, self.n = float(t[0].item()), int(t[1].item())
+    # counters as a flat list of floats: Learner.validate packs every metric's counters and the loss sums into ONE all-reduce that every
+    # rank takes part in, whether its validation shard held tiles or not (a shard is empty when len(valid) < world)
+    def state(self, n_cls: int) -> list:
+        return [self.se, float(self.n)]
+
+    def load_state(self, v: list):
+        self.se, self.n = float(v[0]), int(round(v[1]))
 
     @property
     def value(self) -> float:
@@ -157,12 +158,11 @@ class R2Score:
         self.res += float(((t - p) ** 2).sum().item())
         self._dev = pred.device
 
-    def all_reduce(self):
-        import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size() > 1 and self.n:
-            v = torch.tensor([float(self.n), self.st, self.stt, self.res], dtype=torch.float64, device=self._dev)
-            dist.all_reduce(v)
-            self.n, self.st, self.stt, self.res = int(v[0].item()), float(v[1].item()), float(v[2].item()), float(v[3].item())
+    def state(self, n_cls: int) -> list:
+        return [float(self.n), self.st, self.stt, self.res]
+
+    def load_state(self, v: list):
+        self.n, self.st, self.stt, self.res = int(round(v[0])), float(v[1]), float(v[2]), float(v[3])
 
     @property
     def value(self) -> float:
@@ -190,13 +190,28 @@ class DiceMulti:
         self.inter = inter.double() if self.inter is None else self.inter + inter.double()
         self.union = (cp + ct).double() if self.union is None else self.union + (cp + ct).double()
 
-    def all_reduce(self):
+    def state(self, n_cls: int) -> list:
+        if self.inter is None:          # this rank saw no validation tile: it contributes zeros
+            return [0.0] * (2 * n_cls)
+        return self.inter.cpu().tolist() + self.union.cpu().tolist()
+
+    def load_state(self, v: list):
+        n = len(v) // 2
+        self.inter, self.union = torch.tensor(v[:n], dtype=torch.float64), torch.tensor(v[n:], dtype=torch.float64)
+
+    def all_reduce(self, device=None):
+        """sum of the counters over the ranks; every rank must call it (a rank without tiles passes its class count through `reset`-time
+        zeros via Learner.validate -- standalone use needs counters on every rank)"""
         import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size() > 1 and self.inter is not None:
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.inter is None:
+                raise RuntimeError("DiceMulti.all_reduce on a rank without counters: use Learner.validate, which packs zeros for it")
             dist.all_reduce(self.inter); dist.all_reduce(self.union)
 
     @property
     def value(self) -> float:
+        if self.inter is None:
+            return float("nan")
         i, u = self.inter.cpu().numpy(), self.union.cpu().numpy()
         with np.errstate(invalid="ignore", divide="ignore"):
             s = np.where(u > 0, 2.0 * i / u, np.nan)
@@ -452,7 +467,7 @@ class Learner:
     def __init__(self, dls: DataLoaders, model: HipDynamicUnet, loss_func=None, opt_func: Callable = Adam, lr=1e-3, splitter=None,
                  cbs=None, metrics=None, path=None, model_dir="models", wd=None, wd_bn_bias=False, train_bn=True,
                  moms=(0.95, 0.85, 0.95)):
-        self.dls, self.model = dls, model
+        self._dls, self.model = None, model
         self.loss_func = loss_func if loss_func is not None else CrossEntropyLossFlat(axis=1)
         self.opt_func, self.lr, self.splitter = opt_func, lr, splitter or xresnet_split
         self.cbs: List[Callback] = list(cbs or [])
@@ -469,10 +484,22 @@ class Learner:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.dls = dls                  # through the setter: loaders are sharded by rank wherever they come from
+        self._synced = False
+
+    @property
+    def dls(self):
+        return self._dls
+
+    @dls.setter
+    def dls(self, dls):
+        """every path that hands the Learner its loaders goes through here -- the constructor and `learn.dls = dls` of the fine-tune
+        branch (reference train.py:225-229) alike -- so a tile-DDP run always trains / validates on rank shards"""
+        self._dls = dls
+        if dls is not None and self.world > 1:
             for dl in (getattr(dls, "train", None), getattr(dls, "valid", None)):
                 if dl is not None:
                     dl.shard(self.rank, self.world)
-        self._synced = False
 
     def _barrier(self):
         if self.world > 1:
@@ -621,14 +648,19 @@ class Learner:
             den += d
             for m in self.metrics:
                 m.accumulate_argmax(amax, yb, z.C)
-        for m in self.metrics:
-            if hasattr(m, "all_reduce"):
-                m.all_reduce()
-        if self.world > 1:          # valid_loss = sum of the ranks' numerators / sum of their denominators
+        if self.world > 1:
+            # ONE collective per validation pass, the same on every rank whether or not its shard held a tile: valid_loss = sum of the
+            # ranks' numerators / sum of their denominators, followed by every metric's counters
             import torch.distributed as dist
-            t = torch.tensor([num, den], dtype=torch.float64, device=model._device)
+            states = [m.state(model.n_out) for m in self.metrics]
+            t = torch.tensor([num, den] + [v for st in states for v in st], dtype=torch.float64, device=model._device)
             dist.all_reduce(t)
-            num, den = float(t[0].item()), float(t[1].item())
+            vals = t.cpu().tolist()
+            num, den = vals[0], vals[1]
+            o = 2
+            for m, st in zip(self.metrics, states):
+                m.load_state(vals[o:o + len(st)])
+                o += len(st)
         return [num / max(den, 1e-30)] + [m.value for m in self.metrics]
 
     # -- inference (predict.py:193)

@@ -160,7 +160,8 @@ class HipDynamicUnet(nn.Module):
                 stale.append((cx, 1))
         if not stale:
             return
-        key = tuple((id(cx), mode) for cx, mode in stale)
+        # the cached job table holds raw addresses: a re-pointed parameter or a re-allocated image must not hit an old table
+        key = tuple((id(cx), mode, cx.conv.weight.data_ptr(), (cx.wp_f if mode == 0 else cx.wp_d).data_ptr()) for cx, mode in stale)
         ent = self._pack_tables.get(key)
         if ent is None:
             jobs = (L.PackJob * len(stale))()
@@ -403,15 +404,15 @@ class HipDynamicUnet(nn.Module):
         if reg_kind is None:
             y = y.to(self._device, torch.int64).contiguous()
             loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
-            ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
             if world > 1:
                 import torch.distributed as dist
                 nd = ctx.vec(self, "numden", 2)
-                torch.mul(loss, denom, out=nd[0:1])
-                nd[1:2].copy_(denom)
+                ops.ce_fwd_parts(z, y, weight, nd, ctx.workspace(ops.ce_workspace(P)))      # this rank's numerator and denominator
                 dist.all_reduce(nd)
                 denom.copy_(nd[1:2])
                 torch.div(nd[0:1], nd[1:2], out=loss)
+            else:
+                ops.ce_fwd(z, y, weight, loss, denom, ctx.workspace(ops.ce_workspace(P)))
             ops.ce_bwd(z, y, weight, denom, grad_scale, dz)
         else:
             if self.n_out != 1:

@@ -419,6 +419,14 @@ def ce_fwd(z: TS, target: torch.Tensor, weight, loss, denom, ws):
                           ws.data_ptr(), _stream()), "ce_fwd")
 
 
+def ce_fwd_parts(z: TS, target: torch.Tensor, weight, numden: torch.Tensor, ws):
+    """numden[0] = sum w[y] * nll, numden[1] = sum w[y] over this rank's pixels (tile-DDP: all-reduced before the division)"""
+    _need_f32("ce_fwd_parts", z)
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == z.P and numden.numel() >= 2
+    check(lib.unet_ce_fwd_parts(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, numden.data_ptr(), ws.data_ptr(), _stream()),
+          "ce_fwd_parts")
+
+
 def ce_bwd(z: TS, target, weight, denom, gscale: float, dz: TS):
     check(_fn("ce_bwd", dz)(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, denom.data_ptr(), gscale, dz.ptr, dz.cs,
                           dz.co, _stream()), "ce_bwd")
