@@ -7,7 +7,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import unet_oracle as O  # noqa: E402  (checker)
-from tests.test_configs_gpu import _normalise_head  # noqa: E402
+from tests.test_configs_gpu import (ENC_FACTOR, _attention_logit_scale, _check_grads, _grad_table, _hip_from, _normalise_head,  # noqa: E402
+                                     _sa_pair)
 from tests.test_model_gpu import _make_all_active  # noqa: E402
 
 ARCHS = [
@@ -76,3 +77,39 @@ def test_train_step_gradients_smooth(arch, n_in, n_out, size, bs):
     print("smooth worst", worst)
     assert worst[1] < 2e-3, worst
 
+
+def test_deep_encoder_with_self_attention():
+    """reference params_and_main.py:12,83: xresnet34_deep is an importable ARCHITECTURE and self_attention = True the shipped default.
+    fastai puts SelfAttention on UnetBlock len - 3 = 3 of its six blocks: 432 channels (query / key 54 wide, padded to 56 lanes in the
+    fused QKV buffer) on the 32 x 32 stage of a 256 x 256 tile.  Eval logits / masks and every gradient -- gamma and the spectral-normed
+    projections included -- against the oracle (fp64 adjudicates)."""
+    import copy
+    x, y = O.synthetic_batch(2, 3, 256, 256, 3)
+    ref = _sa_pair("xresnet34_deep", 3, 3, (256, 256), 41, x, blk_idx=7)
+    assert ref.layers[7].conv2[2].query[0].weight.shape[:2] == (54, 432)
+    _normalise_head(ref, x[:1])
+    model = _hip_from(ref, "xresnet34_deep", 3, 3, (256, 256), sa=True)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    err = (z - z32).abs().max().item()
+    print(f"deep + SA eval: |hip-cpu32| {err:.2e} at scale {z32.abs().max().item():.2f}; attention logits up to {_attention_logit_scale(ref, x, 7):.1f}")
+    assert err < 1e-3
+    diff = amax.cpu() != z32.argmax(1)
+    top2 = z32.topk(2, dim=1).values
+    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
+    ref64 = copy.deepcopy(ref).double()
+    ref.train(); ref64.train(); model.train()
+    w = torch.tensor([0.2, 0.5, 0.3])
+    O.CrossEntropyLossFlat(weight=w)(ref(x), y).backward()
+    l64 = O.CrossEntropyLossFlat(weight=w.double())(ref64(x.double()), y)
+    l64.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item())
+    rows = _grad_table(model, ref, ref64)
+    _check_grads(rows, tail_from=9, tail_bar=2e-3, what="xresnet34_deep + SA")
+    sa_rows = [r for r in rows if ".conv2.2." in r[0]]
+    assert len(sa_rows) == 4 and all(r[1] <= max(2e-3, ENC_FACTOR * r[2]) for r in sa_rows), sa_rows

@@ -344,7 +344,7 @@ def test_cfg4_training_step_properties_at_full_size(cfg4):
 
 # ------------------------------------------------------------------------------------------------ shipped default / SA
 
-def _sa_pair(arch, n_in, n_out, size, seed, x):
+def _sa_pair(arch, n_in, n_out, size, seed, x, blk_idx=5):
     """fastai's default initialisation (activations stay O(1): with randomised BatchNorm statistics the norm-free decoder inflates
     them to 1e4 and the attention logits f^T g to 1e8, where ONE fp32 ulp is 8 and softmax is a coin toss for either
     implementation), BatchNorm gammas of the ResBlock tails opened, running statistics moved by one train-mode pass, gamma = 0.7
@@ -365,7 +365,7 @@ def _sa_pair(arch, n_in, n_out, size, seed, x):
         # the attention logits f^T g scale with the SQUARE of the activation magnitude (1e5 here: one fp32 ulp = 0.008 in the
         # exponent of the softmax).  Scale the conv that feeds the attention block instead.
         seen = {}
-        blk = ref.layers[5]
+        blk = ref.layers[blk_idx]
         h = blk.conv2[1].register_forward_hook(lambda m, i, o: seen.__setitem__("a", float(o.abs().max())))
         ref(x)
         h.remove()
@@ -375,9 +375,9 @@ def _sa_pair(arch, n_in, n_out, size, seed, x):
     return ref
 
 
-def _attention_logit_scale(ref, x):
+def _attention_logit_scale(ref, x, blk_idx=5):
     """max |f^T g| the oracle's attention block sees for x (eval mode): the conditioning of its softmax"""
-    sa = ref.layers[5].conv2[2]
+    sa = ref.layers[blk_idx].conv2[2]
     seen = {}
     h = sa.register_forward_hook(lambda m, i, o: seen.__setitem__("x", i[0]))
     with torch.no_grad():

@@ -42,7 +42,16 @@ def _worker(rank, world, port, q):
     step = TrainStep(model, opt, None, world, max_bucket_elems=1 << 20)    # several buckets per span
     assert len(step.reducer.spans) > 8
     step.reducer.reset()
+    seen = []
+    inner = model.grad_ready_hook
+    model.grad_ready_hook = lambda off: (seen.append((off, step.reducer._next)), inner(off))[1]
     loss = model.forward_loss_backward(x, y, None, grad_scale=1.0 / world)
+    model.grad_ready_hook = inner
+    # readiness points: final ResBlock + head first, then one per UnetBlock, the encoder children last -- strictly descending offsets,
+    # and buckets already in flight after the FIRST point (the all-reduce starts while > 90 % of the backward is still to run)
+    offs = [o for o, _ in seen]
+    assert offs == sorted(offs, reverse=True) and len(set(offs)) == len(offs) and len(offs) >= 5 + 7, offs
+    assert offs[0] == model._layer_offset[4 + len(model.sz_chg_idxs)] and seen[1][1] >= 1, seen[:3]
     step.reducer.finish()
     torch.cuda.synchronize()
     summed = local.clone()

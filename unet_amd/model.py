@@ -138,6 +138,13 @@ class HipDynamicUnet(nn.Module):
             if ps:
                 self._enc_child_offset[i] = min(self._param_offsets[id(p)][0] for p in ps)
         self._decoder_offset = min(self._param_offsets[id(p)][0] for l in list(self.layers)[1:] for p in l.parameters())
+        # readiness points of the decoder backward (tile-DDP): flat index of the first parameter of every top-level child.  The backward
+        # runs from the head down, so once child i is done every gradient element at index >= _layer_offset[i] is final
+        self._layer_offset = {}
+        for i, l in enumerate(self.layers):
+            ps = list(l.parameters())
+            if i >= 1 and ps:
+                self._layer_offset[i] = min(self._param_offsets[id(p)][0] for p in ps)
         for m in self.modules():
             cx = getattr(m, "cx", None)
             if isinstance(cx, _ConvExec):
@@ -284,6 +291,9 @@ class HipDynamicUnet(nn.Module):
         ctx.free(do)
         d = L[nb].hip_bwd(ctx, dX.sub(0, self.up_c))            # -> masked grad wrt UnetBlock 3 conv2 pre-activation
         ctx.free(dX)
+        hook = self.grad_ready_hook
+        if hook is not None:                                    # head, final ResBlock, final shuffle: the first bucket can leave now
+            hook(self._layer_offset[nb])
         dskips: Dict[int, TS] = {}
         for k in range(len(self.sz_chg_idxs) - 1, -1, -1):
             idx = self.sz_chg_idxs[k]
@@ -293,6 +303,8 @@ class HipDynamicUnet(nn.Module):
             ctx.free(d)
             d = dn
             dskips[idx] = ds
+            if hook is not None:                                # one readiness point per UnetBlock
+                hook(self._layer_offset[4 + k])
         # middle_conv (d is masked wrt middle_conv[1] pre-activation)
         mids = list(L[3])
         for j in range(len(mids) - 1, -1, -1):
@@ -305,7 +317,6 @@ class HipDynamicUnet(nn.Module):
         de = ctx.tmp(e.N, e.H, e.W, e.C)
         self._post_bx.bwd(ctx, d, None, e, de)
         ctx.free(d)
-        hook = self.grad_ready_hook
         if hook is not None:
             hook(self._decoder_offset)
         # encoder, last child to first

@@ -541,9 +541,12 @@ class SelfAttention(nn.Module):
         self.value = nn.Sequential(nn.utils.spectral_norm(nn.Conv1d(n_channels, n_channels, 1, bias=False)))
         self.gamma = nn.Parameter(torch.tensor([0.0]))
         self.C, self.c8 = n_channels, c8
-        if c8 % 4 != 0:      # the query / key slices of the fused QKV buffer are channel slices: multiples of the 4-channel vector
-            raise ValueError(f"self-attention on {n_channels} channels: the device program needs n_channels divisible by 32 "
-                             f"(xresnet18/34/50/101 decoders: 384 / 1536; xresnet34_deep's attention block has 432)")
+        # the query / key / value slices of the fused QKV buffer are channel slices and start at multiples of the 4-channel vector:
+        # query and key are padded to c8p lanes (xresnet34_deep: 432 channels, 54 -> 56) with zero filter rows, i.e. zero lanes that
+        # add nothing to any product
+        self.c8p = (c8 + 3) // 4 * 4
+        if n_channels % 4 != 0:
+            raise ValueError(f"self-attention on {n_channels} channels: the device program needs a multiple of 4 channels")
 
     @staticmethod
     def _normed_weight(seq: nn.Sequential) -> torch.Tensor:
@@ -578,19 +581,24 @@ class SelfAttention(nn.Module):
     def _scores(self, ctx: Ctx, qkv: TS, TP: TS, ch, W: int, wpa: torch.Tensor):
         """TP <- row-softmax(G_chunk F^T): the rows of beta^T that belong to the chunk"""
         b0, nb, j0, nj = ch
-        N, c8, CQ = TP.C, self.c8, qkv.cs
+        N, c8, c8p, CQ = TP.C, self.c8, self.c8p, qkv.cs
         img = qkv.buf.shape[1] * qkv.buf.shape[2] * CQ * 4
         sz = int(ops.lib.unet_pack_weights_size(N, c8, 1, 0))
         for k in range(nb):
             ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, CQ, 1, N, c8, wpa[k * sz:])                 # (o=i, r=c) = F_b[i][c]
-        ops.conv2d(self._rows(qkv.buf, c8, c8, b0, nb, j0, nj, W), wpa, TP, 1, wp_img_stride=sz)          # T = G F^T
+        ops.conv2d(self._rows(qkv.buf, c8p, c8, b0, nb, j0, nj, W), wpa, TP, 1, wp_img_stride=sz)         # T = G F^T
         ops.row_softmax(TP, TP)                                                                            # in place
 
     def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
-        B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
-        N, CQ = H * W, 2 * c8 + C_
+        B, H, W, C_, c8, c8p = x.N, x.H, x.W, self.C, self.c8, self.c8p
+        N, CQ = H * W, 2 * c8p + C_
         with torch.enable_grad():
-            wcat = torch.cat([self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)], 0)
+            wq_, wk_, wv_ = self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)
+            if c8p != c8:
+                zpad = wq_.new_zeros((c8p - c8,) + tuple(wq_.shape[1:]))
+                wcat = torch.cat([wq_, zpad, wk_, zpad, wv_], 0)
+            else:
+                wcat = torch.cat([wq_, wk_, wv_], 0)
             wcat = wcat.reshape(CQ, C_, 1, 1)
         ctx.saved[(id(self), "wcat")] = wcat
         wq = wcat.detach().contiguous()
@@ -601,7 +609,7 @@ class SelfAttention(nn.Module):
         chunks = self._chunks(B, H, W)
         nbmax = max(c[1] for c in chunks)
         szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
-               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
+               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8p, N, 1, 0))]
         wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
         O = ctx.act(self, "O", B, H, W, C_)
         img = N * CQ * 4      # bytes per image of qkv
@@ -610,7 +618,7 @@ class SelfAttention(nn.Module):
             TP = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
             self._scores(ctx, qkv, TP, ch, W, wpa)
             for k in range(nb):
-                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8, 1, CQ, C_, N, wpa[k * szs[1]:])      # (o=c, r=i) = H_b[i][c]
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8p, 1, CQ, C_, N, wpa[k * szs[1]:])     # (o=c, r=i) = H_b[i][c]
             ops.conv2d(TP, wpa, self._rows(O.buf, 0, C_, b0, nb, j0, nj, W), 1, wp_img_stride=szs[1])             # O = P H
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         gvec.copy_(self.gamma.data.expand(C_))
@@ -623,8 +631,8 @@ class SelfAttention(nn.Module):
     def hip_bwd(self, ctx: Ctx, dout: TS) -> TS:
         """dout = dL/d(out).  Returns dL/dx."""
         x: TS = ctx.saved[(id(self), "x")]
-        B, H, W, C_, c8 = x.N, x.H, x.W, self.C, self.c8
-        N, CQ = H * W, 2 * c8 + C_
+        B, H, W, C_, c8, c8p = x.N, x.H, x.W, self.C, self.c8, self.c8p
+        N, CQ = H * W, 2 * c8p + C_
         qkv, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "O", B, H, W, C_)
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         ops.dot(O, dout, self.gamma.grad, ctx.workspace(ops.colsum_workspace(O.P, C_)))        # dL/dgamma = sum O * dout
@@ -635,9 +643,9 @@ class SelfAttention(nn.Module):
         kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
         nbmax = max(c[1] for c in chunks)
         szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
-               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8, N, 1, 0))]
+               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8p, N, 1, 0))]
         wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
-        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8)
+        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8p)
         img = N * CQ * 4
         for ch in chunks:
             b0, nb, j0, nj = ch
@@ -647,7 +655,7 @@ class SelfAttention(nn.Module):
             dP = self._scratch(ctx, "dP", chunks, N, nb, nj, W)
             dO_c = self._rows(dO.buf, 0, C_, b0, nb, j0, nj, W)
             for k in range(nb):
-                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8, CQ, 1, N, C_, wpa[k * szs[2]:])       # (o=i, r=c) = H_b[i][c]
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8p, CQ, 1, N, C_, wpa[k * szs[2]:])      # (o=i, r=c) = H_b[i][c]
             ops.conv2d(dO_c, wpa, dP, 1, wp_img_stride=szs[2])                                                     # dP = dO H^T
             last = j0 + nj == N
             for k in range(nb):
@@ -656,18 +664,20 @@ class SelfAttention(nn.Module):
                 n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
                 ops.conv2d_wgrad(dO_b, P_b, tmpH, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dH_b (+)= P^T dO -> [N][C]
                 if last:
-                    ops.copy_slice(TS(tmpH[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8, C_))
+                    ops.copy_slice(TS(tmpH[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8p, C_))
             ops.row_softmax_bwd(P, dP, dP)                                                                         # dT in place
             for k in range(nb):
-                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, 1, CQ, c8, N, wpa[k * szs[3]:])                 # (o=c, r=i) = F_b[i][c]
-            ops.conv2d(dP, wpa, self._rows(dqkv.buf, c8, c8, b0, nb, j0, nj, W), 1, wp_img_stride=szs[3])          # dG = dT F
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, 1, CQ, c8p, N, wpa[k * szs[3]:])                # (o=c, r=i) = F_b[i][c]
+            # c8p output channels: the pad lanes of F are zeros, so the pad lanes of dG are written as exact zeros (dqkv is pool memory)
+            ops.conv2d(dP, wpa, self._rows(dqkv.buf, c8p, c8p, b0, nb, j0, nj, W), 1, wp_img_stride=szs[3])        # dG = dT F
             for k in range(nb):
                 b = b0 + k
-                dT_b, G_b = TS(dP.buf[k:k + 1], 0, N), self._rows(qkv.buf, c8, c8, b, 1, j0, nj, W)
+                # G with its zero pad lanes (c8p wide): the gradient rows come out 16-byte aligned, their pad lanes are exact zeros
+                dT_b, G_b = TS(dP.buf[k:k + 1], 0, N), self._rows(qkv.buf, c8p, c8p, b, 1, j0, nj, W)
                 n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
-                ops.conv2d_wgrad(G_b, dT_b, tmpF, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dF_b (+)= dT^T G -> [N][c8]
+                ops.conv2d_wgrad(G_b, dT_b, tmpF, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dF_b (+)= dT^T G -> [N][c8p]
                 if last:
-                    ops.copy_slice(TS(tmpF[:N * c8].view(1, H, W, c8), 0, c8), TS(dqkv.buf[b:b + 1], 0, c8))
+                    ops.copy_slice(TS(tmpF[:N * c8p].view(1, H, W, c8p), 0, c8p), TS(dqkv.buf[b:b + 1], 0, c8p))
         # back through the fused QKV projection
         wcat: torch.Tensor = ctx.saved[(id(self), "wcat")]
         dw = ctx.vec(self, "dwcat", CQ * C_).view(CQ, C_, 1, 1)

@@ -34,7 +34,7 @@ class TrainStep:
         # bench.py: a list here collects (start, end) events around the point where the compute stream waits for the gradient buckets
         self.comm_events: Optional[list] = None
         if world > 1:
-            bounds = [model._decoder_offset] + list(model._enc_child_offset.values())
+            bounds = [model._decoder_offset] + list(model._layer_offset.values()) + list(model._enc_child_offset.values())
             self.reducer = GradReducer(model.flat_grad, bounds, max_bucket_elems)
             model.grad_ready_hook = self.reducer.ready_down_to
 
