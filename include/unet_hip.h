@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 3
+#define UNET_ABI_VERSION 4
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -89,12 +89,20 @@ typedef struct {
     int dtype;                           /* UNET_F32 (default 0) | UNET_BF16: storage type of x, res, mask, y and wp (cast the pointers);
                                             bias stays fp32.  bf16: wp from unet_pack_weights_bf16, colsum / colsumsq unsupported */
     int y_f32;                           /* dtype UNET_BF16 only: y is an fp32 buffer (the logits head feeds the fp32 loss kernels) */
+    float* splitk_ws;                    /* optional scratch for split-K launches (small grid, long reduction): fp32, 16-byte aligned, */
+    size_t splitk_ws_floats;             /*   >= unet_conv2d_splitk_workspace(desc) floats; NULL / too small = never split this launch */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */
 int unet_conv2d_colsum_rows(const unet_conv_desc* d);
 int unet_conv2d(const unet_conv_desc* d, void* stream);
-/* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) -- for profilers / bench.py */
+/* floats of split-K scratch the planner would use for this desc (0: it does not split).  A launch whose output grid cannot fill the chip
+ * although its reduction is long (deep low-resolution stages, small batches) is cut into `splits` contiguous ranges of reduction chunks;
+ * partial sums are added in split order by a second kernel that applies bias / residual / ReLU / mask: deterministic, and shorter
+ * accumulation chains.  unet_set_conv_splitk(0) switches it off process-wide (A/B knob). */
+size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d);
+int unet_set_conv_splitk(int on);
+/* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) + 1000000 * splits -- for profilers / bench.py */
 int unet_conv2d_variant(const unet_conv_desc* d);
 /* MFMA instruction shape used by the conv / wgrad kernels: 16 (v_mfma_f32_16x16x4_f32, 16-channel granularity, default)
  * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */

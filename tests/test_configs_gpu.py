@@ -46,7 +46,7 @@ def _normalise_head(ref, x, target=4.0):
         head.bias.div_(s)
 
 
-def _assert_masks(am_hip, z_ref32, z_ref64, err_hip, err_cpu, what):
+def _assert_masks(am_hip, z_ref32, z_ref64, err_hip, err_cpu, what, max_ties=4):
     """masks must be identical; a pixel may differ only where the fp64 decision margin is below the fp32 evaluation error of
     either implementation (undecidable in fp32), and the HIP mask must then not be further from fp64 than the fp32 oracle's"""
     am32, am64 = z_ref32.argmax(1), z_ref64.argmax(1)
@@ -59,7 +59,7 @@ def _assert_masks(am_hip, z_ref32, z_ref64, err_hip, err_cpu, what):
     assert bool((gap[diff] <= 2.0 * max(err_hip, err_cpu)).all()), f"{what}: a mask pixel differs where fp64 is decided (gap {gap[diff].max():.2e})"
     wrong_hip, wrong_cpu = int((am_hip != am64).sum()), int((am32 != am64).sum())
     assert wrong_hip <= wrong_cpu + n, (what, wrong_hip, wrong_cpu)
-    assert n <= 4, f"{what}: {n} tie pixels differ"
+    assert n <= max_ties, f"{what}: {n} tie pixels differ"
     return n
 
 
@@ -261,15 +261,14 @@ def test_cfg1_xresnet18_rgb_256_batch2_training_step():
     assert (z.double() - z64.detach()).abs().max().item() < 1e-3 * max(1.0, z64.abs().max().item() / 8)
     assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item())
     _check_grads(_grad_table(model, ref, ref64), tail_from=7, tail_bar=2e-3, what="cfg1 B=2")
-    ref.eval(); model.eval()
+    ref.eval(); ref64.eval(); model.eval()
     with torch.no_grad():
-        z32 = ref(x)
+        z32, ze64 = ref(x), ref64(x.double())
         _, amax = model.predict_probs(x.cuda())
         ze = model(x.cuda()).cpu()
     assert (ze - z32).abs().max().item() < 1e-3 * max(1.0, z32.abs().max().item() / 8)
-    diff = amax.cpu() != z32.argmax(1)
-    top2 = z32.topk(2, dim=1).values
-    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 1e-4).all())
+    n = _assert_masks(amax.cpu(), z32, ze64, (ze.double() - ze64).abs().max().item(), (z32.double() - ze64).abs().max().item(), "cfg1")
+    print("cfg1: differing (fp64-adjudicated tie) pixels:", n)
 
 
 # ------------------------------------------------------------------------------------------------ cfg4
@@ -298,9 +297,15 @@ def test_cfg4_one_1024_tile_eval_against_the_oracle(cfg4):
     print(f"cfg4 eval: logit scale {scale:.2f}, |hip-cpu32| {err:.2e}")
     assert err < 1e-3 * max(1.0, scale / 8.0)
     assert (probs.cpu() - torch.softmax(z32, 1)).abs().max().item() < 1e-3
-    diff = amax.cpu() != z32.argmax(1)
-    top2 = z32.topk(2, dim=1).values
-    assert int(diff.sum()) <= 8 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all()), int(diff.sum())
+    # masks: an fp64 run of the same oracle decides every pixel the two fp32 evaluations disagree on (a million pixels, 10 classes)
+    ref64 = copy.deepcopy(ref).double()
+    ref64.eval()
+    with torch.no_grad():
+        z64 = ref64(x.double())
+    del ref64
+    err_hip, err_cpu = (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
+    n = _assert_masks(amax.cpu(), z32, z64, err_hip, err_cpu, "cfg4", max_ties=8)
+    print(f"cfg4 eval: |hip-f64| {err_hip:.2e} |cpu32-f64| {err_cpu:.2e}; differing (fp64-adjudicated tie) pixels: {n}")
 
 
 def test_cfg4_training_step_properties_at_full_size(cfg4):
@@ -344,7 +349,7 @@ def test_cfg4_training_step_properties_at_full_size(cfg4):
 
 # ------------------------------------------------------------------------------------------------ shipped default / SA
 
-def _sa_pair(arch, n_in, n_out, size, seed, x, blk_idx=5):
+def _sa_pair(arch, n_in, n_out, size, seed, x, blk_idx=5, condition=True):
     """fastai's default initialisation (activations stay O(1): with randomised BatchNorm statistics the norm-free decoder inflates
     them to 1e4 and the attention logits f^T g to 1e8, where ONE fp32 ulp is 8 and softmax is a coin toss for either
     implementation), BatchNorm gammas of the ResBlock tails opened, running statistics moved by one train-mode pass, gamma = 0.7
@@ -369,9 +374,10 @@ def _sa_pair(arch, n_in, n_out, size, seed, x, blk_idx=5):
         h = blk.conv2[1].register_forward_hook(lambda m, i, o: seen.__setitem__("a", float(o.abs().max())))
         ref(x)
         h.remove()
-        blk.conv2[0].weight.div_(seen["a"])
-        blk.conv2[0].bias.div_(seen["a"])
-        ref(x)                                      # running statistics downstream follow the new scale
+        if condition:
+            blk.conv2[0].weight.div_(seen["a"])
+            blk.conv2[0].bias.div_(seen["a"])
+            ref(x)                                  # running statistics downstream follow the new scale
     return ref
 
 
@@ -402,11 +408,12 @@ def test_shipped_default_400px_rgb_3class_self_attention_on():
     err = (z - z32).abs().max().item()
     print(f"shipped default eval: |hip-cpu32| {err:.2e} at scale {z32.abs().max().item():.2f}; attention logits up to {_attention_logit_scale(ref, x):.1f}")
     assert err < 1e-3
-    diff = amax.cpu() != z32.argmax(1)
-    top2 = z32.topk(2, dim=1).values
-    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
-    # training step: loss + every gradient against fp64 (incl. gamma and the spectral-normed projections)
     ref64 = copy.deepcopy(ref).double()
+    ref64.eval()
+    with torch.no_grad():
+        z64 = ref64(x.double())
+    _assert_masks(amax.cpu(), z32, z64, (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item(), "shipped default")
+    # training step: loss + every gradient against fp64 (incl. gamma and the spectral-normed projections)
     ref.train(); ref64.train(); model.train()
     w = torch.tensor([0.2, 0.5, 0.3])
     O.CrossEntropyLossFlat(weight=w)(ref(x), y).backward()
@@ -436,10 +443,11 @@ def test_self_attention_at_cfg2_size_4096_positions():
     err = (z - z32).abs().max().item()
     print(f"SA 4096 eval: |hip-cpu32| {err:.2e}; attention logits up to {_attention_logit_scale(ref, x):.1f}")
     assert err < 1e-3
-    diff = amax.cpu() != z32.argmax(1)
-    top2 = z32.topk(2, dim=1).values
-    assert int(diff.sum()) <= 2 and bool(((top2[:, 0] - top2[:, 1])[diff] <= 4 * err).all())
     ref64 = copy.deepcopy(ref).double()
+    ref64.eval()
+    with torch.no_grad():
+        z64 = ref64(x.double())
+    _assert_masks(amax.cpu(), z32, z64, (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item(), "SA 4096")
     ref.train(); ref64.train(); model.train()
     O.CrossEntropyLossFlat()(ref(x), y).backward()
     O.CrossEntropyLossFlat()(ref64(x.double()), y).backward()
@@ -448,3 +456,74 @@ def test_self_attention_at_cfg2_size_4096_positions():
     rows = [r for r in _grad_table(model, ref, ref64) if ".conv2.2." in r[0]]     # gamma, query / key / value weight_orig
     print("SA 4096 gradients (name, e_hip, e_cpu32):", [(r[0].split("conv2.2.")[1], f"{r[1]:.2e}", f"{r[2]:.2e}") for r in rows])
     assert len(rows) == 4 and all(r[1] <= max(2e-3, ENC_FACTOR * r[2]) for r in rows), rows
+
+
+
+def test_self_attention_at_the_unconditioned_scale_is_adjudicated_by_fp64():
+    """The two SA fixtures above scale the conv in front of the attention block so that the attention logits f^T g stay O(100).  Without
+    that step the norm-free decoder feeds activations of O(100) and the logits reach 1e4, where one fp32 ulp of a logit is 1e-3 in the
+    exponent of the softmax: two correct fp32 evaluations then differ visibly, and the question is only whether the HIP path is as close to
+    the truth as the fp32 CPU oracle is.  An fp64 run of the same oracle is the truth: the HIP logits must be no further from it than a
+    small multiple of the fp32 oracle's own distance."""
+    x, _ = O.synthetic_batch(1, 4, 512, 512, 5)
+    ref = _sa_pair("xresnet34", 4, 5, (512, 512), 31, x, condition=False)
+    _normalise_head(ref, x)
+    model = _hip_from(ref, "xresnet34", 4, 5, (512, 512), sa=True)
+    ref64 = copy.deepcopy(ref).double()
+    ref.eval(); ref64.eval(); model.eval()
+    with torch.no_grad():
+        z32, z64 = ref(x), ref64(x.double())
+        _, amax = model.predict_probs(x.cuda())
+        z = model(x.cuda()).cpu()
+    scale = _attention_logit_scale(ref, x)
+    e_hip, e_cpu = (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
+    r_hip, r_cpu = _rel_l2(z, z64), _rel_l2(z32, z64)
+    print(f"SA unconditioned: attention logits up to {scale:.0f}; max |hip-f64| {e_hip:.2e} |cpu32-f64| {e_cpu:.2e}; rel L2 hip {r_hip:.2e} cpu32 {r_cpu:.2e}")
+    assert scale > 1e3                                      # the fixture really is ill conditioned
+    assert r_hip <= 4.0 * r_cpu + 1e-7 and e_hip <= 6.0 * e_cpu + 1e-6
+    # masks against the fp64 decision: the HIP mask may be wrong only where fp32 cannot decide, and no more often than the fp32 oracle
+    am64 = z64.argmax(1)
+    top2 = z64.topk(2, dim=1).values
+    gap = top2[:, 0] - top2[:, 1]
+    wrong_hip, wrong_cpu = amax.cpu() != am64, z32.argmax(1) != am64
+    assert bool((gap[wrong_hip] <= 2.0 * max(e_hip, e_cpu)).all())
+    assert int(wrong_hip.sum()) <= 2 * int(wrong_cpu.sum()) + 4, (int(wrong_hip.sum()), int(wrong_cpu.sum()))
+
+
+def test_cfg4_smooth_network_every_gradient_at_1024():
+    """configs[3] geometry, ONE 1024 x 1024 xresnet50 tile, every pre-activation pushed far from zero (no ReLU can flip): the backward
+    KERNELS at their cfg4 shapes -- 2048- / 4096-channel bottleneck weight gradients, wgrad1x1 at 1024 x 1024, the 392-wide final ResBlock --
+    against the fp32 CPU oracle, per tensor.  Both sides are fp32, so the bar is a few fp32 roundings of a long reduction (up to 1024^2
+    pixels per weight): 5e-4 relative L2; tensors whose gradient is a sum cancelling to ~0 are skipped (the oracle cannot hit them either)."""
+    import torch.nn as nn
+    torch.manual_seed(7)
+    ref = O.DynamicUnet("xresnet50", 8, 10, (1024, 1024))
+    O.randomize_bn_and_zero_gammas(ref, seed=8)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.bias.fill_(8.0)
+            elif isinstance(m, nn.Conv2d) and m.bias is not None:
+                m.weight.mul_(0.01)
+                m.bias.fill_(1.0)
+    model = _hip_from(ref, "xresnet50", 8, 10, (1024, 1024))
+    x, y = O.synthetic_batch(1, 8, 1024, 1024, 10)
+    w = torch.rand(10) + 0.5
+    ref.train(); model.train()
+    l32 = O.CrossEntropyLossFlat(weight=w)(ref(x), y)
+    l32.backward()
+    loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l32.item()) <= 1e-5 * abs(l32.item())
+    rows = []
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        g, r = p.grad.cpu(), q.grad
+        # conditioning of the reduction: |sum| against the size of its terms is not available per term; the tensor's own largest entry
+        # against its mean magnitude separates the cancelling BatchNorm sums (entries ~1e-8 of ~1e-1 terms) from real gradients
+        rows.append((n, _rel_l2(g, r), float(r.abs().max())))
+    gmax = max(r[2] for r in rows)
+    live = [r for r in rows if r[2] > 1e-9 * gmax]
+    live.sort(key=lambda r: -r[1])
+    print(f"cfg4 smooth: {len(live)} of {len(rows)} tensors; worst {[(r[0], f'{r[1]:.2e}', f'{r[2]:.1e}') for r in live[:5]]}")
+    assert len(live) > 0.8 * len(rows)
+    assert all(r[1] <= 5e-4 for r in live), [r for r in live if r[1] > 5e-4][:5]

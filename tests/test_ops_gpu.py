@@ -158,6 +158,61 @@ def test_conv_fwd_slices_relu_res_colsum(ops):
     assert_close(cq_.sum(0).cpu(), (ref * ref).sum((0, 2, 3)), rtol=2e-4, atol=1e-2, what="colsumsq")
 
 
+SPLITK_CASES = [
+    # N, H, W, Cin, Cout, ks: small output grids with a long reduction (deep stages at small batch: cfg1, predict at batch 1)
+    (2, 8, 8, 512, 512, 3),          # xresnet18 layer 4 of a 256 x 256 tile, batch 2
+    (1, 16, 16, 1024, 512, 3),       # middle_conv
+    (2, 8, 8, 520, 200, 3),          # reduction tail (520 = 32 * 16 + 8), produced channels 128 + 72: two channel-range launches
+    (1, 16, 16, 2048, 100, 1),       # 1x1, 128 chunks, a sliver-width output (the split launch must not use the sliver image)
+    (3, 7, 9, 384, 36, 3),           # ragged pixel tile, 64-wide channel block
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv_splitk(ops, case):
+    """Split-K launches (unet_conv_desc.splitk_ws): the planner cuts the reduction of a small-grid launch into contiguous chunk ranges;
+    the slabs are added in split order and the fused epilogue (bias, residual, ReLU, mask) moves into the reduce kernel.  Against fp64
+    torch: as accurate as the unsplit launch or better (shorter accumulation chains); bit-reproducible; forward and input gradient."""
+    from unet_amd._lib import lib
+    N, H, W, Cin, Cout, ks = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    m = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2) + r.double()) * (m > 0)
+    xt, rt, mt = to_ts(x), to_ts(r, cs=Cout + 12, co=4), to_ts(m)
+    wp = ops.pack_weights(w.cuda(), 0)
+    outs, errs = [], []
+    for on in (1, 0, 1):
+        lib.unet_set_conv_splitk(on)
+        try:
+            yt = empty_ts(N, H, W, Cout, cs=Cout + 8 + (-Cout) % 4, co=8)
+            var = ops.conv2d_variant(xt, wp, yt, ks)
+            ops.conv2d(xt, wp, yt, ks, bias=b.cuda(), res=rt, mask=mt, relu=True)
+            torch.cuda.synchronize()
+        finally:
+            lib.unet_set_conv_splitk(1)
+        assert outside_untouched(yt)
+        got = from_ts(yt)
+        outs.append(got)
+        errs.append(((got.double() - ref).norm() / ref.norm()).item())
+        if Cout <= 128:
+            assert (var >= 2000000) == bool(on), (case, on, var)         # the planner splits exactly when allowed
+    assert torch.equal(outs[0], outs[2])
+    print(f"split-K {case}: rel L2 vs fp64 split {errs[0]:.2e} unsplit {errs[1]:.2e}")
+    assert errs[0] <= 3e-7 and errs[0] <= 1.2 * errs[1] + 2e-8
+    # input gradient of the same layer (reduction over Cout)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    refd = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy.double(), padding=ks // 2)
+    dxt = empty_ts(N, H, W, Cin)
+    ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(w.cuda(), 1), dxt, ks, 1)
+    torch.cuda.synchronize()
+    e = ((from_ts(dxt).double() - refd).norm() / refd.norm()).item()
+    assert e <= 6e-7, (case, e)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(ops, case):
     N, H, W, Cin, Cout, ks, stride = case

@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("cout_begin", C.c_int), ("cout_count", C.c_int),
         ("wp_img_stride", C.c_longlong),
         ("dtype", C.c_int), ("y_f32", C.c_int),
+        ("splitk_ws", vp), ("splitk_ws_floats", C.c_size_t),
     ]
 
 
@@ -92,6 +93,8 @@ _sig = {
     "unet_conv2d_colsum_rows": (i, [C.POINTER(ConvDesc)]),
     "unet_conv2d": (i, [C.POINTER(ConvDesc), vp]),
     "unet_conv2d_variant": (i, [C.POINTER(ConvDesc)]),
+    "unet_conv2d_splitk_workspace": (sz, [C.POINTER(ConvDesc)]),
+    "unet_set_conv_splitk": (i, [i]),
     "unet_set_mfma_shape": (i, [i]),
     "unet_set_wgrad_mfma_shape": (i, [i]),
     "unet_set_wgrad_narrow": (i, [i]),
@@ -165,7 +168,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 3:
+if lib.unet_abi_version() != 4:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 
@@ -177,3 +180,8 @@ def check(rc: int, what: str = "") -> None:
     if rc != UNET_OK:
         msg = lib.unet_last_error().decode(errors="replace")
         raise UnetHipError(f"{what}: rc={rc}: {msg}")
+
+
+# A/B knobs from the environment (measurements inside one gpurun call): UNET_CONV_SPLITK=0 switches the split-K planner off
+if os.environ.get("UNET_CONV_SPLITK") is not None:
+    lib.unet_set_conv_splitk(int(os.environ["UNET_CONV_SPLITK"]))

@@ -63,6 +63,9 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
     const int oy0 = ty_t * TH, ox0 = tx_t * TW;
     const int n0 = a.n_base + nt * BN;
+    // split-K: this workgroup reduces chunks [kc0, kc1) only and writes fp32 partial sums to slab blockIdx.y (conv_common.h, Plan)
+    const int kc0 = a.cps ? (int)blockIdx.y * a.cps : 0;
+    const int kc1 = a.cps ? (kc0 + a.cps < a.nchunks ? kc0 + a.cps : a.nchunks) : a.nchunks;
 
     const int S = a.S;
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
@@ -146,20 +149,20 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
     // reduction tail folded over the taps (conv_common.h, bf16_fold_tail): the last chunk runs ntail stages of four taps each
     const int fold = a.fold, last = a.nchunks - 1, ntail = (ntaps + 3) >> 2;
     const int fold_slab0 = 9 * a.nchunks;
-    LOAD_HALO(0, true);
-    LOAD_B(b0, (fold && last == 0) ? fold_slab0 : ts.widx[0] * a.nchunks);
+    LOAD_HALO(kc0, true);
+    LOAD_B(b0, (fold && last == 0) ? fold_slab0 : ts.widx[0] * a.nchunks + kc0);      // (a split launch never folds)
     wait_loads(b0, hreg);
-    STORE_HALO(halo_buf(0), 0);
+    STORE_HALO(halo_buf(kc0 & 1), kc0);
     __syncthreads();
 
-    int t = 0, chunk = 0;
-    const float* hb = halo_buf(0);
+    int t = 0, chunk = kc0;
+    const float* hb = halo_buf(kc0 & 1);
     // stage = (chunk, tap): the next stage's filter tiles (and, during the first tap of a chunk, the next chunk's halo items) are
     // issued at the top and waited for behind the stage's MFMAs; ONE wait asm per stage redefines every register a load writes
     constexpr int MH = M16 / 2;
     constexpr bool HALF_LOADS = M16 > 4;
 #define STAGE_BODY(bu_, bl_) do { \
-        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks); \
+        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < kc1); \
         LOAD_B(bl_, has_next_ ? ((fold && cn_ == last) ? fold_slab0 + tn_ : TAP_WIDX(tn_) * a.nchunks + cn_) : 0); \
         int aoff_; \
         if (fold && chunk == last) {   /* lane group kq reads channel group 0 of the tail chunk at ITS tap, 4 t + kq */ \
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
 #define STAGE(bu_, bl_) do { \
         int tn_ = t + 1, cn_ = chunk; \
         if (tn_ == ((fold && chunk == last) ? ntail : ntaps)) { tn_ = 0; cn_ = chunk + 1; } \
-        const bool has_next_ = cn_ < a.nchunks; \
+        const bool has_next_ = cn_ < kc1; \
         STAGE_BODY(bu_, bl_); \
         if (tn_ == 0 && has_next_) { \
             STORE_HALO(halo_buf(cn_ & 1), cn_); \
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
         t = tn_; chunk = cn_; \
     } while (0)
 
-    const int total = fold ? last * ntaps + ntail : a.nchunks * ntaps;
+    const int total = fold ? last * ntaps + ntail : (kc1 - kc0) * ntaps;
     for (int s = 0; s + 1 < total; s += 2) {
         STAGE(b0, b1);
         STAGE(b1, b0);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
                 for (int r = 0; r < 4; ++r) v[m][r] = mv[m][r] > 0.f ? v[m][r] : 0.f;
         }
         if (y_f32) {
-            float* yb = a.y + img_pix * a.y_cs + a.y_co;
+            float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
 #pragma unroll
             for (int m = 0; m < M16; ++m)
                 if (cvalid && pval[m] && m < m_hi) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
@@ -343,7 +346,7 @@ int plan_bf16(const unet_conv_desc* d, Plan* p) {
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
     p->lds_bytes = (size_t)(32 + 2 * p->max_hpix * LDKB) * sizeof(float);
-    p->k.fold = (p->nparity == 1 && bf16_fold_tail(d->Cin, d->ks * d->ks)) ? 1 : 0;
+    p->k.fold = (p->nparity == 1 && p->splits == 1 && bf16_fold_tail(d->Cin, d->ks * d->ks)) ? 1 : 0;
     UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
     UNET_CHECK_ARG(unet::aligned16(d->y) && (!d->res || unet::aligned16(d->res)) && (!d->mask || unet::aligned16(d->mask)),
                    "conv bf16: y/res/mask must be 16-byte aligned");
@@ -354,19 +357,37 @@ int plan_bf16(const unet_conv_desc* d, Plan* p) {
 
 namespace unetconv {
 
+// plan with split-K when the caller brought a workspace for it, else the plain plan
+static int plan_bf16_ws(const unet_conv_desc* d, Plan* p) {
+    int rc = plan_bf16(d, p);
+    if (rc != UNET_OK) return rc;
+    if (!splitk_redirect(d, p)) {
+        const int keep = g_splitk;
+        g_splitk = 0;
+        rc = plan_bf16(d, p);
+        g_splitk = keep;
+    }
+    return rc;
+}
+
+int plan_bf16_public(const unet_conv_desc* d, Plan* p) { return plan_bf16(d, p); }
+
 int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     Plan p;
-    int rc = plan_bf16(d, &p);
+    int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
-    if (p.hit == 6) return launch_bn<32, 6>(p, d->y_f32, st);
-    return (p.hit == 10) ? launch_tw<10>(p, d->y_f32, st) : launch_tw<4>(p, d->y_f32, st);
+    const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
+    if (p.hit == 6) rc = launch_bn<32, 6>(p, y_f32, st);
+    else rc = (p.hit == 10) ? launch_tw<10>(p, y_f32, st) : launch_tw<4>(p, y_f32, st);
+    if (rc != UNET_OK || p.splits <= 1) return rc;
+    return splitk_reduce(d, p, st);
 }
 
 int conv2d_bf16_variant(const unet_conv_desc* d) {
     Plan p;
-    int rc = plan_bf16(d, &p);
+    int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? 7 : 0);
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? 7 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
 
 }  // namespace unetconv

@@ -33,6 +33,8 @@ struct KArgs {
     int sliver;          // fp32 16x16x4 kernel: the last 1..4 output channels run on v_mfma_f32_4x4x1 (f32_sliver below)
     const float* wsl;    // its filter image [tap][chunk16][4][16]
     long long wp_stride; // floats between the packed filter images of consecutive batch images (0: one image for all)
+    int cps;             // split-K: reduction chunks per split (blockIdx.y = split index); 0 = the whole reduction in one workgroup
+    long long slab;      // split-K: elements between the partial-sum slabs of consecutive splits (y then points at slab 0)
     TapSet taps[4];
 };
 
@@ -226,7 +228,19 @@ struct Plan {
     int tw, bm, bn, hit, nparity, mf, max_hpix;
     size_t lds_bytes;
     dim3 grid;
+    // split-K (small grids with a long reduction): `splits` workgroups share one output tile, each reduces cps chunks into an fp32
+    // slab [split][pixel][cp] of the caller's workspace; splitk_reduce_kernel adds the slabs in split order and applies the epilogue
+    int splits, cp;
+    size_t ws_floats;
 };
+
+extern int g_splitk;      // unet_set_conv_splitk: 1 = the planner may split the reduction (default), 0 = never
+
+// one element of an activation tensor of either storage type (fp32 | bf16 bit pattern)
+__device__ __forceinline__ float ld_act(const float* p) { return *p; }
+__device__ __forceinline__ float ld_act(const unsigned short* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st_act(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_act(unsigned short* p, float v) { *p = __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 // kc: reduction channels per chunk (16 fp32 / 32 bf16 = 64 bytes); vec: channels per 16-byte access (4 fp32 / 8 bf16): channel
 // strides, offsets and the zero-padded channel count of a slice are multiples of vec; mf: MFMA shape of the fp32 kernels (16 | 32)
@@ -341,7 +355,28 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
         const int th_ = bm / p->tw;
         return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(cols, bn) * p->nparity;
     };
-    if (p->bn >= 64 && blocks(128, p->bn) < 400) {
+    // Split-K first: a grid that cannot fill the chip with full-size tiles although the reduction is long (deep low-resolution stages,
+    // small batches: BASELINE configs[0], predict at batch 1).  Instead of shrinking the tile -- fewer MACs per operand byte and still one
+    // long serial reduction per workgroup -- `splits` workgroups per output tile each take a contiguous range of reduction chunks.
+    // Partial sums meet in fixed order in the reduce kernel: deterministic, and the accumulation chain of an output element becomes
+    // `splits` chains of K / splits products (the fp32 MFMA sums one k-ordered chain: its rounding error grows like sqrt(K)).
+    p->splits = 1; p->cp = 0; p->ws_floats = 0;
+    if (g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8) {
+        const long long b = blocks(128, p->bn);
+        if (b < 256) {
+            int sp = (int)((384 + b - 1) / b);
+            if (sp > k.nchunks / 4) sp = k.nchunks / 4;
+            if (sp > 32) sp = 32;
+            if (sp >= 2) {
+                k.cps = unet::cdiv(k.nchunks, sp);
+                p->splits = unet::cdiv(k.nchunks, k.cps);
+                p->cp = unet::roundup(cols, 4);
+                k.slab = (long long)d->N * d->OH * d->OW * p->cp;
+                p->ws_floats = (size_t)p->splits * k.slab;
+            }
+        }
+    }
+    if (p->splits == 1 && p->bn >= 64 && blocks(128, p->bn) < 400) {
         p->bm = 64;
         if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
     }
@@ -375,20 +410,36 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // one filter image for all batch images, no column sums
     k.sliver = 0; k.wsl = nullptr;
     if (kc == 16 && p->mf == 16 && p->bm == 128 && p->bn == 128 && p->hit == 4 && p->nparity == 1 && f32_sliver(d->Cout) && k.n_end == d->Cout &&
-        d->wp_img_stride == 0 && d->colsum == nullptr && d->colsumsq == nullptr) {
+        d->wp_img_stride == 0 && d->colsum == nullptr && d->colsumsq == nullptr && p->splits == 1) {
         k.sliver = 1;
         k.wsl = d->wp + (size_t)T * k.nchunks * k.coutPad * 16;
         p->lds_bytes += (size_t)2 * 9 * 64 * sizeof(float);      // two chunk buffers at the kernel's fixed stride of 9 taps (a 1x1 filter uses one tap of each)
     }
     // (the 16x16x4 kernel remaps block ids XCD-aware and needs a multiple of 8; the surplus workgroups exit at once)
-    p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), 1, (unsigned)p->nparity);
+    p->grid = dim3((unsigned)unet::roundup((int)((long long)k.mtiles * k.ntn), p->mf == 16 ? 8 : 1), (unsigned)p->splits, (unsigned)p->nparity);
     UNET_CHECK_ARG((long long)k.mtiles * k.ntn < (1ll << 31), "conv: grid too large");
     return UNET_OK;
 }
 
 
+// Split-K launches: the kernels write plain partial sums (no bias / residual / activation / mask) into the workspace slabs; called by
+// both storage types after make_plan.  Returns false when the plan splits but the caller's workspace is missing or too small
+// (the planner then has to be re-run without splitting).
+static inline bool splitk_redirect(const unet_conv_desc* d, Plan* p) {
+    if (p->splits <= 1) return true;
+    if (d->splitk_ws == nullptr || d->splitk_ws_floats < p->ws_floats) return false;
+    KArgs& k = p->k;
+    k.bias = nullptr; k.res = nullptr; k.mask = nullptr; k.flags = 0;
+    k.y = d->splitk_ws - k.n_base;          // the kernels address channel c of a pixel as y[pixel * y_cs + y_co + c]: slab column 0 = n_base
+    k.y_cs = p->cp; k.y_co = 0;
+    return true;
+}
+// epilogue of a split launch (elementwise.hip): y = act(sum_s slab[s] + bias + res) masked, in split order
+int splitk_reduce(const unet_conv_desc* d, const Plan& p, hipStream_t st);
+
 // bf16-storage kernels (conv_bf16.hip), reached through unet_conv2d / unet_conv2d_variant with desc.dtype == UNET_BF16
 int conv2d_bf16(const unet_conv_desc* d, hipStream_t st);
 int conv2d_bf16_variant(const unet_conv_desc* d);
+int plan_bf16_public(const unet_conv_desc* d, Plan* p);
 
 }  // namespace unetconv

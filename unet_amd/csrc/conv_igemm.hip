@@ -327,6 +327,9 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
     const int oy0 = ty_t * TH, ox0 = tx_t * TW;
     const int n0 = a.n_base + nt * BN;
+    // split-K: this workgroup reduces chunks [kc0, kc1) only and writes its partial sums to slab blockIdx.y
+    const int kc0 = a.cps ? (int)blockIdx.y * a.cps : 0;
+    const int kc1 = a.cps ? (kc0 + a.cps < a.nchunks ? kc0 + a.cps : a.nchunks) : a.nchunks;
 
     const int S = a.S;
     const int HH = (TH - 1) * S + ts.ext_y, HW = (TW - 1) * S + ts.ext_x;
@@ -445,23 +448,23 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     const int ntaps = ts.n;
 #pragma unroll
     for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
-    LOAD_HALO(0, true);
-    LOAD_B(b0, ts.widx[0], 0);
+    LOAD_HALO(kc0, true);
+    LOAD_B(b0, ts.widx[0], kc0);
     WAIT_LOADS(b0);
-    STORE_HALO(halo_buf(0), 0);
+    STORE_HALO(halo_buf(kc0 & 1), kc0);
     __syncthreads();
 
     // Stage = (chunk, tap).  The loop body is written twice (operand B ping-pongs between b0 and b1 without register copies).
     // Loads in flight: the next stage's B tiles and, during the first tap of a chunk, the next chunk's halo items; both are
     // issued at the top of a stage and waited for at its end (behind the stage's 64 MFMAs).
-    int t = 0, chunk = 0;
-    int ksteps = a.Cin >= KC ? 4 : ((a.Cin + 3) >> 2);   // tail chunk: channel-transposed, step kk = channels 4kk..4kk+3
-    const float* hb = halo_buf(0);
+    int t = 0, chunk = kc0;
+    int ksteps = (a.Cin - kc0 * KC) >= KC ? 4 : ((a.Cin - kc0 * KC + 3) >> 2);   // tail chunk: channel-transposed, step kk = channels 4kk..4kk+3
+    const float* hb = halo_buf(kc0 & 1);
     // Every stage ends in ONE wait asm that (re)defines both the B tiles and the halo registers, on every path, so the
     // compiler has no merge point of its own between a load and its wait where it could copy a register that is still in
     // flight; tests/test_isa_cpu.py checks the generated ISA for exactly that.
 #define STAGE_BODY(bu_, bl_, FULL_) do { \
-        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < a.nchunks);   /* EXEC-masked off in the other stages */ \
+        LOAD_HALO(chunk + 1, t == 0 && chunk + 1 < kc1);   /* EXEC-masked off in the other stages */ \
         /* after the last stage: a dummy reload of slab 0 keeps the number of loads per stage fixed */ \
         LOAD_B(bl_, has_next_ ? TAP_WIDX(tn_) : 0, has_next_ ? cn_ : 0); \
         const float* ha_ = hb + TAP_OFF(t); \
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
 #define STAGE(bu_, bl_, FULL_) do { \
         int tn_ = t + 1, cn_ = chunk; \
         if (tn_ == ntaps) { tn_ = 0; cn_ = chunk + 1; } \
-        const bool has_next_ = cn_ < a.nchunks; \
+        const bool has_next_ = cn_ < kc1; \
         STAGE_BODY(bu_, bl_, FULL_); \
         if (tn_ == 0 && has_next_) { \
             STORE_HALO(halo_buf(cn_ & 1), cn_); \
@@ -510,8 +513,8 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
 
     // The stages of the full 16-channel chunks run first (an even number of them, so that the b0/b1 roles line up), with
     // compile-time 4 k-steps; the remaining stages -- the tail chunk when Cin % 16 != 0 -- run the guarded form.
-    const int total = a.nchunks * ntaps;
-    const int total_full = ((has_tail ? a.nchunks - 1 : a.nchunks) * ntaps) & ~1;
+    const int total = (kc1 - kc0) * ntaps;
+    const int total_full = (((has_tail && kc1 == a.nchunks) ? kc1 - kc0 - 1 : kc1 - kc0) * ntaps) & ~1;
     for (int s = 0; s < total_full; s += 2) {
         STAGE(b0, b1, true);
         STAGE(b1, b0, true);
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_igemm16_ke
     const bool relu = a.flags & UNET_CONV_RELU;
     const int OS = a.OS;
     const size_t img_pix = (size_t)img * a.OH * a.OW;
-    float* yb = a.y + img_pix * a.y_cs + a.y_co;
+    float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
     const float* resb = a.res ? a.res + img_pix * a.res_cs + a.res_co : nullptr;
     const float* maskb = a.mask ? a.mask + img_pix * a.mask_cs + a.mask_co : nullptr;
     // pixel indices of this lane's 4 accumulator rows for every M tile
@@ -701,6 +704,9 @@ __global__ void pack_weights_strided_kernel(const float* __restrict__ w, long lo
 
 // MFMA shape of the conv kernels: 16 = v_mfma_f32_16x16x4_f32 with per-tile skipping (default), 32 = v_mfma_f32_32x32x2_f32
 static int g_mfma_shape = 16;
+}  // namespace
+namespace unetconv { int g_splitk = 1; }
+namespace {
 
 static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_plan(d, p, KC, 4, g_mfma_shape); }
 
@@ -762,7 +768,11 @@ int launch_tw(const Plan& p, hipStream_t st) {
 
 extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
     Plan p;
+    // the plan of the launch that WILL carry the column-sum pointers (they may still be null in this query): never split
+    const int keep = unetconv::g_splitk;
+    unetconv::g_splitk = 0;
     int rc = make_plan(d, &p);
+    unetconv::g_splitk = keep;
     if (rc != UNET_OK) return rc;
     const int wm = (p.bn == 32 && p.bm == 128) ? 4 : 2;
     return p.nparity * p.k.mtiles * wm;
@@ -774,22 +784,112 @@ extern "C" int unet_set_mfma_shape(int shape) {
     return UNET_OK;
 }
 
+static int make_plan_ws(const unet_conv_desc* d, Plan* p);
+
 extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16_variant(d);
     Plan p;
-    int rc = make_plan(d, &p);
+    int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0);
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
+}
+
+// ------------------------------------------------------------------ split-K epilogue
+// y[p][c] = mask(act(sum_s slab[s][p][c] + bias[c] + res[p][c])): the slabs are added in split order (deterministic), four channels per
+// thread (16-byte slab reads; 16-byte fp32 / 8-byte bf16 stores).  HBM-bound: splits x the output once in, the output once out.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long slab, long long P, int cols,
+                                                            int cp, const float* __restrict__ bias, const T* __restrict__ res, int res_cs,
+                                                            int res_co, const T* __restrict__ mask, int mask_cs, int mask_co,
+                                                            T* __restrict__ y, int y_cs, int y_co, int relu) {
+    const int q4 = cp >> 2;
+    const long long total = P * q4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / q4;
+        const int c = 4 * (int)(i - p * q4);
+        float4 v = *reinterpret_cast<const float4*>(ws + p * cp + c);
+        for (int s = 1; s < splits; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(ws + (size_t)s * slab + p * cp + c);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = c + r < cols;
+            float t = live ? o[r] : 0.f;
+            if (live && bias != nullptr) t += bias[c + r];
+            if (live && res != nullptr) t += unetconv::ld_act(res + (size_t)p * res_cs + res_co + c + r);
+            if (relu) t = fmaxf(t, 0.f);
+            if (live && mask != nullptr) t = unetconv::ld_act(mask + (size_t)p * mask_cs + mask_co + c + r) > 0.f ? t : 0.f;
+            o[r] = t;
+        }
+        T* yo = y + (size_t)p * y_cs + y_co + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c + r < cols) unetconv::st_act(yo + r, o[r]);
+    }
+}
+}  // namespace
+
+int unetconv::splitk_reduce(const unet_conv_desc* d, const Plan& p, hipStream_t st) {
+    const long long P = (long long)d->N * d->OH * d->OW;
+    const int cols = p.k.n_end - p.k.n_base, nb = p.k.n_base;
+    const int relu = (d->flags & UNET_CONV_RELU) ? 1 : 0;
+    const float* bias = d->bias ? d->bias + nb : nullptr;
+    const void* mask = (d->flags & UNET_CONV_MASK) ? (const void*)d->mask : nullptr;
+    const int grid = unet::ew_grid(P * (p.cp >> 2), 256);
+    if (d->dtype == UNET_BF16 && !d->y_f32) {
+        typedef unsigned short T;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, st, d->splitk_ws, p.splits, p.k.slab, P, cols, p.cp, bias,
+                           (const T*)d->res, d->res_cs, d->res_co + nb, (const T*)mask, d->mask_cs, d->mask_co + nb, (T*)d->y, d->y_cs,
+                           d->y_co + nb, relu);
+    } else {
+        // (bf16 storage with fp32 logits: residual / mask operands of such a launch would be bf16 -- the head has neither)
+        UNET_CHECK_ARG(d->dtype == UNET_F32 || (d->res == nullptr && mask == nullptr), "split-K: fp32 output with bf16 residual / mask");
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, st, d->splitk_ws, p.splits, p.k.slab, P, cols, p.cp, bias,
+                           (const float*)d->res, d->res_cs, d->res_co + nb, (const float*)mask, d->mask_cs, d->mask_co + nb, (float*)d->y,
+                           d->y_cs, d->y_co + nb, relu);
+    }
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+// plan with split-K when the caller brought a workspace for it, else the plain plan
+static int make_plan_ws(const unet_conv_desc* d, Plan* p) {
+    int rc = make_plan(d, p);
+    if (rc != UNET_OK) return rc;
+    if (!unetconv::splitk_redirect(d, p)) {
+        const int keep = unetconv::g_splitk;
+        unetconv::g_splitk = 0;
+        rc = make_plan(d, p);
+        unetconv::g_splitk = keep;
+    }
+    return rc;
 }
 
 extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16(d, (hipStream_t)stream);
     UNET_CHECK_ARG(d == nullptr || d->dtype == UNET_F32, "conv: unknown dtype %d", d->dtype);
     Plan p;
-    int rc = make_plan(d, &p);
+    int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
+    rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
+    if (rc != UNET_OK || p.splits <= 1) return rc;
+    return unetconv::splitk_reduce(d, p, st);
+}
+
+extern "C" size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d) {
+    Plan p;
+    if (d == nullptr) return 0;
+    const int rc = d->dtype == UNET_BF16 ? unetconv::plan_bf16_public(d, &p) : make_plan(d, &p);
+    return rc == UNET_OK ? p.ws_floats : 0;
+}
+
+extern "C" int unet_set_conv_splitk(int on) {
+    unetconv::g_splitk = on ? 1 : 0;
+    return UNET_OK;
 }
 
 extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {

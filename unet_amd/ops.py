@@ -183,7 +183,25 @@ class ConvProbe:
 CONV_PROBE: Optional[ConvProbe] = None
 
 
+# Scratch for split-K conv launches (unet_conv_desc.splitk_ws): one fp32 buffer per device, grown on demand, reused by every launch
+# (stream ordered).  It reaches its final size during the eager warm-up steps, so a captured step sees a static address.
+_SPLITK_WS = {}
+
+
+def _splitk_ws(d: ConvDesc):
+    need = int(lib.unet_conv2d_splitk_workspace(C.byref(d)))
+    if need == 0:
+        d.splitk_ws, d.splitk_ws_floats = None, 0
+        return
+    dev = torch.cuda.current_device()
+    buf = _SPLITK_WS.get(dev)
+    if buf is None or buf.numel() < need:
+        buf = _SPLITK_WS[dev] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=f"cuda:{dev}")
+    d.splitk_ws, d.splitk_ws_floats = buf.data_ptr(), buf.numel()
+
+
 def _launch_conv_part(d: ConvDesc, what: str, alg_flops: float):
+    _splitk_ws(d)
     pr = CONV_PROBE
     if pr is not None and lib.unet_conv2d_variant(C.byref(d)) == pr.variant:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -228,7 +246,9 @@ def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, 
 
 def conv2d_variant(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, kind: int = 0) -> int:
     """id of the kernel instantiation the planner picks for this launch (unet_conv2d_variant; scripts/layer_table.py, tests)"""
-    return int(lib.unet_conv2d_variant(C.byref(_conv_desc(x, wp, y, ks, stride, kind))))
+    d = _conv_desc(x, wp, y, ks, stride, kind)
+    _splitk_ws(d)
+    return int(lib.unet_conv2d_variant(C.byref(d)))
 
 
 def conv2d_dgrad(dy: TS, wp_dgrad: torch.Tensor, dx: TS, ks: int, stride: int = 1, res=None, mask=None, colsum=None):
