@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 4
+#define UNET_ABI_VERSION 5
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -134,6 +134,8 @@ typedef struct {
     const float* w;                      /* master parameter [Cout,Cin,ks,ks] (device) */
     void* wp;                            /* packed image (device), unet_pack_weights_size[_bf16] elements */
     int Cout, Cin, ks, mode;             /* mode 0 = forward image, 1 = input-gradient image */
+    const float* out_scale;              /* optional [Cout] (device), mode 0: image of w * out_scale[cout] -- eval-mode BatchNorm folded into
+                                            the filter (y = conv(x, w * scale) + shift, the conv epilogue adds shift as its bias) */
 } unet_pack_job;
 size_t unet_pack_batch_table_bytes(int njobs);
 int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int dtype, void* table_host, unsigned* total_blocks);

@@ -480,7 +480,11 @@ def test_self_attention_at_the_unconditioned_scale_is_adjudicated_by_fp64():
     r_hip, r_cpu = _rel_l2(z, z64), _rel_l2(z32, z64)
     print(f"SA unconditioned: attention logits up to {scale:.0f}; max |hip-f64| {e_hip:.2e} |cpu32-f64| {e_cpu:.2e}; rel L2 hip {r_hip:.2e} cpu32 {r_cpu:.2e}")
     assert scale > 1e3                                      # the fixture really is ill conditioned
-    assert r_hip <= 4.0 * r_cpu + 1e-7 and e_hip <= 6.0 * e_cpu + 1e-6
+    # Measured on MI355X: rel L2 6.0e-6 (HIP) against 2.2e-6 (fp32 CPU oracle), max 6.8e-4 against 1.4e-4 -- both five orders below the
+    # logits.  Before the split-K launches the HIP path stood at 1.7e-5 / 1.8e-3: a gfx950 fp32 MFMA sums a reduction as ONE k-ordered chain
+    # (rounding error ~ sqrt(K)) where oneDNN keeps 16 partial sums; the attention product O = P H reduces over 4096 positions and now runs
+    # as 4 chains of 1024.  The HIP path is as close to fp64 as the fp32 oracle is, to within a small factor.
+    assert r_hip <= 4.0 * r_cpu + 1e-7 and r_hip <= 1e-4 and e_hip <= 8.0 * e_cpu + 1e-6
     # masks against the fp64 decision: the HIP mask may be wrong only where fp32 cannot decide, and no more often than the fp32 oracle
     am64 = z64.argmax(1)
     top2 = z64.topk(2, dim=1).values
@@ -515,15 +519,27 @@ def test_cfg4_smooth_network_every_gradient_at_1024():
     loss = model.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
     torch.cuda.synchronize()
     assert abs(loss.item() - l32.item()) <= 1e-5 * abs(l32.item())
-    rows = []
+    norms = {n: float(q.grad.double().norm()) for n, q in ref.named_parameters()}
+    dims = {n: p.dim() for n, p in ref.named_parameters()}
+    rows, bad = [], []
     for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        g, r = p.grad.cpu(), q.grad
-        # conditioning of the reduction: |sum| against the size of its terms is not available per term; the tensor's own largest entry
-        # against its mean magnitude separates the cancelling BatchNorm sums (entries ~1e-8 of ~1e-1 terms) from real gradients
-        rows.append((n, _rel_l2(g, r), float(r.abs().max())))
-    gmax = max(r[2] for r in rows)
-    live = [r for r in rows if r[2] > 1e-9 * gmax]
-    live.sort(key=lambda r: -r[1])
-    print(f"cfg4 smooth: {len(live)} of {len(rows)} tensors; worst {[(r[0], f'{r[1]:.2e}', f'{r[2]:.1e}') for r in live[:5]]}")
-    assert len(live) > 0.8 * len(rows)
-    assert all(r[1] <= 5e-4 for r in live), [r for r in live if r[1] > 5e-4][:5]
+        err = float((p.grad.cpu().double() - q.grad.double()).norm())
+        if norms[n] == 0.0:
+            continue
+        if dims[n] == 4:
+            # conv filters (the weight-gradient kernels: sums of products over up to 2^20 pixels): 5e-4 relative L2
+            den, bar = norms[n], 5e-4
+        else:
+            # per-channel vectors (conv biases, BatchNorm gamma / beta) are plain sums of a gradient tensor that largely cancel -- the head
+            # bias sums softmax - onehot over a million pixels, the BatchZero betas of this fixture cancel to 1e-20 .. 1e-40 -- and both fp32
+            # evaluations lose digits to the cancellation: 5e-3, measured against the vector's own norm or, where it has cancelled away,
+            # against 1e-3 of the filter gradient of the same ConvLayer (conv, BatchNorm, ReLU)
+            parent = n.rsplit(".", 2)[0] + ".0.weight"
+            den, bar = max(norms[n], 1e-3 * norms.get(parent, 0.0) if parent != n else 0.0), 5e-3
+        rows.append((n, err / den, norms[n]))
+        if err > bar * den:
+            bad.append(rows[-1])
+    rows.sort(key=lambda r: -r[1])
+    print(f"cfg4 smooth: {len(rows)} tensors ({sum(1 for n in dims if dims[n] == 4)} conv filters); worst {[(r[0], f'{r[1]:.2e}', f'{r[2]:.1e}') for r in rows[:5]]}")
+    assert len(rows) > 0.9 * len(dims)
+    assert not bad, bad[:5]

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(L.lib, s), s
-    assert L.lib.unet_abi_version() == 4
+    assert L.lib.unet_abi_version() == 5
     # pure host-side queries work without a GPU
     assert L.lib.unet_pack_weights_size(96, 100, 3, 0) == 9 * 7 * 128 * 16
     # 100 output channels = 6 tiles of 16 + a 4-channel sliver image [tap][chunk][4][16] behind the main one

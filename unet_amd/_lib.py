@@ -62,7 +62,7 @@ class WgradDesc(C.Structure):
 
 
 class PackJob(C.Structure):
-    _fields_ = [("w", vp), ("wp", vp), ("Cout", C.c_int), ("Cin", C.c_int), ("ks", C.c_int), ("mode", C.c_int)]
+    _fields_ = [("w", vp), ("wp", vp), ("Cout", C.c_int), ("Cin", C.c_int), ("ks", C.c_int), ("mode", C.c_int), ("out_scale", vp)]
 
 
 def declared_symbols() -> list[str]:
@@ -168,7 +168,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 4:
+if lib.unet_abi_version() != 5:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 

@@ -361,22 +361,31 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // Partial sums meet in fixed order in the reduce kernel: deterministic, and the accumulation chain of an output element becomes
     // `splits` chains of K / splits products (the fp32 MFMA sums one k-ordered chain: its rounding error grows like sqrt(K)).
     p->splits = 1; p->cp = 0; p->ws_floats = 0;
-    if (g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8) {
-        const long long b = blocks(128, p->bn);
-        if (b < 256) {
-            int sp = (int)((384 + b - 1) / b);
-            if (sp > k.nchunks / 4) sp = k.nchunks / 4;
-            if (sp > 32) sp = 32;
-            if (sp >= 2) {
-                k.cps = unet::cdiv(k.nchunks, sp);
-                p->splits = unet::cdiv(k.nchunks, k.cps);
-                p->cp = unet::roundup(cols, 4);
-                k.slab = (long long)d->N * d->OH * d->OW * p->cp;
-                p->ws_floats = (size_t)p->splits * k.slab;
-            }
+    bool split = false;
+    if (g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8 && blocks(128, p->bn) < 256) {
+        // at least two chunks per split; when even the deepest split of full-size tiles leaves most CUs idle (a handful of pixel tiles:
+        // 8 x 8 stages at batch 2), the tile shrinks as well
+        const int smax = k.nchunks / 2 < 32 ? k.nchunks / 2 : 32;
+        if (p->bn >= 64 && blocks(128, p->bn) * smax < 384) {
+            p->bm = 64;
+            if (p->bn == 128 && blocks(64, 128) * smax < 384) p->bn = 64;
+        }
+        const long long b = blocks(p->bm, p->bn);
+        int sp = (int)((384 + b - 1) / b);
+        if (sp > smax) sp = smax;
+        if (sp >= 2) {
+            split = true;
+            k.cps = unet::cdiv(k.nchunks, sp);
+            p->splits = unet::cdiv(k.nchunks, k.cps);
+            p->cp = unet::roundup(cols, 4);
+            k.slab = (long long)d->N * d->OH * d->OW * p->cp;
+            p->ws_floats = (size_t)p->splits * k.slab;
+        } else {
+            p->bm = 128;
+            p->bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
         }
     }
-    if (p->splits == 1 && p->bn >= 64 && blocks(128, p->bn) < 400) {
+    if (!split && p->bn >= 64 && blocks(128, p->bn) < 400) {
         p->bm = 64;
         if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
     }

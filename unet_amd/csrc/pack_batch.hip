@@ -12,13 +12,14 @@
 
 namespace {
 
-struct Job {                 // == unet_pack_job_table entry (48 bytes)
+struct Job {                 // == unet_pack_job_table entry (56 bytes)
     const float* w;
     void* wp;
+    const float* scale;      // optional per-output-channel factor (eval-mode BatchNorm folded into the forward image), mode 0 only
     int Cout, Cin, T, mode, nchunks, outPad;
     unsigned block_begin, pad_;
 };
-static_assert(sizeof(Job) == 48, "job table entry size");
+static_assert(sizeof(Job) == 56, "job table entry size");
 
 constexpr int ELEMS_PER_BLOCK = 2048;
 
@@ -40,13 +41,19 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
     for (int k = 0; k < ELEMS_PER_BLOCK / 256; ++k) {
         const size_t i = base + threadIdx.x + k * 256;
         if (i >= total) break;
+        const bool scaled = j.scale != nullptr && j.mode == 0;
         if (bf16) {
-            reinterpret_cast<unsigned short*>(j.wp)[i] =
-                __builtin_bit_cast(unsigned short, (__bf16)unetconv::bf16_image_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, j.outPad, i));
+            float v = unetconv::bf16_image_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, j.outPad, i);
+            const int o = (int)((i >> 5) % j.outPad);
+            if (scaled && o < j.Cout) v *= j.scale[o];          // fp32 product, ONE rounding to bf16
+            reinterpret_cast<unsigned short*>(j.wp)[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
             continue;
         }
         if (i >= main_f32) {          // the fp32 sliver image behind the main one
-            reinterpret_cast<float*>(j.wp)[i] = unetconv::f32_sliver_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, i - main_f32);
+            float v = unetconv::f32_sliver_value(j.w, j.Cout, j.Cin, j.T, j.mode, j.nchunks, i - main_f32);
+            const int o = (out & ~15) + (int)(((i - main_f32) >> 4) & 3);
+            if (scaled && o < j.Cout) v *= j.scale[o];
+            reinterpret_cast<float*>(j.wp)[i] = v;
             continue;
         }
         const int rr = (int)(i & (KC - 1));
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
         const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         float v = 0.f;
         if (j.mode == 0) {
-            if (o < j.Cout && r < j.Cin) v = j.w[((size_t)o * j.Cin + r) * j.T + tap];
+            if (o < j.Cout && r < j.Cin) v = j.w[((size_t)o * j.Cin + r) * j.T + tap] * (scaled ? j.scale[o] : 1.f);
         } else {
             if (o < j.Cin && r < j.Cout) v = j.w[((size_t)r * j.Cin + o) * j.T + tap];
         }
@@ -82,7 +89,7 @@ extern "C" int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int d
                        "pack_batch_build: bad job %d", i);
         const int red = s.mode == 0 ? s.Cin : s.Cout, out = s.mode == 0 ? s.Cout : s.Cin;
         Job& j = t[i];
-        j.w = s.w; j.wp = s.wp; j.Cout = s.Cout; j.Cin = s.Cin; j.T = s.ks * s.ks; j.mode = s.mode;
+        j.w = s.w; j.wp = s.wp; j.scale = s.out_scale; j.Cout = s.Cout; j.Cin = s.Cin; j.T = s.ks * s.ks; j.mode = s.mode;
         j.nchunks = unet::cdiv(red, KC); j.outPad = unet::roundup(out, 128);
         j.block_begin = (unsigned)blocks; j.pad_ = 0;
         const size_t total = dtype == UNET_BF16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : unetconv::f32_image_elems(red, out, j.T);

@@ -14,6 +14,7 @@ C-ABI launches (``unet_amd/modules.py``), so a whole step can be captured in a h
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -39,6 +40,11 @@ class _Marker(nn.Module):
 
 
 class HipDynamicUnet(nn.Module):
+    # eval-mode forward: every BatchNorm that follows a conv is folded into that conv's packed filter (w * gamma / sqrt(var + eps)) and its
+    # epilogue bias (beta - mean * scale), residual add and ReLU included: north_star's "Conv + BN + ReLU fused".  False keeps the separate
+    # BatchNorm-apply pass (A/B and tests); the training path always normalises with batch statistics in its own kernels.
+    fold_eval_bn = os.environ.get("UNET_FOLD_BN", "1") != "0"
+
     def __init__(self, arch: str, n_in: int, n_out: int, img_size: Sequence[int] = (512, 512), self_attention: bool = False,
                  device="cuda", act_dtype: str = "f32"):
         """act_dtype "f32": the parity path (the reference computes in fp32).  "bf16": bf16 storage of activations, activation
@@ -153,41 +159,27 @@ class HipDynamicUnet(nn.Module):
     # ------------------------------------------------------------------ packed filter images
     def _pack_all(self, training: bool):
         """Rebuild every stale packed filter image in ONE launch (unet_pack_batch_run).  The parameters are rewritten by every
-        optimizer step, so in training this runs once per step for all 52 convs x (forward, input-gradient) images."""
-        import ctypes as C
-        from . import _lib as L
+        optimizer step, so in training this runs once per step for all 52 convs x (forward, input-gradient) images.  In eval mode
+        (ctx.fold_bn) the forward image of a conv that is followed by a BatchNorm is w * scale[cout] (eval coefficients, cached)."""
         cxs = [m.cx for m in self.modules() if isinstance(getattr(m, "cx", None), _ConvExec)]
-        stale = []
+        jobs, marks = [], []
         for cx in cxs:
             cx.ensure_buffers(training)
             ver = cx.version()
             if cx._ver_f != ver:
-                stale.append((cx, 0))
+                jobs.append((cx.conv.weight.data, cx.wp_f, 0, cx.fold_scale()))
+                marks.append((cx, 0, ver))
             if training and cx._ver_d != ver:
-                stale.append((cx, 1))
-        if not stale:
+                jobs.append((cx.conv.weight.data, cx.wp_d, 1, None))
+                marks.append((cx, 1, ver))
+        if not jobs:
             return
-        # the cached job table holds raw addresses: a re-pointed parameter or a re-allocated image must not hit an old table
-        key = tuple((id(cx), mode, cx.conv.weight.data_ptr(), (cx.wp_f if mode == 0 else cx.wp_d).data_ptr()) for cx, mode in stale)
-        ent = self._pack_tables.get(key)
-        if ent is None:
-            jobs = (L.PackJob * len(stale))()
-            for j, (cx, mode) in zip(jobs, stale):
-                w = cx.conv.weight
-                j.w, j.wp = w.data_ptr(), (cx.wp_f if mode == 0 else cx.wp_d).data_ptr()
-                j.Cout, j.Cin, j.ks, j.mode = w.shape[0], w.shape[1], w.shape[2], mode
-            dt = L.BF16 if self.ctx.act_dtype == torch.bfloat16 else L.F32
-            host = torch.zeros(int(L.lib.unet_pack_batch_table_bytes(len(stale))), dtype=torch.uint8)
-            blocks = C.c_uint(0)
-            L.check(L.lib.unet_pack_batch_build(jobs, len(stale), dt, host.data_ptr(), C.byref(blocks)), "pack_batch_build")
-            ent = self._pack_tables[key] = (host.to(self._device), len(stale), int(blocks.value), dt)
-        table, n, blocks, dt = ent
-        L.check(L.lib.unet_pack_batch_run(table.data_ptr(), n, blocks, dt, ops._stream()), "pack_batch_run")
-        for cx, mode in stale:
+        ops.pack_jobs(jobs, self.ctx.act_dtype == torch.bfloat16, self._device, self._pack_tables)
+        for cx, mode, ver in marks:
             if mode == 0:
-                cx._ver_f = cx.version()
+                cx._ver_f = ver
             else:
-                cx._ver_d = cx.version()
+                cx._ver_d = ver
 
     def param_span(self, p: nn.Parameter) -> Tuple[int, int]:
         return self._param_offsets[id(p)]
@@ -227,6 +219,7 @@ class HipDynamicUnet(nn.Module):
             raise ValueError("bf16 storage mode needs tile sides divisible by 32 (no nearest-resize kernels in bf16)")
         ctx = self.ctx
         ctx.training = training
+        ctx.fold_bn = bool(self.fold_eval_bn) and not training     # eval: Conv + BN + ReLU = ONE launch (BatchNorm folded into filter + bias)
         self._pack_all(training and ctx.need_grad)
         L = self.layers
         enc: Encoder = L[0]

@@ -53,6 +53,10 @@ class Ctx:
         # bumped whenever parameter memory is rewritten behind torch's back (HIP Adam step, all-reduce ...):
         # packed filter images older than this epoch are rebuilt
         self.weights_epoch = 0
+        # bumped whenever BatchNorm running statistics move (a training-mode forward): cached eval coefficients and folded filter
+        # images are older than this epoch
+        self.bn_epoch = 0
+        self.fold_bn = False                # this forward folds eval-mode BatchNorms into the conv in front of them
 
     # activations are keyed by (owner id, tag, shape): allocated once per input geometry
     def act(self, owner, tag, N, H, W, C, zero=False, dtype=None) -> TS:
@@ -153,24 +157,33 @@ class _ConvExec:
         self._ver_f = None
         self._ver_d = None
         self.ctx: Optional["Ctx"] = None   # set by HipDynamicUnet once the tree is built
+        self.fold: Optional["_BNExec"] = None       # the BatchNorm that follows this conv (ConvLayer with norm), folded in eval mode
+
+    def fold_scale(self) -> Optional[torch.Tensor]:
+        """per-output-channel factor of the forward image: the eval-mode BatchNorm scale when this forward folds it, else None"""
+        if self.fold is None or self.ctx is None or not self.ctx.fold_bn:
+            return None
+        return self.fold.coeffs(self.ctx, None)[0]
 
     def packed(self, mode: int) -> torch.Tensor:
-        w = self.conv.weight
-        ver = (w._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
-        dt = torch.float32 if self.ctx is None else self.ctx.act_dtype
+        ver = self.version()
         if mode == 0:
             if self.wp_f is None or self._ver_f != ver:
-                self.wp_f = ops.pack_weights(w.data, 0, self.wp_f, dtype=dt)
+                self.ensure_buffers(False)
+                ops.pack_jobs([(self.conv.weight.data, self.wp_f, 0, self.fold_scale())], self.wp_f.dtype == torch.bfloat16, self.wp_f.device)
                 self._ver_f = ver
             return self.wp_f
         if self.wp_d is None or self._ver_d != ver:
-            self.wp_d = ops.pack_weights(w.data, 1, self.wp_d, dtype=dt)
+            self.ensure_buffers(True)
+            ops.pack_jobs([(self.conv.weight.data, self.wp_d, 1, None)], self.wp_d.dtype == torch.bfloat16, self.wp_d.device)
             self._ver_d = ver
         return self.wp_d
 
     def version(self):
         w = self.conv.weight
-        return (w._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
+        c = self.ctx
+        folded = c is not None and c.fold_bn and self.fold is not None
+        return (w._version, w.data_ptr(), 0 if c is None else c.weights_epoch, c.bn_epoch if folded else -1)
 
     def ensure_buffers(self, with_dgrad: bool):
         """the persistent packed-image buffers (HipDynamicUnet packs all of them in one launch: unet_pack_batch_run)"""
@@ -236,8 +249,15 @@ class _BNExec:
             mean, invstd = ctx.vec(self, "mean", C_), ctx.vec(self, "invstd", C_)
             ops.bn_finalize(ps, pq, rows, P, C_, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
                             BN_MOM, BN_EPS, scale, shift, mean, invstd, bn.num_batches_tracked)
+            ctx.bn_epoch += 1               # running statistics moved: eval coefficients / folded filters are stale
+            self._eval_key = None
         else:
-            ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, BN_EPS, scale, shift)
+            # eval coefficients depend on the parameters and the running statistics only: one launch per change, not per forward
+            key = (ctx.weights_epoch, ctx.bn_epoch, bn.weight.data_ptr(), bn.running_mean.data_ptr(), bn.weight._version, bn.bias._version,
+                   bn.running_mean._version, bn.running_var._version)
+            if getattr(self, "_eval_key", None) != key:
+                ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, BN_EPS, scale, shift)
+                self._eval_key = key
         return scale, shift
 
     def bwd(self, ctx: Ctx, dout: TS, out: Optional[TS], x: TS, dx: TS, gout: Optional[TS] = None, g_accumulate=False):
@@ -284,12 +304,16 @@ class ConvLayer(nn.Sequential):
         self.has_bn, self.has_act = bn, act
         self.cx = _ConvExec(conv)
         self.bx = _BNExec(self[1]) if bn else None
+        self.cx.fold = self.bx
         self.nf = nf
 
     # ---- encoder flavour: conv -> BN -> [ReLU]; returns the materialised activation
     def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
         OH, OW = self.cx.out_hw(x.H, x.W)
-        if self.has_bn:
+        if self.has_bn and ctx.fold_bn:      # eval: conv(x, w * scale) + shift [-> ReLU] in ONE launch
+            a = ctx.act(self, "a", x.N, OH, OW, self.nf)
+            self.fold_fwd(ctx, x, a)
+        elif self.has_bn:
             y = ctx.act(self, "y", x.N, OH, OW, self.nf)
             scale, shift = self._conv_bn(ctx, x, y)
             a = ctx.act(self, "a", x.N, OH, OW, self.nf)
@@ -299,6 +323,11 @@ class ConvLayer(nn.Sequential):
             self.cx.fwd(x, a, relu=self.has_act)
         ctx.saved[(id(self), "x")] = x
         return a
+
+    def fold_fwd(self, ctx: Ctx, x: TS, out: TS, res: Optional[TS] = None, relu: Optional[bool] = None):
+        """eval mode: out = act(conv(x, w * scale) + shift [+ res]); the filter image carries the BatchNorm scale (model._pack_all)"""
+        _, shift = self.bx.coeffs(ctx, None)
+        ops.conv2d(x, self.cx.packed(0), out, self.cx.ks, self.cx.stride, bias=shift, res=res, relu=self.has_act if relu is None else relu)
 
     def raw_fwd(self, ctx: Ctx, x: TS) -> Tuple[TS, torch.Tensor, torch.Tensor]:
         """conv + BN statistics only (the affine is applied by the caller, fused with the residual add)."""
@@ -382,11 +411,20 @@ class ResBlock(nn.Module):
         h = x
         for cl in list(self.convpath)[:-1]:
             h = cl.hip_fwd(ctx, h)
-        y2, s2, b2 = self.convpath[-1].raw_fwd(ctx, h)
         p = x
         if self.pool:
             p = ctx.act(self, "pool", x.N, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
             ops.avgpool(x, p)
+        if ctx.fold_bn:         # eval: both BatchNorms folded; out = relu(conv_last(h) + shift + idpath(x)) is the last conv's epilogue
+            last: ConvLayer = self.convpath[-1]
+            res = p
+            if self.idconv is not None:
+                res = ctx.act(self.idconv, "a", p.N, p.H, p.W, self.nf)
+                self.idconv.fold_fwd(ctx, p, res, relu=False)
+            out = ctx.act(self, "out", res.N, res.H, res.W, self.nf)
+            last.fold_fwd(ctx, h, out, res=res, relu=True)
+            return out
+        y2, s2, b2 = self.convpath[-1].raw_fwd(ctx, h)
         out = ctx.act(self, "out", y2.N, y2.H, y2.W, self.nf)
         if self.idconv is not None:
             yi, si, bi = self.idconv.raw_fwd(ctx, p)
@@ -820,6 +858,7 @@ class Encoder(nn.Sequential):
         new_conv = nn.Conv2d(c_in, 32, kernel_size=3, stride=2, padding=1, bias=False)
         self[0][0] = new_conv
         self[0].cx = _ConvExec(new_conv)
+        self[0].cx.fold = self[0].bx
         self.out_channels = block_szs[-1] * expansion
         # DynamicUnet hooks the children whose output is larger than the next child's: the last stem conv (before the max-pool) and
         # every stage but the last (each later stage starts with a stride-2 block)

@@ -122,6 +122,32 @@ def pack_weights(w: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None,
     return out
 
 
+def pack_jobs(jobs, bf16: bool, device, cache: Optional[dict] = None):
+    """Packed filter images of several convs in ONE launch (unet_pack_batch_run).  jobs: [(w [Cout,Cin,ks,ks] fp32 master parameter, packed
+    image tensor, mode 0 | 1, out_scale [Cout] fp32 or None)].  The device job table holds raw addresses: `cache` (a dict owned by the
+    caller) keeps tables keyed by every address in them."""
+    if not jobs:
+        return
+    key = tuple((w.data_ptr(), wp.data_ptr(), mode, 0 if sc is None else sc.data_ptr()) for w, wp, mode, sc in jobs) + (bf16,)
+    ent = None if cache is None else cache.get(key)
+    if ent is None:
+        arr = (L.PackJob * len(jobs))()
+        for j, (w, wp, mode, sc) in zip(arr, jobs):
+            assert w.is_contiguous() and w.dtype == torch.float32 and (sc is None or (sc.dtype == torch.float32 and sc.numel() >= w.shape[0]))
+            j.w, j.wp = w.data_ptr(), wp.data_ptr()
+            j.Cout, j.Cin, j.ks, j.mode = w.shape[0], w.shape[1], w.shape[2], mode
+            j.out_scale = None if sc is None else sc.data_ptr()
+        dt = L.BF16 if bf16 else L.F32
+        host = torch.zeros(int(lib.unet_pack_batch_table_bytes(len(jobs))), dtype=torch.uint8)
+        blocks = C.c_uint(0)
+        check(lib.unet_pack_batch_build(arr, len(jobs), dt, host.data_ptr(), C.byref(blocks)), "pack_batch_build")
+        ent = (host.to(device), len(jobs), int(blocks.value), dt)
+        if cache is not None:
+            cache[key] = ent
+    table, n, blocks, dt = ent
+    check(lib.unet_pack_batch_run(table.data_ptr(), n, blocks, dt, _stream()), "pack_batch_run")
+
+
 def pack_weights_strided(w_base_ptr: int, so: int, sr: int, O: int, R: int, out: torch.Tensor) -> torch.Tensor:
     """packed 1x1 filter image whose (out o, reduction r) element is the float at w_base_ptr + 4*(o*so + r*sr)"""
     assert out.numel() >= lib.unet_pack_weights_size(O, R, 1, 0)
