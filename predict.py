@@ -345,19 +345,35 @@ class _TilePrefetcher:
         return buf
 
     def _work(self):
+        # tile files are decoded by a small pool (file read, strip copies and the band de-interleave release the GIL), `depth` batches ahead
+        from concurrent.futures import ThreadPoolExecutor
         try:
-            for first, n in self.batches:
-                arrs = [_as_samples(open_tile(self.tiles[first + j])) for j in range(n)]
-                a0 = arrs[0]
-                tdt = _torch_samples(a0[:0]).dtype
-                buf = self._buf((a0.shape, tdt), (self.n_pad,) + a0.shape, tdt)
-                for j, a in enumerate(arrs):
-                    buf[j].copy_(_torch_samples(a))
-                self.q.put((first, n, buf))
+            workers = max(2, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)))
+        except OSError:
+            workers = 4
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                load = lambda path: np.ascontiguousarray(_as_samples(open_tile(path)))
+                pending, nxt = [], 0
+                for bi, (first, n) in enumerate(self.batches):
+                    while nxt < len(self.batches) and nxt <= bi + self.depth:
+                        f0, n0 = self.batches[nxt]
+                        pending.append([ex.submit(load, self.tiles[f0 + j]) for j in range(n0)])
+                        nxt += 1
+                    arrs = [f.result() for f in pending.pop(0)]
+                    self._emit(first, n, arrs)
             self.q.put(None)
         except BaseException as e:      # noqa: BLE001  (surfaces in the consumer)
             self.err = e
             self.q.put(None)
+
+    def _emit(self, first, n, arrs):
+        a0 = arrs[0]
+        tdt = _torch_samples(a0[:0]).dtype
+        buf = self._buf((a0.shape, tdt), (self.n_pad,) + a0.shape, tdt)
+        for j, a in enumerate(arrs):
+            buf[j].copy_(_torch_samples(a))
+        self.q.put((first, n, buf))
 
     def __iter__(self):
         while True:

@@ -485,14 +485,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
     // row stride and its column / channel validity does not change.  The per-item offsets are set up once per strip; the in-loop
     // prefetch then costs a few adds per item instead of re-deriving (pixel, channel quad) from the thread index -- measured by
     // switching the in-loop loads off: 7.53 -> 6.60 ms per 100->100 launch, i.e. their ADDRESS ARITHMETIC, not their bytes, cost 12 %.
-    int dyo[DIT], xo[RIT];          // element offsets inside the image row block (dy: row oy, x: row iy), -1 = never valid
+    // Element offsets inside the image row block (dy: row oy, x: row iy).  An item that is never valid (a channel quad beyond the real
+    // channels: 3 of 28 for 100 channels; a pixel beyond the row) keeps the offset of the NEAREST VALID item -- the last real quad of its
+    // own pixel, the last pixel of the row -- with the bits inverted (negative = select zero).  Round 2 sent all of them to ONE address
+    // (offset 0 of the row / the first pixel of the image): 11 % of all lanes of every load instruction hammered a single cache line and
+    // the fabric read traffic of the 100 -> 100 launch rose from 8.1 to 10.0 GB (profiles/r02_b vs r02_a; the 96-channel instantiation,
+    // which has no invalid quads, did not move).  The clamped address is one a neighbouring lane loads anyway: no request of its own.
+    int dyo[DIT], xo[RIT];
     auto strip_setup = [&](const TilePos& t) {
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
             const int e = tid + it * 256;
             const int p = e / Q, q = e - p * Q;
             const bool ok = (e < PT * Q) && (t.ox0 + p) < a.OW && 4 * q < a.Cout4;
-            dyo[it] = ok ? (t.ox0 + p) * a.dy_cs + 4 * q : -1;
+            const int pc = (t.ox0 + p) < a.OW ? t.ox0 + p : a.OW - 1, qc = 4 * q < a.Cout4 ? 4 * q : a.Cout4 - 4;
+            const int off = pc * a.dy_cs + qc;
+            dyo[it] = ok ? off : ~off;
         }
 #pragma unroll
         for (int j = 0; j < RIT; ++j) {
@@ -500,27 +508,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
             const int hx = e / Q, q = e - hx * Q;
             const int ix = t.ox0 - 1 + hx;
             const bool ok = (e < HW * Q) && ix >= 0 && ix < a.IW && 4 * q < cw4;
-            xo[j] = ok ? ix * a.x_cs + 4 * q : -1;
+            const int ixc = ix < 0 ? 0 : (ix < a.IW ? ix : a.IW - 1), qc = 4 * q < cw4 ? 4 * q : cw4 - 4;
+            const int off = ixc * a.x_cs + qc;
+            xo[j] = ok ? off : ~off;
         }
     };
     // the tile one row below `t` (same strip): dy row t.oy + 1 ... = nx.oy, input row nx.oy + 1
     auto prefetch_rolling = [&](const TilePos& nx, float4 (&rdy)[DIT], float4 (&rxr)[RIT]) {
         const float* dyrow = nx.dyb;                                            // already points at image row nx.oy
         const int iy = nx.oy + 1;
-        const float* xrow = nx.xb + (size_t)iy * a.IW * a.x_cs;
         const bool rowok = iy < a.IH;                                           // (iy >= 0 always: nx.oy >= 1)
+        const float* xrow = nx.xb + (size_t)(rowok ? iy : a.IH - 1) * a.IW * a.x_cs;       // below the image: the last row's lines, zero selected
         // unconditional loads from a clamped address + select: a conditional load is a branch around it (8 exec-mask branches per tile)
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
             const bool ok = dyo[it] >= 0;
-            const float4 v = *reinterpret_cast<const float4*>(dyrow + (ok ? dyo[it] : 0));
+            const float4 v = *reinterpret_cast<const float4*>(dyrow + (ok ? dyo[it] : ~dyo[it]));
             rdy[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < RIT; ++j) {
-            const bool ok = rowok && xo[j] >= 0;
-            const float4 v = *reinterpret_cast<const float4*>(ok ? xrow + xo[j] : nx.xb);       // nx.xb: first pixel of the image, always mapped
-            rxr[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = xo[j] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(xrow + (ok ? xo[j] : ~xo[j]));
+            rxr[j] = (ok && rowok) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
