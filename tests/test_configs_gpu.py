@@ -81,7 +81,10 @@ def _grad_table(model, ref, ref64):
 # Both are far inside north_star's 1e-3 logit bar; the gradient inherits the ratio: measured e_hip / e_cpu32 is ~2 in the decoder
 # and 4-9 in the deep encoder (K up to 9216 and few pixels per channel).  Hence: decoder tail absolute bar; everywhere else the HIP
 # gradient may be at most ENC_FACTOR x as far from fp64 as the fp32 CPU oracle is on the same tensor, and never beyond ENC_CAP.
-ENC_FACTOR, ENC_CAP = 12.0, 5e-2
+# Round 3: the deep stages at small batch now run as split-K launches (chains of K / splits products, partial sums added in fixed order):
+# the forward error of the K = 4608 / 9216 layers dropped from 6.3e-7 / 9.4e-7 to 2.2e-7 / 2.4e-7 against fp64 (oneDNN: 2.5e-7), and the measured
+# gradient ratios e_hip / e_cpu32 with it -- cfg2 max 3.2 (was 3.7), cfg1 3.9 (was 8.6), shipped default 3.3 -- so the factor is 5, not 12.
+ENC_FACTOR, ENC_CAP = 5.0, 3e-2
 
 
 def _check_grads(rows, tail_from, tail_bar, what):
