@@ -888,7 +888,7 @@ extern "C" size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d) {
 }
 
 extern "C" int unet_set_conv_splitk(int on) {
-    unetconv::g_splitk = on ? 1 : 0;
+    unetconv::g_splitk = on < 0 ? 0 : on;       // 0 off, 1 default threshold, n > 1: split launches of fewer than n full-size tiles (tuning knob)
     return UNET_OK;
 }
 
