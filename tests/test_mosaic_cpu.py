@@ -113,3 +113,81 @@ def test_arbitrary_tile_sets_are_sorted_and_batched_by_size():
     plan = MergePlan(places[o], 164, 128, 1)
     assert plan.batches(0, 16) == [(0, 4), (4, 1)]                              # the 32 x 32 tile cannot share a launch with 64 x 64 ones
     assert plan.batches(0, 3) == [(0, 3), (3, 1), (4, 1)]
+
+
+# ------------------------------------------------------------------------------------------------ the exchange itself, two gloo ranks on the CPU
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _exchange_worker(rank, world, port, q):
+    """what the ranks of predict._Merge do between the forward passes and the finalisation, with the device kernels replaced by numpy:
+    slabs travel through predict._exchange (isend / irecv pair), strips through predict._Merge._gather_rows (send / recv to rank 0)"""
+    import os
+    import types
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import predict as P
+    H, W, size, C = 1500, 700, 512, 3
+    wins = sliding_windows(H, W, size, 0.2)
+    places = np.concatenate([wins, np.full((len(wins), 2), size)], axis=1)
+    g = np.random.default_rng(5)
+    probs = [g.random((C, size, size), dtype=np.float32) for _ in places]           # the same "predictions" on both ranks
+    plan = MergePlan(places, H, W, world)
+    lo, hi = plan.own[rank]
+    m, c = np.zeros((C, hi - lo, W), np.float32), np.zeros((hi - lo, W), np.int32)
+    a, b = plan.ranges[rank]
+    for i in range(a, b):
+        y, x, h, w = plan.places[i]
+        r0, r1 = max(y, lo), min(y + h, hi)
+        if r1 > r0:
+            m[:, r0 - lo:r1 - lo, x:x + w] += probs[i][:, r0 - y:r1 - y]
+            c[r0 - lo:r1 - lo, x:x + w] += 1
+    send = None
+    if plan.slabs(rank):
+        send = torch.from_numpy(np.concatenate([probs[i][:, :rows].ravel() for i, rows in plan.slabs(rank)]))
+    nrecv = plan.slab_floats(rank + 1, C) if rank + 1 < plan.active else 0
+    got = P._exchange(send if rank > 0 else None, rank - 1, nrecv, rank + 1, torch.float32, "cpu")
+    if got is not None:
+        off = 0
+        for i, rows in plan.slabs(rank + 1):
+            y, x, h, w = plan.places[i]
+            slab = got[off:off + C * rows * w].view(C, rows, w).numpy()
+            off += C * rows * w
+            m[:, y - lo:y - lo + rows, x:x + w] += slab
+            c[y - lo:y - lo + rows, x:x + w] += 1
+    m[:, c > 0] /= c[c > 0]
+    me = types.SimpleNamespace(plan=plan, rank=rank, world=world, lo=lo, hi=hi, C=C, dev="cpu")
+    full = P._Merge._gather_rows(me, torch.from_numpy(m.argmax(0).astype(np.uint8)), False)
+    allc = P._Merge._gather_rows(me, torch.from_numpy(m), True)
+    if rank == 0:
+        rm = np.zeros((C, H, W), np.float32); rc = np.zeros((H, W), np.int32)
+        for (y, x, h, w), p in zip(places, probs):
+            rm[:, y:y + h, x:x + w] += p
+            rc[y:y + h, x:x + w] += 1
+        rm[:, rc > 0] /= rc[rc > 0]
+        q.put((rank, bool(np.array_equal(full, rm.argmax(0).astype(np.uint8))), bool(np.array_equal(allc, rm))))
+    else:
+        q.put((rank, full is None, allc is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_exchange_and_strip_gather_two_gloo_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True), (1, True, True)], res
