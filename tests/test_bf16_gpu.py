@@ -226,7 +226,9 @@ def test_elementwise_twins_bf16():
     mean, invstd = x.mean((0, 2, 3)).cuda(), (1.0 / (x.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()).cuda()
     dout = _bf(torch.randn(N, C, H, W, generator=g)); out = _bf(torch.randn(N, C, H, W, generator=g))
     ops.bn_bwd_reduce(_ts(dout), _ts(out), _ts(x), mean, invstd, pa); ops.bn_bwd_reduce(f32(dout), f32(out), f32(x), mean, invstd, pb)
-    assert torch.equal(pa, pb)
+    # (the bf16 entry point reduces 8 channels per thread: the same fp32 terms, grouped into the partial rows differently)
+    sa, sb = pa.view(2, rows, C).double().sum(1), pb.view(2, rows, C).double().sum(1)
+    assert (sa - sb).abs().max().item() <= 1e-5 * sb.abs().max().item()
     c1, c2, gam = torch.randn(C, generator=g).cuda() * 0.1, torch.randn(C, generator=g).cuda() * 0.1, torch.rand(C, generator=g).cuda() + 0.5
     da, db = _empty(N, H, W, C), _empty(N, H, W, C, dtype=torch.float32)
     ga, gb = _empty(N, H, W, C), _empty(N, H, W, C, dtype=torch.float32)

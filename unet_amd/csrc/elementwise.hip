@@ -11,6 +11,7 @@
 // and predict.py:193-232.
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdarg.h>
 
 #include "common.h"
@@ -75,6 +76,35 @@ struct QuadWalk {
     }
 };
 
+// N consecutive elements (N * sizeof(T) a multiple of 16 bytes, 16-byte aligned) <-> floats
+template <int N> __device__ __forceinline__ void ldn(const float* p, float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k += 4) { const float4 t = ld4(p + k); v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w; }
+}
+template <int N> __device__ __forceinline__ void ldn(const unet_bf16* p, float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k += 8) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + k);
+        v[k] = __uint_as_float(u.x << 16); v[k + 1] = __uint_as_float(u.x & 0xffff0000u);
+        v[k + 2] = __uint_as_float(u.y << 16); v[k + 3] = __uint_as_float(u.y & 0xffff0000u);
+        v[k + 4] = __uint_as_float(u.z << 16); v[k + 5] = __uint_as_float(u.z & 0xffff0000u);
+        v[k + 6] = __uint_as_float(u.w << 16); v[k + 7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+}
+template <int N> __device__ __forceinline__ void stn(float* p, const float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k += 4) st4(p + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+}
+template <int N> __device__ __forceinline__ void stn(unet_bf16* p, const float (&v)[N]) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int k = 0; k < N; k += 8) {
+        const bf16x8 h = {(__bf16)v[k], (__bf16)v[k + 1], (__bf16)v[k + 2], (__bf16)v[k + 3], (__bf16)v[k + 4], (__bf16)v[k + 5], (__bf16)v[k + 6], (__bf16)v[k + 7]};
+        *reinterpret_cast<uint4*>(p + k) = __builtin_bit_cast(uint4, h);
+    }
+}
+
+
 // --------------------------------------------------------------------------
 // Per-channel reduction over pixels.  F(p, c4) -> two float4 values; result
 // planes out0[rows][Cp], out1[rows][Cp] (one row per workgroup).
@@ -122,6 +152,12 @@ __device__ __forceinline__ void channel_reduce(F f, long long P, int C4, int TC,
         }
         __syncthreads();
     }
+}
+
+// bf16 8-channel (16-byte) forms of the BatchNorm apply / backward kernels; UNET_EW_OCT=0 keeps the quad forms (A/B inside one process)
+static bool use_oct() {
+    static const int on = [] { const char* e = getenv("UNET_EW_OCT"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
+    return on != 0;
 }
 
 static int pick_tc(int C4) {
@@ -334,6 +370,150 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             st4(gp, g_acc ? (ld4(gp) + g) : g);
         }
     }
+}
+
+// ---- bf16 storage, 8 channels (16 bytes) per access: the quad forms above move 8 bytes per lane with bf16 tensors, i.e. twice the
+// load / store instructions per byte of the fp32 path they were written for (bn_bwd_reduce ran SLOWER in bf16 than in fp32 at 16 x 256^2 x 64).
+// Same arithmetic per element; used when every channel count / stride / offset involved is a multiple of 8.
+__global__ __launch_bounds__(256) void affine_act_oct_kernel(const unet_bf16* __restrict__ x, int x_cs, int x_co, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const unet_bf16* __restrict__ x2, int x2_cs,
+                                                             int x2_co, const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                             unet_bf16* __restrict__ y, int y_cs, int y_co, long long P, int C8, int relu) {
+    for (QuadWalk w(C8); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 8 * w.c4;
+        float v[8];
+        ldn<8>(x + (size_t)p * x_cs + x_co + c, v);
+        if (scale != nullptr) {
+            float sc[8], sh[8];
+            ldn<8>(scale + c, sc); ldn<8>(shift + c, sh);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+        }
+        if (x2 != nullptr) {
+            float u[8];
+            ldn<8>(x2 + (size_t)p * x2_cs + x2_co + c, u);
+            if (scale2 != nullptr) {
+                float sc[8], sh[8];
+                ldn<8>(scale2 + c, sc); ldn<8>(shift2 + c, sh);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = u[k] * sc[k] + sh[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] + u[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        stn<8>(y + (size_t)p * y_cs + y_co + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_oct_kernel(const unet_bf16* __restrict__ dout, int d_cs, int d_co,
+                                                               const unet_bf16* __restrict__ out, int o_cs, int o_co,
+                                                               const unet_bf16* __restrict__ x, int x_cs, int x_co,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ c1,
+                                                               const float* __restrict__ c2, unet_bf16* __restrict__ dx, int dx_cs, int dx_co,
+                                                               unet_bf16* gout, int g_cs, int g_co, int g_acc, long long P, int C8) {
+    for (QuadWalk w(C8); w.p < P; w.next()) {
+        const long long p = w.p;
+        const int c = 8 * w.c4;
+        float g[8], xv[8], mu[8], is[8], gm[8], a1[8], a2[8], r[8];
+        ldn<8>(dout + (size_t)p * d_cs + d_co + c, g);
+        if (out != nullptr) {
+            float o[8];
+            ldn<8>(out + (size_t)p * o_cs + o_co + c, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+        }
+        ldn<8>(x + (size_t)p * x_cs + x_co + c, xv);
+        ldn<8>(mean + c, mu); ldn<8>(invstd + c, is); ldn<8>(c1 + c, a1); ldn<8>(c2 + c, a2);
+        if (gamma) ldn<8>(gamma + c, gm);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            r[k] = (gamma ? gm[k] : 1.f) * is[k] * (g[k] - a1[k] - xh * a2[k]);
+        }
+        stn<8>(dx + (size_t)p * dx_cs + dx_co + c, r);
+        if (gout != nullptr) {
+            unet_bf16* gp = gout + (size_t)p * g_cs + g_co + c;
+            if (g_acc) {
+                float old[8];
+                ldn<8>(gp, old);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = old[k] + g[k];
+            }
+            stn<8>(gp, g);
+        }
+    }
+}
+
+// channel_reduce with 8 channels per thread (tx = channel oct): out0 / out1 rows of Cp floats as in the quad form
+template <typename F>
+__device__ __forceinline__ void channel_reduce8(F f, long long P, int C8, int TC, float* out0, float* out1, int Cp) {
+    __shared__ float sm0[256 * 8];
+    __shared__ float sm1[256 * 8];
+    const int tx = threadIdx.x % TC, ty = threadIdx.x / TC, PY = 256 / TC;
+    for (int cbase = 0; cbase < C8; cbase += TC) {
+        const int c8 = cbase + tx;
+        float s0[8], s1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+        if (c8 < C8) {
+            const long long step = (long long)gridDim.x * PY;
+            long long p = (long long)blockIdx.x * PY + ty;
+            for (; p + step < P; p += 2 * step) {          // two pixels per trip: six independent 16-byte loads in flight
+                float a0[8], b0[8], a1[8], b1[8];
+                f(p, c8, a0, b0);
+                f(p + step, c8, a1, b1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s0[k] += a0[k] + a1[k]; s1[k] += b0[k] + b1[k]; }
+            }
+            for (; p < P; p += step) {
+                float a0[8], b0[8];
+                f(p, c8, a0, b0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s0[k] += a0[k]; s1[k] += b0[k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sm0[k * 256 + threadIdx.x] = s0[k]; sm1[k * 256 + threadIdx.x] = s1[k]; }
+        __syncthreads();
+        if (ty == 0 && c8 < C8) {
+            for (int j = 1; j < PY; ++j) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s0[k] += sm0[k * 256 + j * TC + tx]; s1[k] += sm1[k * 256 + j * TC + tx]; }
+            }
+            stn<8>(out0 + (size_t)blockIdx.x * Cp + 8 * c8, s0);
+            if (out1 != nullptr) stn<8>(out1 + (size_t)blockIdx.x * Cp + 8 * c8, s1);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_oct_kernel(const unet_bf16* __restrict__ dout, int d_cs, int d_co,
+                                                                const unet_bf16* __restrict__ out, int o_cs, int o_co,
+                                                                const unet_bf16* __restrict__ x, int x_cs, int x_co,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                long long P, int C8, int TC, float* out0, float* out1, int Cp) {
+    channel_reduce8(
+        [&](long long p, int c8, float (&v0)[8], float (&v1)[8]) {
+            float xv[8], mu[8], is[8];
+            ldn<8>(dout + (size_t)p * d_cs + d_co + 8 * c8, v0);
+            if (out != nullptr) {
+                float o[8];
+                ldn<8>(out + (size_t)p * o_cs + o_co + 8 * c8, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v0[k] = o[k] > 0.f ? v0[k] : 0.f;
+            }
+            ldn<8>(x + (size_t)p * x_cs + x_co + 8 * c8, xv);
+            ldn<8>(mean + 8 * c8, mu); ldn<8>(invstd + 8 * c8, is);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v1[k] = v0[k] * ((xv[k] - mu[k]) * is[k]);
+        },
+        P, C8, TC, out0, out1, Cp);
 }
 
 // ------------------------------------------------------------------ pooling
@@ -552,34 +732,6 @@ __global__ __launch_bounds__(256) void shuffle_blur_bwd_kernel(const T* __restri
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int V = 4; };
 template <> struct VecOf<unet_bf16> { static constexpr int V = 8; };
-
-// N consecutive elements (N * sizeof(T) a multiple of 16 bytes, 16-byte aligned) <-> floats
-template <int N> __device__ __forceinline__ void ldn(const float* p, float (&v)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; k += 4) { const float4 t = ld4(p + k); v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w; }
-}
-template <int N> __device__ __forceinline__ void ldn(const unet_bf16* p, float (&v)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; k += 8) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p + k);
-        v[k] = __uint_as_float(u.x << 16); v[k + 1] = __uint_as_float(u.x & 0xffff0000u);
-        v[k + 2] = __uint_as_float(u.y << 16); v[k + 3] = __uint_as_float(u.y & 0xffff0000u);
-        v[k + 4] = __uint_as_float(u.z << 16); v[k + 5] = __uint_as_float(u.z & 0xffff0000u);
-        v[k + 6] = __uint_as_float(u.w << 16); v[k + 7] = __uint_as_float(u.w & 0xffff0000u);
-    }
-}
-template <int N> __device__ __forceinline__ void stn(float* p, const float (&v)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; k += 4) st4(p + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
-}
-template <int N> __device__ __forceinline__ void stn(unet_bf16* p, const float (&v)[N]) {
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-    for (int k = 0; k < N; k += 8) {
-        const bf16x8 h = {(__bf16)v[k], (__bf16)v[k + 1], (__bf16)v[k + 2], (__bf16)v[k + 3], (__bf16)v[k + 4], (__bf16)v[k + 5], (__bf16)v[k + 6], (__bf16)v[k + 7]};
-        *reinterpret_cast<uint4*>(p + k) = __builtin_bit_cast(uint4, h);
-    }
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void shuffle_blur_vec_kernel(const T* __restrict__ yc, int yc_cs, int yc_co, T* __restrict__ X, int X_cs,
@@ -1043,6 +1195,8 @@ static int bn_stats_impl(const T* x, int x_cs, int x_co, long long P, int C, flo
     UNET_CHECK_ARG(x && partial && P > 0 && C > 0 && (C & 3) == 0, "bn_stats: bad args (C must be a multiple of 4)");
     UNET_CHECK_ARG(unet::slice_ok(x_cs, x_co, C), "bn_stats: bad slice");
     const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
+    // (an 8-channel form of this ONE-tensor reduction measured slower than the quad form -- 24 vs 14 us at 16 x 256^2 x 32: half the threads
+    //  per pixel row, and the quad form already keeps four loads in flight -- so the statistics pass stays as it is in both storage types)
     hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, P, C4, TC, partial, partial + (size_t)rows * C, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
@@ -1079,6 +1233,15 @@ static int affine_act_impl(const T* x, int x_cs, int x_co, const float* scale, c
     UNET_CHECK_ARG((scale == nullptr && scale2 == nullptr) || (C & 3) == 0, "affine_act: per-channel vectors need C % 4 == 0");
     if (x2) UNET_CHECK_ARG(pslice_ok(x2_cs, x2_co, C), "affine_act: bad x2 slice");
     const int C4 = c4of(C);
+    if constexpr (sizeof(T) == 2) {
+        if (use_oct() && C % 8 == 0 && x_cs % 8 == 0 && x_co % 8 == 0 && y_cs % 8 == 0 && y_co % 8 == 0 && (!x2 || (x2_cs % 8 == 0 && x2_co % 8 == 0)) &&
+            unet::aligned16(x) && unet::aligned16(y) && (!x2 || unet::aligned16(x2))) {
+            hipLaunchKernelGGL(affine_act_oct_kernel, dim3(ew_grid(P * (C / 8), 256)), dim3(256), 0, ST, x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co,
+                               scale2, shift2, y, y_cs, y_co, P, C / 8, relu);
+            UNET_CHECK_LAUNCH();
+            return UNET_OK;
+        }
+    }
     hipLaunchKernelGGL((affine_act_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, scale, shift, x2, x2_cs, x2_co, scale2,
                        shift2, y, y_cs, y_co, P, C4, relu);
     UNET_CHECK_LAUNCH();
@@ -1098,6 +1261,15 @@ static int bn_bwd_reduce_impl(const T* dout, int d_cs, int d_co, const T* out, i
     UNET_CHECK_ARG(unet::slice_ok(d_cs, d_co, C) && unet::slice_ok(x_cs, x_co, C), "bn_bwd_reduce: bad slice");
     if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_reduce: bad out slice");
     const int rows = stats_rows(P), C4 = C / 4, TC = pick_tc(C4);
+    if constexpr (sizeof(T) == 2) {
+        if (use_oct() && C % 8 == 0 && d_cs % 8 == 0 && d_co % 8 == 0 && x_cs % 8 == 0 && x_co % 8 == 0 && (!out || (o_cs % 8 == 0 && o_co % 8 == 0)) &&
+            unet::aligned16(dout) && unet::aligned16(x) && (!out || unet::aligned16(out))) {
+            hipLaunchKernelGGL(bn_bwd_reduce_oct_kernel, dim3(rows), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd,
+                               P, C / 8, pick_tc(C / 8), partial, partial + (size_t)rows * C, C);
+            UNET_CHECK_LAUNCH();
+            return UNET_OK;
+        }
+    }
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co, mean, invstd, P,
                        C4, TC, partial, partial + (size_t)rows * C, C);
     UNET_CHECK_LAUNCH();
@@ -1127,6 +1299,16 @@ static int bn_bwd_apply_impl(const T* dout, int d_cs, int d_co, const T* out, in
     if (out) UNET_CHECK_ARG(unet::slice_ok(o_cs, o_co, C), "bn_bwd_apply: bad out slice");
     if (gout) UNET_CHECK_ARG(unet::slice_ok(g_cs, g_co, C), "bn_bwd_apply: bad gout slice");
     const int C4 = C / 4;
+    if constexpr (sizeof(T) == 2) {
+        if (use_oct() && C % 8 == 0 && d_cs % 8 == 0 && d_co % 8 == 0 && x_cs % 8 == 0 && x_co % 8 == 0 && dx_cs % 8 == 0 && dx_co % 8 == 0 &&
+            (!out || (o_cs % 8 == 0 && o_co % 8 == 0)) && (!gout || (g_cs % 8 == 0 && g_co % 8 == 0)) && unet::aligned16(dout) && unet::aligned16(x) &&
+            unet::aligned16(dx) && (!out || unet::aligned16(out)) && (!gout || unet::aligned16(gout))) {
+            hipLaunchKernelGGL(bn_bwd_apply_oct_kernel, dim3(ew_grid(P * (C / 8), 256)), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs,
+                               x_co, mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C / 8);
+            UNET_CHECK_LAUNCH();
+            return UNET_OK;
+        }
+    }
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, dout, d_cs, d_co, out, o_cs, o_co, x, x_cs, x_co,
                        mean, invstd, gamma, c1, c2, dx, dx_cs, dx_co, gout, g_cs, g_co, g_accumulate, P, C4);
     UNET_CHECK_LAUNCH();
