@@ -350,6 +350,8 @@ int unet_avgpool2_ceil_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y
 int unet_avgpool2_ceil_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
 int unet_shuffle_blur_bf16(const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* X, int X_cs, int X_co, int N, int h, int w, int Cu, int do_blur, void* stream);
 int unet_shuffle_blur_bwd_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+int unet_resize_nearest_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW, int C, void* stream);
+int unet_resize_nearest_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int OH, int OW, int C, void* stream);
 int unet_nchw_to_nhwc_bf16(const float* x, unet_bf16* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream);
 int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate, void* stream);
 int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream);

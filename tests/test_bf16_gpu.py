@@ -336,6 +336,43 @@ def test_bf16_training_step_against_the_fp32_oracle(nets):
     assert cos >= 0.99 and worst[1] >= 0.97
 
 
+def test_bf16_tiles_not_divisible_by_32():
+    """the reference's shipped tile size is 400 (params_and_main.py:36): ceil-mode average pools and nearest resizes in the decoder.  bf16 storage
+    ran only on /32 tiles before round 3 (no bf16 resize kernels); 3-band 208 x 176 tiles, xresnet34, eval + one training step against the fp32 oracle"""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(2)
+    ref = O.DynamicUnet("xresnet34", 3, 3, (208, 176))
+    O.randomize_bn_and_zero_gammas(ref, seed=3)
+    x, y = O.synthetic_batch(2, 3, 208, 176, 3)
+    ref.eval()
+    with torch.no_grad():
+        s = ref(x).abs().max().item() / 4.0
+        ref.layers[-1][0].weight.div_(s); ref.layers[-1][0].bias.div_(s)
+    m16 = HipDynamicUnet("xresnet34", 3, 3, (208, 176), act_dtype="bf16")
+    m16.load_state_dict(ref.state_dict())
+    m16.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = m16.predict_probs(x.cuda())
+        z = m16(x.cuda()).cpu()
+    rel = ((z - z32).norm() / z32.norm()).item()
+    agree = (amax.cpu() == z32.argmax(1)).float().mean().item()
+    print(f"bf16 208x176 eval: rel-L2 {rel:.3e} mask agreement {agree:.5f}")
+    assert rel <= 2e-2 and agree >= 0.99
+    w = torch.tensor([0.2, 0.5, 0.3])
+    ref.train(); m16.train()
+    l32 = O.CrossEntropyLossFlat(weight=w)(ref(x), y)
+    l32.backward()
+    loss = m16.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l32.item()) <= 5e-3 * abs(l32.item())
+    gh = torch.cat([p.grad.flatten() for p in m16.parameters()]).cpu().double()
+    gr = torch.cat([q.grad.flatten() for q in ref.parameters()]).double()
+    cos = F.cosine_similarity(gh, gr, dim=0).item()
+    print(f"bf16 208x176 train step: loss {loss.item():.5f} vs {l32.item():.5f}, gradient cos {cos:.5f}")
+    assert cos >= 0.99
+
+
 def test_bf16_training_follows_the_fp32_hip_path():
     """ten fit steps from the same initial weights: the bf16-storage model's loss curve stays within 2 % of the fp32 HIP path and
     goes down; master weights stay fp32 (updates far below one bf16 ulp are not lost)"""

@@ -154,7 +154,7 @@ _sig = {
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
-           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
+           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
 _sig["unet_pack_weights_size_bf16"] = _sig["unet_pack_weights_size"]
 _sig["unet_pack_weights_bf16"] = _sig["unet_pack_weights"]

@@ -840,7 +840,8 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
     return s < in - 1 ? s : in - 1;
 }
 
-__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const T* __restrict__ x, int x_cs, int x_co, T* __restrict__ y,
                                                              int y_cs, int y_co, int N, int IH, int IW, int OH, int OW, int C4) {
     const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
     const long long total = (long long)N * OH * OW * C4;
@@ -855,7 +856,8 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_co, T* __restrict__ dx,
                                                                  int dx_cs, int dx_co, int N, int IH, int IW, int OH, int OW, int C4) {
     const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
     const long long total = (long long)N * IH * IW * C4;
@@ -1435,27 +1437,37 @@ extern "C" int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, cons
 extern "C" int unet_shuffle_blur_bwd_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* dyc, int dyc_cs,
                                      int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream) { return shuffle_blur_bwd_impl<unet_bf16>(dX, dX_cs, dX_co, yc, yc_cs, yc_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, do_blur, stream); }
 
-extern "C" int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW,
-                                   int C, void* stream) {
+template <typename T>
+static int resize_nearest_impl(const T* x, int x_cs, int x_co, T* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW, int C,
+                               void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0, "resize_nearest: bad args");
     UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "resize_nearest: bad slice");
     const int C4 = c4of(C);
-    hipLaunchKernelGGL(resize_nearest_kernel, dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co,
+    hipLaunchKernelGGL((resize_nearest_kernel<T>), dim3(ew_grid((long long)N * OH * OW * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co,
                        N, IH, IW, OH, OW, C4);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW,
+                                   int C, void* stream) { return resize_nearest_impl<float>(x, x_cs, x_co, y, y_cs, y_co, N, IH, IW, OH, OW, C, stream); }
+extern "C" int unet_resize_nearest_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW,
+                                   int C, void* stream) { return resize_nearest_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, N, IH, IW, OH, OW, C, stream); }
 
-extern "C" int unet_resize_nearest_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW,
-                                       int OH, int OW, int C, void* stream) {
+template <typename T>
+static int resize_nearest_bwd_impl(const T* dy, int dy_cs, int dy_co, T* dx, int dx_cs, int dx_co, int N, int IH, int IW, int OH, int OW,
+                                   int C, void* stream) {
     UNET_CHECK_ARG(dy && dx && N > 0 && C > 0, "resize_nearest_bwd: bad args");
     UNET_CHECK_ARG(pslice_ok(dy_cs, dy_co, C) && pslice_ok(dx_cs, dx_co, C), "resize_nearest_bwd: bad slice");
     const int C4 = c4of(C);
-    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx,
-                       dx_cs, dx_co, N, IH, IW, OH, OW, C4);
+    hipLaunchKernelGGL((resize_nearest_bwd_kernel<T>), dim3(ew_grid((long long)N * IH * IW * C4, 256)), dim3(256), 0, ST, dy, dy_cs, dy_co, dx, dx_cs,
+                       dx_co, N, IH, IW, OH, OW, C4);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_resize_nearest_bwd(const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs, int dx_co, int N, int IH, int IW, int OH,
+                                       int OW, int C, void* stream) { return resize_nearest_bwd_impl<float>(dy, dy_cs, dy_co, dx, dx_cs, dx_co, N, IH, IW, OH, OW, C, stream); }
+extern "C" int unet_resize_nearest_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int OH,
+                                       int OW, int C, void* stream) { return resize_nearest_bwd_impl<unet_bf16>(dy, dy_cs, dy_co, dx, dx_cs, dx_co, N, IH, IW, OH, OW, C, stream); }
 
 template <typename T>
 static int nchw_to_nhwc_impl(const float* x, T* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream) {

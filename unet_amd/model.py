@@ -49,8 +49,7 @@ class HipDynamicUnet(nn.Module):
                  device="cuda", act_dtype: str = "f32"):
         """act_dtype "f32": the parity path (the reference computes in fp32).  "bf16": bf16 storage of activations, activation
         gradients and packed filters with fp32 accumulation in the matrix cores; parameters, gradients of parameters, BatchNorm
-        statistics, logits, loss and optimizer state stay fp32 (BASELINE.json configs[1] variant; classification, tiles divisible
-        by 32, no self-attention)."""
+        statistics, logits, loss and optimizer state stay fp32 (BASELINE.json configs[1] variant; classification, no self-attention)."""
         super().__init__()
         if act_dtype not in ("f32", "bf16"):
             raise ValueError(f"act_dtype must be 'f32' or 'bf16', not {act_dtype!r}")
@@ -215,8 +214,6 @@ class HipDynamicUnet(nn.Module):
             x = x.contiguous()
             N, _, H, W = x.shape
             put = lambda buf, at, _x=x: ops.nchw_to_nhwc(_x, ops.TS(buf, 0, buf.shape[3]), at=at)
-        if self.act_dtype == "bf16" and (H % 32 or W % 32):
-            raise ValueError("bf16 storage mode needs tile sides divisible by 32 (no nearest-resize kernels in bf16)")
         ctx = self.ctx
         ctx.training = training
         ctx.fold_bn = bool(self.fold_eval_bn) and not training     # eval: Conv + BN + ReLU = ONE launch (BatchNorm folded into filter + bias)

@@ -397,13 +397,13 @@ def shuffle_blur_bwd(dX: TS, yc: TS, dyc: TS, blur: bool):
 
 
 def resize_nearest(x: TS, y: TS):
-    _need_f32("resize_nearest", x, y)
-    check(lib.unet_resize_nearest(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, y.H, y.W, x.C, _stream()), "resize_nearest")
+    assert x.bf16 == y.bf16
+    check(_fn("resize_nearest", x)(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.N, x.H, x.W, y.H, y.W, x.C, _stream()), "resize_nearest")
 
 
 def resize_nearest_bwd(dy: TS, dx: TS):
-    _need_f32("resize_nearest_bwd", dy, dx)
-    check(lib.unet_resize_nearest_bwd(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dy.H, dy.W, dx.C, _stream()),
+    assert dy.bf16 == dx.bf16
+    check(_fn("resize_nearest_bwd", dy)(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, dx.N, dx.H, dx.W, dy.H, dy.W, dx.C, _stream()),
           "resize_nearest_bwd")
 
 
