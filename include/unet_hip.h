@@ -355,6 +355,14 @@ int unet_resize_nearest_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet
 int unet_nchw_to_nhwc_bf16(const float* x, unet_bf16* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream);
 int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate, void* stream);
 int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream);
+/* bf16 SelfAttention (round 3): the attention logits and the gradient of the attention weights stay fp32 (the products that make them write
+ * fp32: unet_conv_desc.y_f32), the weights themselves and every other tensor are bf16 */
+int unet_pack_weights_strided_bf16(const unet_bf16* w, long long so, long long sr, unet_bf16* wp, int O, int R, void* stream);
+int unet_row_softmax_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
+int unet_row_softmax_bwd_bf16(const unet_bf16* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, long long P, int C, void* stream);
+int unet_relu_mask_bf16(const unet_bf16* g, int g_cs, int g_co, const unet_bf16* ref, int r_cs, int r_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
+int unet_dot_bf16(const unet_bf16* x, int x_cs, int x_co, const unet_bf16* y, int y_cs, int y_co, long long P, int C, float* out, float* workspace, void* stream);
+int unet_cast_slice_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -373,6 +373,47 @@ def test_bf16_tiles_not_divisible_by_32():
     assert cos >= 0.99
 
 
+@pytest.mark.parametrize("size", [(200, 200), (256, 192)])
+def test_bf16_self_attention_against_the_fp32_oracle(size):
+    """the reference's shipped configuration has self_attention = True (params_and_main.py:83): SelfAttention(384) in bf16 storage -- fused QKV,
+    attention logits and the gradient of the attention weights in fp32, everything else bf16.  200 x 200 tiles put 25 x 25 = 625 positions on the
+    attention stage (not a multiple of 8: padded rows); eval and one training step against the fp32 oracle with the conditioned fixture of
+    tests/test_configs_gpu.py"""
+    from tests.test_configs_gpu import _normalise_head, _sa_pair
+    from unet_amd.model import HipDynamicUnet
+    x, y = O.synthetic_batch(2, 3, size[0], size[1], 3)
+    ref = _sa_pair("xresnet34", 3, 3, size, 61, x)
+    _normalise_head(ref, x[:1])
+    m16 = HipDynamicUnet("xresnet34", 3, 3, size, self_attention=True, act_dtype="bf16")
+    r = m16.load_state_dict(ref.state_dict())
+    assert not r.missing_keys and not r.unexpected_keys
+    ref.eval(); m16.eval()
+    with torch.no_grad():
+        z32 = ref(x)
+        _, amax = m16.predict_probs(x.cuda())
+        z = m16(x.cuda()).cpu()
+    rel = ((z - z32).norm() / z32.norm()).item()
+    agree = (amax.cpu() == z32.argmax(1)).float().mean().item()
+    print(f"bf16 + SA {size} eval: rel-L2 {rel:.3e} mask agreement {agree:.5f}")
+    assert rel <= 3e-2 and agree >= 0.98
+    w = torch.tensor([0.2, 0.5, 0.3])
+    ref.train(); m16.train()
+    for p in ref.parameters():
+        p.grad = None
+    l32 = O.CrossEntropyLossFlat(weight=w)(ref(x), y)
+    l32.backward()
+    loss = m16.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l32.item()) <= 1e-2 * abs(l32.item()), (loss.item(), l32.item())
+    gh = torch.cat([p.grad.flatten() for p in m16.parameters()]).cpu().double()
+    gr = torch.cat([q.grad.flatten() for q in ref.parameters()]).double()
+    cos = F.cosine_similarity(gh, gr, dim=0).item()
+    sa = {n.split("conv2.2.")[1]: F.cosine_similarity(p.grad.flatten().cpu().double(), q.grad.flatten().double(), dim=0).item()
+          for (n, p), (_, q) in zip(m16.named_parameters(), ref.named_parameters()) if ".conv2.2." in n}
+    print(f"bf16 + SA {size} train step: loss {loss.item():.5f} vs {l32.item():.5f}, gradient cos {cos:.5f}, attention parameters {sa}")
+    assert cos >= 0.98 and len(sa) == 4 and all(v >= 0.9 for v in sa.values()), sa
+
+
 def test_bf16_training_follows_the_fp32_hip_path():
     """ten fit steps from the same initial weights: the bf16-storage model's loss curve stays within 2 % of the fp32 HIP path and
     goes down; master weights stay fp32 (updates far below one bf16 ulp are not lost)"""

@@ -156,6 +156,9 @@ _sig = {
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
            "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
+for _n in ("pack_weights_strided", "row_softmax", "row_softmax_bwd", "relu_mask", "dot"):
+    _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
+_sig["unet_cast_slice_bf16"] = (i, [vp, i, i, vp, i, i, ll, i, vp])
 _sig["unet_pack_weights_size_bf16"] = _sig["unet_pack_weights_size"]
 _sig["unet_pack_weights_bf16"] = _sig["unet_pack_weights"]
 

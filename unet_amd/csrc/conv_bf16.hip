@@ -297,6 +297,18 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, u16* __res
         wp[i] = __builtin_bit_cast(u16, (__bf16)bf16_image_value(w, Cout, Cin, T, mode, nchunks, outPad, i));
 }
 
+// 1x1 "weights" that are bf16 activations (self-attention operands): element (out o, reduction r) = w[o * so + r * sr]; the image
+// unet_pack_weights_bf16 makes for ks = 1, mode 0: wp[chunk32][outPad][32], zero padded
+__global__ void pack_weights_strided_bf16_kernel(const u16* __restrict__ w, long long so, long long sr, u16* __restrict__ wp, int O, int R,
+                                                 int outPad, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i & 31);
+        const size_t j = i >> 5;
+        const int o = (int)(j % outPad), r = (int)(j / outPad) * 32 + rr;
+        wp[i] = (o < O && r < R) ? w[(long long)o * so + (long long)r * sr] : (u16)0;
+    }
+}
+
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
 int launch_cfg(const Plan& p, int y_f32, hipStream_t st) {
     auto kern = conv_bf16_kernel<TW, MT, NT, WM, WN, HIT>;
@@ -401,6 +413,16 @@ extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mod
     const int T = ks * ks;
     const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
     return bf16_image_elems(red, unet::roundup(out, 128), T);
+}
+
+extern "C" int unet_pack_weights_strided_bf16(const unet_bf16* w, long long so, long long sr, unet_bf16* wp, int O, int R, void* stream) {
+    UNET_CHECK_ARG(w && wp && O > 0 && R > 0, "pack_weights_strided_bf16: bad args");
+    const int outPad = unet::roundup(O, 128);
+    const size_t total = bf16_image_elems(R, outPad, 1);
+    hipLaunchKernelGGL(pack_weights_strided_bf16_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, w, so, sr, wp,
+                       O, R, outPad, total);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
 }
 
 extern "C" int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream) {

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // per-channel partial sums of x * y (self-attention: dL/dgamma = sum O * dout)
-__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(const T* __restrict__ x, int x_cs, int x_co, const T* __restrict__ y, int y_cs,
                                                   int y_co, long long P, int C4, int TC, float* out0, int Cp) {
     channel_reduce(
         [&](long long p, int c4, float4& v0, float4& v1) {
@@ -918,8 +919,9 @@ __global__ __launch_bounds__(256) void copy_slice_kernel(const T* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ g, int g_cs, int g_co, const float* __restrict__ ref,
-                                                        int r_cs, int r_co, float* __restrict__ y, int y_cs, int y_co, long long P, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ g, int g_cs, int g_co, const T* __restrict__ ref,
+                                                        int r_cs, int r_co, T* __restrict__ y, int y_cs, int y_co, long long P, int C4) {
     for (QuadWalk w(C4); w.p < P; w.next()) {
         const long long p = w.p;
         const int c = 4 * w.c4;
@@ -1079,11 +1081,12 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max) {
     return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+template <typename TO>      // logits are always fp32 (bf16 storage: the product that makes them writes fp32, unet_conv_desc.y_f32); TO = float | bf16 weights
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ x, int x_cs, int x_co, TO* __restrict__ y, int y_cs,
                                                           int y_co, long long P, int C) {
     for (long long p = blockIdx.x; p < P; p += gridDim.x) {
         const float* xr = x + (size_t)p * x_cs + x_co;
-        float* yr = y + (size_t)p * y_cs + y_co;
+        TO* yr = y + (size_t)p * y_cs + y_co;
         float m = -INFINITY;
         for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, xr[c]);
         m = block_reduce(m, true);
@@ -1091,22 +1094,23 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
         for (int c = threadIdx.x; c < C; c += 256) s += expf(xr[c] - m);
         s = block_reduce(s, false);
         const float inv = 1.f / s;
-        for (int c = threadIdx.x; c < C; c += 256) yr[c] = expf(xr[c] - m) * inv;
+        for (int c = threadIdx.x; c < C; c += 256) st1(yr + c, expf(xr[c] - m) * inv);
     }
 }
 
 // dx[p][c] = y[p][c] * (dy[p][c] - sum_c' y[p][c'] dy[p][c'])
-__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __restrict__ y, int y_cs, int y_co, const float* __restrict__ dy,
-                                                              int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co,
+template <typename TW>      // TW = storage type of the softmax weights y and of the result dx; dy (the gradient of the weights) is fp32
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const TW* __restrict__ y, int y_cs, int y_co, const float* __restrict__ dy,
+                                                              int dy_cs, int dy_co, TW* __restrict__ dx, int dx_cs, int dx_co,
                                                               long long P, int C) {
     for (long long p = blockIdx.x; p < P; p += gridDim.x) {
-        const float* yr = y + (size_t)p * y_cs + y_co;
+        const TW* yr = y + (size_t)p * y_cs + y_co;
         const float* gr = dy + (size_t)p * dy_cs + dy_co;
-        float* dr = dx + (size_t)p * dx_cs + dx_co;
+        TW* dr = dx + (size_t)p * dx_cs + dx_co;
         float s = 0.f;
-        for (int c = threadIdx.x; c < C; c += 256) s += yr[c] * gr[c];
+        for (int c = threadIdx.x; c < C; c += 256) s += ld1(yr + c) * gr[c];
         s = block_reduce(s, false);
-        for (int c = threadIdx.x; c < C; c += 256) dr[c] = yr[c] * (gr[c] - s);
+        for (int c = threadIdx.x; c < C; c += 256) st1(dr + c, ld1(yr + c) * (gr[c] - s));
     }
 }
 
@@ -1501,12 +1505,32 @@ extern "C" int unet_copy_slice(const float* x, int x_cs, int x_co, float* y, int
 extern "C" int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate,
                                void* stream) { return copy_slice_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, P, C, accumulate, stream); }
 
-extern "C" int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_cs, int r_co, float* y, int y_cs, int y_co,
-                              long long P, int C, void* stream) {
+template <typename T>
+static int relu_mask_impl(const T* g, int g_cs, int g_co, const T* ref, int r_cs, int r_co, T* y, int y_cs, int y_co, long long P, int C,
+                          void* stream) {
     UNET_CHECK_ARG(g && ref && y && P > 0 && C > 0, "relu_mask: bad args");
     UNET_CHECK_ARG(pslice_ok(g_cs, g_co, C) && pslice_ok(r_cs, r_co, C) && pslice_ok(y_cs, y_co, C), "relu_mask: bad slice");
     const int C4 = c4of(C);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, g, g_cs, g_co, ref, r_cs, r_co, y, y_cs, y_co, P, C4);
+    hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, g, g_cs, g_co, ref, r_cs, r_co, y, y_cs, y_co, P, C4);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+extern "C" int unet_relu_mask(const float* g, int g_cs, int g_co, const float* ref, int r_cs, int r_co, float* y, int y_cs, int y_co,
+                              long long P, int C, void* stream) { return relu_mask_impl<float>(g, g_cs, g_co, ref, r_cs, r_co, y, y_cs, y_co, P, C, stream); }
+extern "C" int unet_relu_mask_bf16(const unet_bf16* g, int g_cs, int g_co, const unet_bf16* ref, int r_cs, int r_co, unet_bf16* y, int y_cs, int y_co,
+                              long long P, int C, void* stream) { return relu_mask_impl<unet_bf16>(g, g_cs, g_co, ref, r_cs, r_co, y, y_cs, y_co, P, C, stream); }
+
+// fp32 -> bf16 copy of a channel slice (bf16 self-attention: fp32 weight-gradient results into the bf16 gradient of the fused QKV tensor)
+__global__ __launch_bounds__(256) void cast_slice_kernel(const float* __restrict__ x, int x_cs, int x_co, unet_bf16* __restrict__ y, int y_cs,
+                                                         int y_co, long long P, int C4) {
+    for (QuadWalk w(C4); w.p < P; w.next())
+        st4(y + (size_t)w.p * y_cs + y_co + 4 * w.c4, ld4(x + (size_t)w.p * x_cs + x_co + 4 * w.c4));
+}
+extern "C" int unet_cast_slice_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream) {
+    UNET_CHECK_ARG(x && y && P > 0 && C > 0, "cast_slice: bad args");
+    UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "cast_slice: bad slice");
+    const int C4 = c4of(C);
+    hipLaunchKernelGGL(cast_slice_kernel, dim3(ew_grid(P * C4, 256)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
@@ -1524,17 +1548,22 @@ extern "C" int unet_colsum(const float* x, int x_cs, int x_co, long long P, int 
     return UNET_OK;
 }
 
-extern "C" int unet_dot(const float* x, int x_cs, int x_co, const float* y, int y_cs, int y_co, long long P, int C, float* out,
-                        float* workspace, void* stream) {
+template <typename T>
+static int dot_impl(const T* x, int x_cs, int x_co, const T* y, int y_cs, int y_co, long long P, int C, float* out, float* workspace,
+                    void* stream) {
     UNET_CHECK_ARG(x && y && out && workspace && P > 0 && C > 0, "dot: bad args");
     UNET_CHECK_ARG(pslice_ok(x_cs, x_co, C) && pslice_ok(y_cs, y_co, C), "dot: bad slice");
     const int rows = stats_rows(P), C4 = c4of(C), Cp = 4 * C4, TC = pick_tc(C4);
-    hipLaunchKernelGGL(dot_kernel, dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, TC, workspace, Cp);
+    hipLaunchKernelGGL((dot_kernel<T>), dim3(rows), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C4, TC, workspace, Cp);
     UNET_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, ST, workspace, (long long)rows * Cp, out);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+extern "C" int unet_dot(const float* x, int x_cs, int x_co, const float* y, int y_cs, int y_co, long long P, int C, float* out,
+                        float* workspace, void* stream) { return dot_impl<float>(x, x_cs, x_co, y, y_cs, y_co, P, C, out, workspace, stream); }
+extern "C" int unet_dot_bf16(const unet_bf16* x, int x_cs, int x_co, const unet_bf16* y, int y_cs, int y_co, long long P, int C, float* out,
+                        float* workspace, void* stream) { return dot_impl<unet_bf16>(x, x_cs, x_co, y, y_cs, y_co, P, C, out, workspace, stream); }
 
 static int ce_rows(long long P) {
     long long r = (P + 255) / 256;
@@ -1617,7 +1646,13 @@ extern "C" int unet_softmax_argmax(const float* z, int z_cs, int z_co, int N, in
 
 extern "C" int unet_row_softmax(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, long long P, int C, void* stream) {
     UNET_CHECK_ARG(x && y && P > 0 && C > 0 && x_co + C <= x_cs && y_co + C <= y_cs, "row_softmax: bad args");
-    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C);
+    hipLaunchKernelGGL((row_softmax_kernel<float>), dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+extern "C" int unet_row_softmax_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream) {
+    UNET_CHECK_ARG(x && y && P > 0 && C > 0 && x_co + C <= x_cs && y_co + C <= y_cs, "row_softmax_bf16: bad args");
+    hipLaunchKernelGGL((row_softmax_kernel<unet_bf16>), dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, x, x_cs, x_co, y, y_cs, y_co, P, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
@@ -1625,8 +1660,16 @@ extern "C" int unet_row_softmax(const float* x, int x_cs, int x_co, float* y, in
 extern "C" int unet_row_softmax_bwd(const float* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co, float* dx, int dx_cs,
                                     int dx_co, long long P, int C, void* stream) {
     UNET_CHECK_ARG(y && dy && dx && P > 0 && C > 0 && y_co + C <= y_cs && dy_co + C <= dy_cs && dx_co + C <= dx_cs, "row_softmax_bwd: bad args");
-    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, y, y_cs, y_co, dy, dy_cs, dy_co, dx,
+    hipLaunchKernelGGL((row_softmax_bwd_kernel<float>), dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, y, y_cs, y_co, dy, dy_cs, dy_co, dx,
                        dx_cs, dx_co, P, C);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+extern "C" int unet_row_softmax_bwd_bf16(const unet_bf16* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs,
+                                         int dx_co, long long P, int C, void* stream) {
+    UNET_CHECK_ARG(y && dy && dx && P > 0 && C > 0 && y_co + C <= y_cs && dy_co + C <= dy_cs && dx_co + C <= dx_cs, "row_softmax_bwd_bf16: bad args");
+    hipLaunchKernelGGL((row_softmax_bwd_kernel<unet_bf16>), dim3((unsigned)(P < 65536 ? P : 65536)), dim3(256), 0, ST, y, y_cs, y_co, dy, dy_cs, dy_co,
+                       dx, dx_cs, dx_co, P, C);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

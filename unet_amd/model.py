@@ -49,12 +49,10 @@ class HipDynamicUnet(nn.Module):
                  device="cuda", act_dtype: str = "f32"):
         """act_dtype "f32": the parity path (the reference computes in fp32).  "bf16": bf16 storage of activations, activation
         gradients and packed filters with fp32 accumulation in the matrix cores; parameters, gradients of parameters, BatchNorm
-        statistics, logits, loss and optimizer state stay fp32 (BASELINE.json configs[1] variant; classification, no self-attention)."""
+        statistics, logits (and attention logits), loss and optimizer state stay fp32 (BASELINE.json configs[1] variant; classification)."""
         super().__init__()
         if act_dtype not in ("f32", "bf16"):
             raise ValueError(f"act_dtype must be 'f32' or 'bf16', not {act_dtype!r}")
-        if act_dtype == "bf16" and self_attention:
-            raise ValueError("self-attention is only available on the fp32 path")
         self.act_dtype = act_dtype
         self.self_attention = bool(self_attention)
         self.arch, self.n_in, self.n_out = arch, n_in, n_out

@@ -582,9 +582,9 @@ class SelfAttention(nn.Module):
         # the query / key / value slices of the fused QKV buffer are channel slices and start at multiples of the 4-channel vector:
         # query and key are padded to c8p lanes (xresnet34_deep: 432 channels, 54 -> 56) with zero filter rows, i.e. zero lanes that
         # add nothing to any product
-        self.c8p = (c8 + 3) // 4 * 4
-        if n_channels % 4 != 0:
-            raise ValueError(f"self-attention on {n_channels} channels: the device program needs a multiple of 4 channels")
+        self.c8p = (c8 + 3) // 4 * 4          # fp32 storage (4-lane vectors); bf16 storage pads to 8 lanes (ops.rupv at run time)
+        if n_channels % 8 != 0:
+            raise ValueError(f"self-attention on {n_channels} channels: the device program needs a multiple of 8 channels")
 
     @staticmethod
     def _normed_weight(seq: nn.Sequential) -> torch.Tensor:
@@ -611,53 +611,69 @@ class SelfAttention(nn.Module):
         cs = buf.shape[3]
         return TS(buf[b0].view(-1, cs)[j0:j0 + nj].view(1, nj // W, W, cs), co, C)
 
-    def _scratch(self, ctx: Ctx, tag: str, chunks, N: int, nb: int, nj: int, W: int) -> TS:
-        big = max(c[1] * c[3] for c in chunks) * N
-        buf = ctx.vec(self, tag, big)
-        return TS(buf[:nb * nj * N].view(nb, nj // W, W, N), 0, N)
+    def _scratch(self, ctx: Ctx, tag: str, chunks, N: int, nb: int, nj: int, W: int, dtype=torch.float32) -> TS:
+        """[nb, nj / W, W, Np] view of a scratch buffer holding one N-wide row per attention row of the chunk.  Rows are Np = roundup(N, 8)
+        elements long (16-byte rows in both storage types: 50 x 50 = 2500 positions of the reference's 400-px tiles are not a multiple of 8);
+        the pad lanes of the view are zeroed, the kernels read them as part of the last channel vector"""
+        Np = (N + 7) // 8 * 8
+        big = max(c[1] * c[3] for c in chunks) * Np
+        buf = ctx.vec(self, tag, big, dtype=dtype)
+        v = buf[:nb * nj * Np].view(nb, nj // W, W, Np)
+        if Np != N:
+            v[..., N:].zero_()
+        return TS(v, 0, N)
 
-    def _scores(self, ctx: Ctx, qkv: TS, TP: TS, ch, W: int, wpa: torch.Tensor):
-        """TP <- row-softmax(G_chunk F^T): the rows of beta^T that belong to the chunk"""
+    def _scores(self, ctx: Ctx, qkv: TS, chunks, ch, W: int, wpa: torch.Tensor) -> TS:
+        """row-softmax(G_chunk F^T): the rows of beta^T that belong to the chunk.  The logits are fp32 in both storage modes (bf16: the
+        product writes fp32, unet_conv_desc.y_f32); the weights come back in the activation storage type (fp32: in place)."""
         b0, nb, j0, nj = ch
-        N, c8, c8p, CQ = TP.C, self.c8, self.c8p, qkv.cs
-        img = qkv.buf.shape[1] * qkv.buf.shape[2] * CQ * 4
-        sz = int(ops.lib.unet_pack_weights_size(N, c8, 1, 0))
+        N = qkv.buf.shape[1] * qkv.buf.shape[2]
+        c8, dt = self.c8, qkv.buf.dtype
+        c8p, CQ, es = ops.rupv(c8, dt), qkv.cs, qkv.buf.element_size()
+        img = N * CQ * es
+        sz = ops.pack_size(N, c8, dt)
         for k in range(nb):
             ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, CQ, 1, N, c8, wpa[k * sz:])                 # (o=i, r=c) = F_b[i][c]
-        ops.conv2d(self._rows(qkv.buf, c8p, c8, b0, nb, j0, nj, W), wpa, TP, 1, wp_img_stride=sz)         # T = G F^T
-        ops.row_softmax(TP, TP)                                                                            # in place
+        T = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
+        ops.conv2d(self._rows(qkv.buf, c8p, c8, b0, nb, j0, nj, W), wpa, T, 1, wp_img_stride=sz)          # T = G F^T
+        if dt == torch.float32:
+            ops.row_softmax(T, T)                                                                          # in place
+            return T
+        P = self._scratch(ctx, "P16", chunks, N, nb, nj, W, dtype=dt)
+        ops.row_softmax(T, P)
+        return P
+
+    def _wcat(self, c8p: int) -> torch.Tensor:
+        wq_, wk_, wv_ = self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)
+        if c8p != self.c8:
+            zpad = wq_.new_zeros((c8p - self.c8,) + tuple(wq_.shape[1:]))
+            return torch.cat([wq_, zpad, wk_, zpad, wv_], 0)
+        return torch.cat([wq_, wk_, wv_], 0)
 
     def hip_fwd(self, ctx: Ctx, x: TS) -> TS:
-        B, H, W, C_, c8, c8p = x.N, x.H, x.W, self.C, self.c8, self.c8p
+        B, H, W, C_, c8, dt = x.N, x.H, x.W, self.C, self.c8, ctx.act_dtype
+        c8p, es = ops.rupv(c8, dt), x.buf.element_size()      # query / key slices padded to the vector width (fp32: 4 lanes, bf16: 8)
         N, CQ = H * W, 2 * c8p + C_
         with torch.enable_grad():
-            wq_, wk_, wv_ = self._normed_weight(self.query), self._normed_weight(self.key), self._normed_weight(self.value)
-            if c8p != c8:
-                zpad = wq_.new_zeros((c8p - c8,) + tuple(wq_.shape[1:]))
-                wcat = torch.cat([wq_, zpad, wk_, zpad, wv_], 0)
-            else:
-                wcat = torch.cat([wq_, wk_, wv_], 0)
-            wcat = wcat.reshape(CQ, C_, 1, 1)
+            wcat = self._wcat(c8p).reshape(CQ, C_, 1, 1)
         ctx.saved[(id(self), "wcat")] = wcat
         wq = wcat.detach().contiguous()
-        wp = ctx.vec(self, "wp_f", ops.lib.unet_pack_weights_size(CQ, C_, 1, 0))
-        ops.pack_weights(wq, 0, wp)
+        wp = ctx.vec(self, "wp_f", ops.pack_size(CQ, C_, dt), dtype=dt)
+        ops.pack_weights(wq, 0, wp, dtype=dt)
         qkv = ctx.act(self, "qkv", B, H, W, CQ)
         ops.conv2d(x, wp, qkv, 1)
         chunks = self._chunks(B, H, W)
         nbmax = max(c[1] for c in chunks)
-        szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
-               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8p, N, 1, 0))]
-        wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
+        szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
+        wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
         O = ctx.act(self, "O", B, H, W, C_)
-        img = N * CQ * 4      # bytes per image of qkv
+        img = N * CQ * es     # bytes per image of qkv
         for ch in chunks:
             b0, nb, j0, nj = ch
-            TP = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
-            self._scores(ctx, qkv, TP, ch, W, wpa)
+            P = self._scores(ctx, qkv, chunks, ch, W, wpa)
             for k in range(nb):
-                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8p, 1, CQ, C_, N, wpa[k * szs[1]:])     # (o=c, r=i) = H_b[i][c]
-            ops.conv2d(TP, wpa, self._rows(O.buf, 0, C_, b0, nb, j0, nj, W), 1, wp_img_stride=szs[1])             # O = P H
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 2 * c8p * es, 1, CQ, C_, N, wpa[k * szs[1]:])   # (o=c, r=i) = H_b[i][c]
+            ops.conv2d(P, wpa, self._rows(O.buf, 0, C_, b0, nb, j0, nj, W), 1, wp_img_stride=szs[1])                 # O = P H
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
         gvec.copy_(self.gamma.data.expand(C_))
         out = ctx.act(self, "out", B, H, W, C_)
@@ -669,7 +685,8 @@ class SelfAttention(nn.Module):
     def hip_bwd(self, ctx: Ctx, dout: TS) -> TS:
         """dout = dL/d(out).  Returns dL/dx."""
         x: TS = ctx.saved[(id(self), "x")]
-        B, H, W, C_, c8, c8p = x.N, x.H, x.W, self.C, self.c8, self.c8p
+        B, H, W, C_, c8, dt = x.N, x.H, x.W, self.C, self.c8, ctx.act_dtype
+        c8p, es, bf = ops.rupv(c8, dt), x.buf.element_size(), ctx.act_dtype == torch.bfloat16
         N, CQ = H * W, 2 * c8p + C_
         qkv, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "O", B, H, W, C_)
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
@@ -680,20 +697,21 @@ class SelfAttention(nn.Module):
         chunks = self._chunks(B, H, W)
         kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
         nbmax = max(c[1] for c in chunks)
-        szs = [int(ops.lib.unet_pack_weights_size(N, c8, 1, 0)), int(ops.lib.unet_pack_weights_size(C_, N, 1, 0)),
-               int(ops.lib.unet_pack_weights_size(N, C_, 1, 0)), int(ops.lib.unet_pack_weights_size(c8p, N, 1, 0))]
-        wpa = ctx.vec(self, "wp_a", nbmax * max(szs))
-        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8p)
-        img = N * CQ * 4
+        szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
+        wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
+        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8p)              # weight-gradient results: fp32 in both modes
+        put = ops.cast_slice if bf else ops.copy_slice                                          # ... into the gradient of the QKV tensor
+        img = N * CQ * es
         for ch in chunks:
             b0, nb, j0, nj = ch
-            P = self._scratch(ctx, "TP", chunks, N, nb, nj, W)
-            if not kept:
-                self._scores(ctx, qkv, P, ch, W, wpa)                                            # recompute beta^T rows
-            dP = self._scratch(ctx, "dP", chunks, N, nb, nj, W)
+            if kept:
+                P = self._scratch(ctx, "P16" if bf else "TP", chunks, N, nb, nj, W, dtype=dt)
+            else:
+                P = self._scores(ctx, qkv, chunks, ch, W, wpa)                                   # recompute beta^T rows
+            dP = self._scratch(ctx, "dP", chunks, N, nb, nj, W)                                  # fp32 (bf16: written by the product as fp32)
             dO_c = self._rows(dO.buf, 0, C_, b0, nb, j0, nj, W)
             for k in range(nb):
-                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 8 * c8p, CQ, 1, N, C_, wpa[k * szs[2]:])      # (o=i, r=c) = H_b[i][c]
+                ops.pack_weights_strided(qkv.ptr + (b0 + k) * img + 2 * c8p * es, CQ, 1, N, C_, wpa[k * szs[2]:])  # (o=i, r=c) = H_b[i][c]
             ops.conv2d(dO_c, wpa, dP, 1, wp_img_stride=szs[2])                                                     # dP = dO H^T
             last = j0 + nj == N
             for k in range(nb):
@@ -702,27 +720,32 @@ class SelfAttention(nn.Module):
                 n = ops.wgrad_workspace(dO_b, P_b, 1, 1)
                 ops.conv2d_wgrad(dO_b, P_b, tmpH, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dH_b (+)= P^T dO -> [N][C]
                 if last:
-                    ops.copy_slice(TS(tmpH[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8p, C_))
-            ops.row_softmax_bwd(P, dP, dP)                                                                         # dT in place
+                    put(TS(tmpH[:N * C_].view(1, H, W, C_), 0, C_), TS(dqkv.buf[b:b + 1], 2 * c8p, C_))
+            if bf:
+                dT = self._scratch(ctx, "dT16", chunks, N, nb, nj, W, dtype=dt)
+                ops.row_softmax_bwd(P, dP, dT)
+            else:
+                dT = dP
+                ops.row_softmax_bwd(P, dP, dP)                                                                     # dT in place
             for k in range(nb):
                 ops.pack_weights_strided(qkv.ptr + (b0 + k) * img, 1, CQ, c8p, N, wpa[k * szs[3]:])                # (o=c, r=i) = F_b[i][c]
             # c8p output channels: the pad lanes of F are zeros, so the pad lanes of dG are written as exact zeros (dqkv is pool memory)
-            ops.conv2d(dP, wpa, self._rows(dqkv.buf, c8p, c8p, b0, nb, j0, nj, W), 1, wp_img_stride=szs[3])        # dG = dT F
+            ops.conv2d(dT, wpa, self._rows(dqkv.buf, c8p, c8p, b0, nb, j0, nj, W), 1, wp_img_stride=szs[3])        # dG = dT F
             for k in range(nb):
                 b = b0 + k
                 # G with its zero pad lanes (c8p wide): the gradient rows come out 16-byte aligned, their pad lanes are exact zeros
-                dT_b, G_b = TS(dP.buf[k:k + 1], 0, N), self._rows(qkv.buf, c8p, c8p, b, 1, j0, nj, W)
+                dT_b, G_b = TS(dT.buf[k:k + 1], 0, N), self._rows(qkv.buf, c8p, c8p, b, 1, j0, nj, W)
                 n = ops.wgrad_workspace(G_b, dT_b, 1, 1)
                 ops.conv2d_wgrad(G_b, dT_b, tmpF, 1, 1, ctx.workspace(n), accumulate=j0 > 0)                       # dF_b (+)= dT^T G -> [N][c8p]
                 if last:
-                    ops.copy_slice(TS(tmpF[:N * c8p].view(1, H, W, c8p), 0, c8p), TS(dqkv.buf[b:b + 1], 0, c8p))
+                    put(TS(tmpF[:N * c8p].view(1, H, W, c8p), 0, c8p), TS(dqkv.buf[b:b + 1], 0, c8p))
         # back through the fused QKV projection
         wcat: torch.Tensor = ctx.saved[(id(self), "wcat")]
         dw = ctx.vec(self, "dwcat", CQ * C_).view(CQ, C_, 1, 1)
         n = ops.wgrad_workspace(x, dqkv, 1, 1)
         ops.conv2d_wgrad(x, dqkv, dw, 1, 1, ctx.workspace(n))
-        wpd = ctx.vec(self, "wp_d", ops.lib.unet_pack_weights_size(CQ, C_, 1, 1))
-        ops.pack_weights(wcat.detach().contiguous(), 1, wpd)
+        wpd = ctx.vec(self, "wp_d", int((ops.lib.unet_pack_weights_size_bf16 if bf else ops.lib.unet_pack_weights_size)(CQ, C_, 1, 1)), dtype=dt)
+        ops.pack_weights(wcat.detach().contiguous(), 1, wpd, dtype=dt)
         dx = ctx.tmp(B, H, W, C_)
         ops.conv2d_dgrad(dqkv, wpd, dx, 1, 1, res=dout)                                           # + identity branch
         ctx.free(dO)

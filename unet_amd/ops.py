@@ -149,20 +149,41 @@ def pack_jobs(jobs, bf16: bool, device, cache: Optional[dict] = None):
 
 
 def pack_weights_strided(w_base_ptr: int, so: int, sr: int, O: int, R: int, out: torch.Tensor) -> torch.Tensor:
-    """packed 1x1 filter image whose (out o, reduction r) element is the float at w_base_ptr + 4*(o*so + r*sr)"""
+    """packed 1x1 filter image whose (out o, reduction r) element is the element at w_base_ptr + es * (o*so + r*sr) of an activation buffer
+    of out's storage type (es = 4 fp32 / 2 bf16)"""
+    if out.dtype == torch.bfloat16:
+        assert out.numel() >= lib.unet_pack_weights_size_bf16(O, R, 1, 0)
+        check(lib.unet_pack_weights_strided_bf16(w_base_ptr, so, sr, out.data_ptr(), O, R, _stream()), "pack_weights_strided_bf16")
+        return out
     assert out.numel() >= lib.unet_pack_weights_size(O, R, 1, 0)
     check(lib.unet_pack_weights_strided(w_base_ptr, so, sr, out.data_ptr(), O, R, _stream()), "pack_weights_strided")
     return out
 
 
+def pack_size(O: int, R: int, dtype) -> int:
+    """elements of the packed 1x1 image of an [O, R] operand in storage type dtype"""
+    return int((lib.unet_pack_weights_size_bf16 if dtype == torch.bfloat16 else lib.unet_pack_weights_size)(O, R, 1, 0))
+
+
 def row_softmax(x: "TS", y: "TS"):
-    _need_f32("row_softmax", x, y)
-    check(lib.unet_row_softmax(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, _stream()), "row_softmax")
+    """y = softmax over the C channels of every pixel of x; x (the logits) is fp32, y fp32 or bf16"""
+    _need_f32("row_softmax (logits)", x)
+    fn = lib.unet_row_softmax_bf16 if y.bf16 else lib.unet_row_softmax
+    check(fn(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, _stream()), "row_softmax")
 
 
 def row_softmax_bwd(y: "TS", dy: "TS", dx: "TS"):
-    _need_f32("row_softmax_bwd", y, dy, dx)
-    check(lib.unet_row_softmax_bwd(y.ptr, y.cs, y.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, y.P, y.C, _stream()), "row_softmax_bwd")
+    """dx = y * (dy - sum_c y dy); y and dx share a storage type (fp32 | bf16), dy is fp32"""
+    _need_f32("row_softmax_bwd (dy)", dy)
+    assert y.bf16 == dx.bf16
+    fn = lib.unet_row_softmax_bwd_bf16 if y.bf16 else lib.unet_row_softmax_bwd
+    check(fn(y.ptr, y.cs, y.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, y.P, y.C, _stream()), "row_softmax_bwd")
+
+
+def cast_slice(x: "TS", y: "TS"):
+    """fp32 slice -> bf16 slice (same geometry)"""
+    assert not x.bf16 and y.bf16 and x.P == y.P and x.C == y.C
+    check(lib.unet_cast_slice_bf16(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, _stream()), "cast_slice")
 
 
 def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, bias=None, res: Optional[TS] = None,
@@ -431,8 +452,8 @@ def copy_slice(x: TS, y: TS, accumulate=False):
 
 
 def relu_mask(g: TS, ref: TS, y: TS):
-    _need_f32("relu_mask", g, ref, y)
-    check(lib.unet_relu_mask(g.ptr, g.cs, g.co, ref.ptr, ref.cs, ref.co, y.ptr, y.cs, y.co, g.P, g.C, _stream()), "relu_mask")
+    assert g.bf16 == ref.bf16 == y.bf16
+    check(_fn("relu_mask", g)(g.ptr, g.cs, g.co, ref.ptr, ref.cs, ref.co, y.ptr, y.cs, y.co, g.P, g.C, _stream()), "relu_mask")
 
 
 def colsum_workspace(P, C_) -> int:
@@ -446,10 +467,10 @@ def colsum(x: TS, out: torch.Tensor, ws: torch.Tensor):
 
 
 def dot(x: TS, y: TS, out: torch.Tensor, ws: torch.Tensor):
-    """out[0] = sum(x * y) over all pixels and channels"""
-    _need_f32("dot", x, y)
+    """out[0] = sum(x * y) over all pixels and channels (fp32 accumulation)"""
+    assert x.bf16 == y.bf16
     assert ws.numel() >= colsum_workspace(x.P, x.C)
-    check(lib.unet_dot(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "dot")
+    check(_fn("dot", x)(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.P, x.C, out.data_ptr(), ws.data_ptr(), _stream()), "dot")
 
 
 # ------------------------------------------------------------------ loss
