@@ -257,17 +257,19 @@ def _want(regression, all_classes, specific_class):
 # ----------------------------------------------------------------------------------------------- configs[4]: a whole raster
 
 def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_empty: float = 0.9, dtype: str = "int8", nodata=None,
-                   regression: bool = False, all_classes: bool = False, specific_class: Optional[int] = None, batch_size: int = 16,
-                   out_path=None, class_zero: bool = False, timing: Optional[dict] = None):
+                   regression: bool = False, all_classes: bool = False, specific_class: Optional[int] = None, large_file: bool = False,
+                   batch_size: int = 16, out_path=None, class_zero: bool = False, timing: Optional[dict] = None):
     """Sliding-window prediction of a whole raster: equals split_raster(raster, patch_size=size, patch_overlap=overlap, max_empty) ->
     save_predictions(merge=True) on the tiles it writes (create_tiles_unet.py:252-434, predict.py:146-334).
 
     model    HipDynamicUnet (eval weights) or a Learner
     raster   path of a GeoTIFF, or an integer array [C, H, W] (numpy / torch, host or device)
     dtype    "int8" | "int16": the reference's DATATYPE switch -- int16 rasters are divided by 255 twice (utils.py:248-249 + IntToFloatTensor)
+    large_file  the reference's int8 merge (predict.py:209-214,288-289,324-329): probabilities as around(p * 31) in int8 rasters, int8 hit
+             counters, integer floor division -- same numbers as save_predictions(merge=True, large_file=True)
     Returns on rank 0 the merged array (uint8 argmax [H', W'] by default; float32 [C, H', W'] for all_classes; one float32 plane for
-    specific_class / regression) where H' x W' is the extent of the kept windows, None on the other ranks; with out_path it is also
-    written as a GeoTIFF (class_zero shifts the class ids back, predict.py:19-52)."""
+    specific_class / regression; int8 planes with large_file) where H' x W' is the extent of the kept windows, None on the other ranks;
+    with out_path it is also written as a GeoTIFF (class_zero shifts the class ids back, predict.py:19-52)."""
     model = getattr(model, "model", model)
     rank, local_rank, world = _dist_ctx()
     dev = model._device
@@ -308,7 +310,7 @@ def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_
         return ops.WindowBatch(src, gtab, first, n_pad, size, size)
 
     want = _want(regression, all_classes, specific_class)
-    out = _run_merge(model, places, MH, MW, regression, False, rank, world, batch_size, make_input, want, timing)
+    out = _run_merge(model, places, MH, MW, regression, bool(large_file and not regression), rank, world, batch_size, make_input, want, timing)
     if rank == 0 and out_path is not None:
         ogt = None if gt is None else [gt[0] + ox * gt[1], gt[1], 0.0, gt[3] + oy * gt[5], 0.0, gt[5]]
         store_tif(out_path, out, ogt, tags, -9999 if regression else None, class_zero)

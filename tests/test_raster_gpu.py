@@ -123,6 +123,11 @@ def test_predict_raster_equals_tile_files_flow_and_oracle(tmp_path):
     assert np.array_equal(d, out) and dmeta["geotransform"] == meta["geotransform"] == gt
     f2 = P.save_predictions(pkl, tiles / "img_tiles", False, merge=True, all_classes=True, AOI="flowall", validation_vision=False, batch_size=5)
     assert np.array_equal(read_tiff(f2)[0], allc)                 # float mosaics: same additions in the same order
+    # the reference's int8 "large_file" merge (predict.py:209-214, 324-329), raster path == tile-file path == the host arithmetic in numpy
+    f3 = P.save_predictions(pkl, tiles / "img_tiles", False, merge=True, all_classes=True, large_file=True, AOI="flow8", validation_vision=False,
+                            batch_size=5)
+    big8 = P.predict_raster(model, rpath, size, overlap, max_empty=max_empty, batch_size=5, all_classes=True, large_file=True)
+    assert big8.dtype == np.int8 and np.array_equal(read_tiff(f3)[0], big8)
 
     # (b) the per-tile device path
     mosaic, count = _tile_path_merge(model, zimg, wins, size, "int8", 3, rep=5)
@@ -130,6 +135,15 @@ def test_predict_raster_equals_tile_files_flow_and_oracle(tmp_path):
     am = torch.empty(count.shape, dtype=torch.uint8, device="cuda")
     ops.mosaic_finalize(mosaic, count, am)
     assert np.array_equal(am.cpu().numpy(), out) and np.array_equal(mosaic.cpu().numpy(), allc)
+
+    acc8, cnt8 = np.zeros((3, 700, 620), np.int8), np.zeros((3, 700, 620), np.int8)
+    for y, x in wins:
+        t = torch.from_numpy(scale_input(zimg[:, y:y + size, x:x + size], "int8"))[None].cuda().repeat(5, 1, 1, 1)
+        pr = model.predict_probs(t)[0][0].cpu().numpy()
+        acc8[:, y:y + size, x:x + size] += np.around(pr * 31).astype(np.int8)
+        cnt8[:, y:y + size, x:x + size] += 1
+    acc8[cnt8 > 0] //= cnt8[cnt8 > 0]
+    assert np.array_equal(acc8, big8)
 
     # (c) the CPU oracle: cut -> predict -> sum of probabilities / hit counter -> argmax (predict.py:193-203, 284-334)
     acc, cnt = np.zeros((3, 700, 620), np.float32), np.zeros((700, 620), np.int32)
