@@ -1,0 +1,46 @@
+"""A/B of two settings of unet_set_bf16_big_tile on one box, interleaved: python scripts/conv_ab.py A B [reps]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from unet_amd import ops
+from unet_amd.ops import TS
+import unet_amd._lib as L
+
+A, B = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dt = torch.bfloat16
+N, H = 16, 512
+g = torch.Generator(device="cuda").manual_seed(0)
+shapes = [(96, 96), (100, 100), (128, 128), (96, 100), (116, 100)]
+data = {}
+for Cin, Cout in shapes:
+    x = TS(torch.randn((N, H, H, ops.rupv(Cin, dt)), device="cuda", generator=g).to(dt), 0, Cin)
+    y = TS(torch.empty((N, H, H, ops.rupv(Cout, dt)), device="cuda", dtype=dt), 0, Cout)
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) / (Cin * 9) ** 0.5
+    data[(Cin, Cout)] = (x, y, ops.pack_weights(w, 0, dtype=dt))
+
+
+def run(k, n=20):
+    x, y, wp = data[k]
+    for _ in range(3):
+        ops.conv2d(x, wp, y, 3, 1)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        ops.conv2d(x, wp, y, 3, 1)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+res = {}
+for r in range(reps):
+    for k in shapes:
+        for v in (A, B):
+            L.lib.unet_set_bf16_big_tile(v)
+            res.setdefault((k, v), []).append(run(k))
+for k in shapes:
+    fl = 2.0 * N * H * H * k[0] * k[1] * 9
+    ta, tb = min(res[(k, A)]), min(res[(k, B)])
+    print(f"{k[0]:4d}->{k[1]:4d}  setting {A}: {ta:7.3f} ms {fl / ta / 1e9:7.1f} TF   setting {B}: {tb:7.3f} ms {fl / tb / 1e9:7.1f} TF   B/A time {tb / ta:.3f}", flush=True)
+L.lib.unet_set_bf16_big_tile(1)

@@ -173,6 +173,60 @@ def test_conv_bf16_big_tile_shared_odd_tile(Cout):
     assert bool((full[..., :32] == 7.25).all()) and bool((full[..., 32 + ops.rupv(Cout, torch.bfloat16):] == 7.25).all()), "wrote outside the slice"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (Cin, Cout, H, W): 16-wide channel tiles per 128-block / reduction tail
+    (32, 72, 256, 256),       # 5 tiles (shared third tile), one chunk
+    (96, 96, 250, 270),       # 6 tiles, ragged image edges (out-of-image halo items and pixels)
+    (100, 100, 256, 256),     # 7 tiles, tap-folded reduction tail
+    (112, 128, 256, 256),     # 8 tiles, zero-padded tail chunk (16 live channels of 32)
+    (40, 228, 256, 256),      # two launches: a full block of 8 tiles + a narrow block of 7; folded tail of 8 channels
+    (64, 160, 256, 256),      # 8 tiles + a 2-tile block (runs as 5 tiles over the zero filters of the padded image)
+])
+def test_conv_bf16_t256_kernel(case):
+    """conv_bf16_t256_kernel (the 256-pixel tile of the large 3x3 layers, variant ...7): forward with bias + residual + ReLU into a channel
+    slice, fp32 output, and the input gradient (filter slabs walked backwards) with residual + mask -- against fp64 on the same bf16 values.
+    The input is a slice of a wider buffer whose neighbouring channels are NOT zero: a tail chunk must not read them."""
+    from unet_amd import ops
+    Cin, Cout, H, W = case
+    N = 2
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    wb = _bf(w)
+    b = torch.randn(Cout, generator=g)
+    r = _bf(torch.randn(N, Cout, H, W, generator=g))
+    ref = F.relu(F.conv2d(x.double(), wb.double(), b.double(), padding=1) + r.double())
+    ci, co = ops.rupv(Cin, torch.bfloat16), ops.rupv(Cout, torch.bfloat16)
+    xt = _ts(x, cs=ci + 48, co=16)
+    rt = _ts(r, cs=co + 16, co=16)
+    yt = _empty(N, H, W, Cout, cs=co + 40, co=32)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    assert ops.conv2d_variant(xt, wp, yt, 3, 1) % 10 == 7
+    ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True)
+    got = _back(yt)
+    assert (got.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-5
+    full = yt.buf.float().cpu()
+    assert bool((full[..., :32] == 7.25).all()) and bool((full[..., 32 + co:] == 7.25).all()), "wrote outside the slice"
+    # fp32 output (the logits form), no epilogue
+    yf = _empty(N, H, W, Cout, dtype=torch.float32)
+    ops.conv2d(xt, wp, yf, 3, 1)
+    ref0 = F.conv2d(x.double(), wb.double(), padding=1)
+    assert (from_ts(yf).cpu().double() - ref0).abs().max().item() <= 5e-5 * ref0.abs().max().item() + 1e-6
+    # input gradient
+    dy = _bf(torch.randn(N, Cout, H, W, generator=g))
+    m = _bf(torch.randn(N, Cin, H, W, generator=g))
+    rr = _bf(torch.randn(N, Cin, H, W, generator=g))
+    dref = (torch.nn.grad.conv2d_input(x.shape, wb.double(), dy.double(), padding=1) + rr.double()) * (m > 0)
+    dxt = _empty(N, H, W, Cin, cs=ci + 8, co=8)
+    wpd = ops.pack_weights(w.cuda(), 1, dtype=torch.bfloat16)
+    dyt = _ts(dy, cs=co + 24, co=8)
+    if Cin > 64:
+        assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
+    ops.conv2d_dgrad(dyt, wpd, dxt, 3, 1, res=_ts(rr), mask=_ts(m, cs=ci + 16, co=16))
+    assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-5
+
+
 def test_conv_epilogue_slices_residual_relu_mask_bf16():
     """channel-sliced operands (concat elimination), bias + residual + ReLU forward epilogue, residual + ReLU-mask dgrad epilogue"""
     from unet_amd import ops
@@ -269,7 +323,7 @@ def test_elementwise_twins_bf16():
     assert (_back(acc_a) - from_ts(acc_b)).abs().max().item() <= tol(from_ts(acc_b))
     # the fp32-only entry points refuse bf16 tensors instead of misreading them
     with pytest.raises(Exception, match="bf16"):
-        ops.relu_mask(_ts(x), _ts(x), _ts(x))
+        ops.colsum(_ts(x), torch.zeros(C, device="cuda"), torch.zeros(ops.colsum_workspace(N * H * W, C), device="cuda"))
 
 
 @pytest.fixture(scope="module")

@@ -289,6 +289,358 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
 #undef TILE_COL
 }
 
+// ---- the 256-pixel tile of the large 3x3 layers: a main loop without bookkeeping --------------------------------------------------
+// In-kernel stamps of conv_bf16_kernel<32,4,2,2,2,6> (scripts/stamps_conv_bf16.py, 128 -> 128 at 16 x 512^2): 77 % of a workgroup's life
+// is the main loop, 2070 clocks per stage for the 2 x 32 MFMAs (1024 clocks) of the two waves of a SIMD, and only 10 % of that inside the
+// vmcnt waits and barriers.  The ISA of one stage: 32 MFMAs next to ~130 SALU, ~50 VALU, 35 branches and 44 s_waitcnt -- tap-table
+// decoding, 64-bit slab addresses, readfirstlanes, per-tile validity branches, LDS addresses.  A wave issues one instruction per ~4
+// clocks in order, so each wave spends ~1000 clocks per stage issuing bookkeeping during which it issues no MFMA: the loop is
+// instruction-issue bound.  This kernel is the same decomposition (2 x 2 waves, each 128 pixels x 64 channels, halo tile of 10 x 34
+// pixels x 32 channels double buffered in LDS, filter tiles global -> VGPR one stage ahead, identical accumulation chains per output
+// element up to the tap order of the input gradient) specialised to what the planner sends here -- 3x3 filter, stride 1, 32-pixel-wide
+// tile -- so that everything the generic loop computes per stage is a literal:
+//   * the nine taps are unrolled: LDS operand address = ONE lane register + an immediate (tap, pixel tile), no address arithmetic;
+//   * the filter slab pointer advances by one 64-bit scalar add per stage (taps in LDS order; the input gradient walks the slabs
+//     backwards: KArgs.sliver = 1);
+//   * halo items are buffer loads (out-of-image and channel-tail items read as zero through the descriptor's range check: no
+//     clamping, no select before the LDS store), issued in the first tap of a chunk only;
+//   * only the third / fourth channel tile of a wave can be absent or shared: two wave-uniform branches per half stage.
+constexpr int T256_HW = 34, T256_HPIX = 10 * 34, T256_ROWB = 4 * LDKB, T256_BUFB = T256_HPIX * T256_ROWB;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// NL filter tiles of one stage at p + lane offset + {0, 2048, 4096, 6144}; the last one through `vs` when it is the shared tile (SH)
+template <int NL, int SH>
+__device__ __forceinline__ void gld_bn(v4f (&d)[4], unsigned v0, unsigned v2, unsigned vs, const char* p) {
+    static_assert(NL == 3 || NL == 4, "filter tiles per wave");
+    if constexpr (NL == 4)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %7\n\tglobal_load_dwordx4 %1, %4, %7 offset:2048\n\t"
+                     "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %6, %7 offset:2048"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(v0), "v"(v2), "v"(SH ? vs : v2), "s"(p));
+    else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %5\n\tglobal_load_dwordx4 %1, %3, %5 offset:2048\n\t"
+                     "global_load_dwordx4 %2, %4, %5"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(v0), "v"(SH ? vs : v2), "s"(p));
+}
+// six halo items through a buffer descriptor (EXEC-masked like gld_halo: executed in the first tap of every chunk, fetches when `fetch`)
+__device__ __forceinline__ void gld_halo6_buf(v4f (&h)[6], const unsigned (&vo)[6], v4i rs, int soff, bool fetch) {
+    const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
+    u64 sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %[h0], %[o0], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h1], %[o1], %[rs], %[so] offen\n\t"
+                 "buffer_load_dwordx4 %[h2], %[o2], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h3], %[o3], %[rs], %[so] offen\n\t"
+                 "buffer_load_dwordx4 %[h4], %[o4], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h5], %[o5], %[rs], %[so] offen\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]), [sv] "=&s"(sv)
+                 : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]), [rs] "s"(rs), [so] "s"(soff),
+                   [on] "s"(on)
+                 : "scc");
+}
+
+#ifdef UNET_STAMPS
+// diagnostic build only (-DUNET_STAMPS; scripts/stamps_conv_bf16.py): wave 0 of every workgroup records shader-clock stamps around its
+// prologue, main loop and epilogue and the clocks it spent inside the per-stage vmcnt waits and the chunk barriers
+__device__ unsigned long long* g_stamps = nullptr;
+#define STAMP() __builtin_amdgcn_s_memtime()
+#define STAMP_WAIT(x_) do { const unsigned long long w0_ = STAMP(); x_; stw_ += STAMP() - w0_; } while (0)
+#define STAMP_BAR(x_) do { const unsigned long long w0_ = STAMP(); x_; stb_ += STAMP() - w0_; } while (0)
+#else
+#define STAMP_WAIT(x_) x_
+#define STAMP_BAR(x_) x_
+#endif
+
+// NTOT = 16-wide channel tiles of the workgroup (5..8), dealt round-robin to the two waves of a pixel row: NF = NTOT / 2 full tiles per
+// wave, and an odd last tile SHARED -- each wave multiplies it with the first half of ITS pixel tiles, wave wn = 1 numbers its halves
+// swapped (`r`), so the code of the two waves is the same and the stage body has no branch at all.
+template <int NTOT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32) {
+    constexpr int TW = 32, TH = 8, BN = 128, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
+    constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
+    static_assert(NTOT >= 5 && NTOT <= 8, "channel tiles of the 128-wide block");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const TapSet& ts = a.taps[0];
+#ifdef UNET_STAMPS
+    const unsigned long long st0_ = STAMP();
+    unsigned long long stw_ = 0, stb_ = 0;
+#endif
+
+    const int per_xcd = (int)(gridDim.x >> 3);
+    int bid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (bid >= a.mtiles * a.ntn) return;
+    const int nt = __builtin_amdgcn_readfirstlane(bid % a.ntn); bid /= a.ntn;
+    const int tx_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_x); bid /= a.tiles_x;
+    const int ty_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_y);
+    const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
+    const int oy0 = ty_t * TH, ox0 = tx_t * TW;
+    const int n0 = a.n_base + nt * BN;
+    const int kc0 = a.cps ? (int)blockIdx.y * a.cps : 0;
+    const int kc1 = a.cps ? (kc0 + a.cps < a.nchunks ? kc0 + a.cps : a.nchunks) : a.nchunks;
+    const int rev = a.sliver;                                  // taps in LDS order: the input gradient reads the filter slabs backwards
+    const int fold = a.fold, last = a.nchunks - 1;
+    const int kend = fold ? last : kc1;                        // chunks [kc0, kend) run nine plain stages; a folded tail chunk three
+
+    // ---- halo items: byte offsets inside the image, out-of-image items far beyond the descriptor's range (they read as zero) ----
+    constexpr unsigned OOB = 0x80000000u;
+    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * 2;
+    v4i rs;
+    {
+        const u64 b = sgpr_ptr(xb);
+        rs[0] = (int)(unsigned)b; rs[1] = (int)(unsigned)(b >> 32);
+        rs[2] = __builtin_amdgcn_readfirstlane(a.IH * a.IW * a.x_cs * 2); rs[3] = 0x00020000;
+    }
+    const int iy0 = oy0 + ts.min_dy, ix0 = ox0 + ts.min_dx;
+    unsigned goff[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = tid + it * NTH;
+        const int p = e >> 2, q = e & 3;
+        const int hy = p / T256_HW, hx = p - hy * T256_HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool inb = (e < T256_HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        goff[it] = inb ? (unsigned)((iy * a.IW + ix) * a.x_cs + a.x_co + 8 * q) * 2u : OOB;
+    }
+    // channels of the tail chunk beyond the (8-padded) input width belong to a neighbouring slice: this thread's channel group (tid & 3)
+    const bool tail_cut = last * KCB + 8 * (tid & 3) >= a.Cin4;
+    v4f hreg[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+#define T256_LOAD_HALO(chunk_, on_) do { unsigned vo_[HIT]; const bool cut_ = tail_cut && (chunk_) == last; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = cut_ ? OOB : goff[it]; \
+        gld_halo6_buf(hreg, vo_, rs, (chunk_) * (KCB * 2), (on_)); } while (0)
+    const unsigned vst = (unsigned)((tid >> 2) * T256_ROWB + (tid & 3) * 16);
+    const bool st5 = tid + 5 * NTH < T256_HPIX * 4;
+#define T256_STORE_HALO(buf_) do { char* d_ = lds + (buf_) * T256_BUFB + vst; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) \
+            if (it < 5 || st5) *reinterpret_cast<v4f*>(d_ + it * (NTH / 4) * T256_ROWB) = hreg[it]; } while (0)
+
+    // ---- channel tiles of this wave ----
+    const int r = (NTOT & 1) ? wn : 0;                  // pixel-tile halves swapped (accumulator half h holds pixel tiles 4 (h ^ r) ..)
+#define TILE_COL(n_) (((n_) == NF ? (n_) * 2 : (n_) * 2 + wn) * 16)
+    const unsigned voff = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
+    const unsigned voff2 = voff + 4096u;
+    const unsigned voffs = (NL > 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
+    const size_t slab_b = (size_t)a.coutPad * KCB * 2;
+    const char* wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2));
+    const long long tap_step = (rev ? -1ll : 1ll) * (long long)a.nchunks * (long long)slab_b;
+    const char* w0 = wbase + (rev ? 8ll * a.nchunks * (long long)slab_b : 0ll);       // slab of LDS tap 0, chunk 0
+    const char* wfold = wbase + (size_t)9 * a.nchunks * slab_b;
+    v4f b0[N16], b1[N16];
+
+    f32x4 acc[M16][N16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m)
+#pragma unroll
+        for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS operand address of pixel tile 0, tap 0 in buffer 0 (bytes); pixel tile m: + MOFF(m), tap t: + TOFF(t) -- immediates
+    const unsigned vbase = (unsigned)(((wm * 4) * T256_HW + l15) * T256_ROWB + 16 * kq);
+    const unsigned hsw = (unsigned)(r * 2 * T256_HW * T256_ROWB);           // (pixel tiles 4..7 lie two tile rows below tiles 0..3)
+#define MOFF(m_) ((((m_) >> 1) * T256_HW + ((m_) & 1) * 16) * T256_ROWB)
+#define TOFF(t_) ((((t_) / 3) * T256_HW + (t_) % 3) * T256_ROWB)
+    // folded tail: lane group kq reads channel group 0 of the tail chunk at ITS tap 4 j + kq (tap index in filter order)
+    unsigned vfold[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int tl = 4 * j + kq;
+        tl = tl < 9 ? tl : 0;                   // (beyond the taps the fold slab holds zeros)
+        const int pos = rev ? 8 - tl : tl;
+        vfold[j] = (unsigned)(((pos / 3) * T256_HW + pos % 3) * T256_ROWB) - 16u * (unsigned)kq;
+    }
+
+    // one stage: 2 halves x (4 pixel tiles from LDS, up to 4 x 4 MFMAs)
+#define T256_MFMA(bu_, addr_) do { \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
+            bf16x8 pv_[MH]; \
+            const unsigned ah_ = (addr_) + (h == 0 ? hsw : 2 * T256_HW * T256_ROWB - hsw); \
+            _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(lds + ah_ + MOFF(m))); \
+            _Pragma("unroll") for (int n = 0; n < NL; ++n) { \
+                if (n < NF || h == 0) { \
+                    const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
+                    _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                        acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, pv_[m], acc[h * MH + m][n], 0, 0, 0); \
+                } \
+            } \
+        } } while (0)
+
+    // ---- prologue: first halo tile, first filter tiles ----
+    const bool first_fold = fold && kc0 == last;
+    T256_LOAD_HALO(kc0, true);
+    gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, first_fold ? wfold : w0 + (size_t)kc0 * slab_b);
+    wait_loads(b0, hreg);
+    T256_STORE_HALO(kc0 & 1);
+    __syncthreads();
+#ifdef UNET_STAMPS
+    const unsigned long long st1_ = STAMP();
+#endif
+
+    const char* wcur = w0 + (size_t)kc0 * slab_b;
+    unsigned vcur = vbase + (unsigned)((kc0 & 1) * T256_BUFB);
+    for (int chunk = kc0; chunk < kend; ++chunk) {
+        const bool more = chunk + 1 < kend;
+        const bool next_any = more || fold;              // another halo tile is needed
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // the NEXT stage's filter tiles (after the last stage: a dummy fetch of the first slab keeps the load / wait pattern fixed)
+            if (t < 8) wcur += tap_step;
+            else wcur = more ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
+            if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wcur); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wcur);
+            if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);
+            // (sched_barrier: the wait names only the registers being loaded, nothing else keeps it behind the stage's MFMAs)
+            if (t & 1) { T256_MFMA(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); STAMP_WAIT(wait_loads(b0, hreg)); }
+            else { T256_MFMA(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); STAMP_WAIT(wait_loads(b1, hreg)); }
+        }
+        // the ninth stage loaded b1: the next chunk starts with b0 again
+#pragma unroll
+        for (int n = 0; n < N16; ++n) b0[n] = b1[n];
+        if (next_any) {
+            T256_STORE_HALO((chunk + 1) & 1);
+            STAMP_BAR(__syncthreads());
+            vcur = vbase + (unsigned)(((chunk + 1) & 1) * T256_BUFB);
+        }
+    }
+    if (fold) {
+        gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wfold + slab_b);
+        T256_MFMA(b0, vcur + vfold[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP_WAIT(wait_loads(b1, hreg));
+        gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wfold + 2 * slab_b);
+        T256_MFMA(b1, vcur + vfold[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP_WAIT(wait_loads(b0, hreg));
+        T256_MFMA(b0, vcur + vfold[2]);
+    }
+#undef T256_MFMA
+#undef T256_LOAD_HALO
+#undef T256_STORE_HALO
+#undef MOFF
+#undef TOFF
+
+#ifdef UNET_STAMPS
+    const unsigned long long st2_ = STAMP();
+#endif
+    // ---- epilogue: lane (pixel l15 of every pixel tile) x (4 consecutive channels 4kq.. of every channel tile) ----
+    const bool relu = a.flags & UNET_CONV_RELU;
+    const size_t img_pix = (size_t)img * a.OH * a.OW;
+    const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
+    const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+    int pidx[M16];
+    bool pval[M16];
+#pragma unroll
+    for (int m = 0; m < M16; ++m) {
+        const int pix = (wm * M16 + (m ^ (r * MH))) * 16 + l15;
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        pval[m] = oy < a.OH && ox < a.OW;
+        pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
+    }
+#pragma unroll
+    for (int n = 0; n < N16; ++n) {
+        if (n >= NL) continue;
+        const int c4 = n0 + TILE_COL(n) + 4 * kq;
+        constexpr int m_lo = 0;
+        const int m_hi = (n == NF) ? MH : M16;   // this wave's share of tile n
+        const bool cvalid = c4 < a.n_end;
+        const int cc = cvalid ? c4 : 0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && cvalid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (c4 + r < a.Cout) ? a.bias[c4 + r] : 0.f;
+        }
+        f32x4 v[M16];
+#pragma unroll
+        for (int m = 0; m < M16; ++m) v[m] = acc[m][n] + bv;
+        if (resb != nullptr) {
+            f32x4 rv[M16];
+#pragma unroll
+            for (int m = 0; m < M16; ++m) rv[m] = ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+#pragma unroll
+            for (int m = 0; m < M16; ++m) v[m] += rv[m];
+        }
+        if (relu) {
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.f);
+        }
+        if (maskb != nullptr) {
+            f32x4 mv[M16];
+#pragma unroll
+            for (int m = 0; m < M16; ++m) mv[m] = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = mv[m][r] > 0.f ? v[m][r] : 0.f;
+        }
+        if (y_f32) {
+            float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+                if (cvalid && pval[m] && m >= m_lo && m < m_hi) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
+        } else {
+            u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+                if (cvalid && pval[m] && m >= m_lo && m < m_hi) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
+        }
+    }
+#undef TILE_COL
+#ifdef UNET_STAMPS
+    if (g_stamps != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores of this wave have left
+        unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+        o[0] = st0_; o[1] = st1_; o[2] = st2_; o[3] = STAMP(); o[4] = stw_; o[5] = stb_; o[6] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        o[7] = 1;
+    }
+#endif
+}
+
+#ifdef UNET_STAMPS
+extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+template <int NTOT>
+int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
+    auto kern = conv_bf16_t256_kernel<NTOT>;
+    static unsigned long long configured = 0;
+    if (unet::first_use_on_device(&configured))
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, p.grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+// the channel-tile count is a template parameter: a launch whose last 128-wide channel block is narrower than the others (Cout = 228:
+// 8 + 7 tiles) is issued as two launches over disjoint channel ranges
+int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
+    const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn;
+    const int last_tiles = (cols - (nblk - 1) * 128 + 15) / 16;
+    auto one = [&](const Plan& q, int tiles) {
+        switch (tiles < 5 ? 5 : tiles) {         // (a narrower block multiplies the zero filters of the padded image: results beyond n_end are not stored)
+            case 8: return launch_t256n<8>(q, y_f32, st);
+            case 7: return launch_t256n<7>(q, y_f32, st);
+            case 6: return launch_t256n<6>(q, y_f32, st);
+            case 5: return launch_t256n<5>(q, y_f32, st);
+        }
+        unet::set_error("conv bf16: %d channel tiles in a 128-wide block of the 256-pixel tile", tiles);
+        return (int)UNET_E_UNSUPPORTED;
+    };
+    if (nblk == 1 || last_tiles == 8) return one(p, nblk == 1 ? last_tiles : 8);
+    Plan q = p;                                       // the full blocks
+    q.k.ntn = nblk - 1; q.k.n_end = p.k.n_base + (nblk - 1) * 128;
+    q.grid.x = (unsigned)unet::roundup(q.k.mtiles * q.k.ntn, 8);
+    int rc = one(q, 8);
+    if (rc != UNET_OK) return rc;
+    q = p;                                            // the narrow last block
+    q.k.ntn = 1; q.k.n_base = p.k.n_base + (nblk - 1) * 128;
+    q.grid.x = (unsigned)unet::roundup(q.k.mtiles, 8);
+    return one(q, last_tiles);
+}
+
 // packed filter image (bf16; layout: conv_common.h, bf16_image_value) from the fp32 master parameter [Cout,Cin,ks,ks]
 //   mode 0: o = cout, reduction r = cin;  mode 1 (input gradient): o = cin, reduction r = cout
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin, int T, int mode, int nchunks,
@@ -322,8 +674,7 @@ int launch_cfg(const Plan& p, int y_f32, hipStream_t st) {
 
 template <int TW, int HIT>
 int launch_bn(const Plan& p, int y_f32, hipStream_t st) {
-    if (p.bm == 256) {          // (TW = 32, HIT = 6 by construction of the plan)
-        if constexpr (TW == 32 && HIT == 6) return launch_cfg<32, 4, 2, 2, 2, 6>(p, y_f32, st);
+    if (p.bm == 256) {          // (dispatched to conv_bf16_t256_kernel by conv2d_bf16)
         unet::set_error("conv bf16: inconsistent plan for the 256-pixel tile");
         return UNET_E_UNSUPPORTED;
     }
@@ -358,6 +709,7 @@ int plan_bf16(const unet_conv_desc* d, Plan* p) {
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
     p->lds_bytes = (size_t)(32 + 2 * p->max_hpix * LDKB) * sizeof(float);
+    if (p->hit == 6) p->k.sliver = p->k.taps[0].dy[0] > 0 ? 1 : 0;      // 256-pixel tile: 1 = the taps of the input gradient (filter slabs backwards)
     p->k.fold = (p->nparity == 1 && p->splits == 1 && bf16_fold_tail(d->Cin, d->ks * d->ks)) ? 1 : 0;
     UNET_CHECK_ARG(d->Cout % 4 == 0 || d->y_co + unet::roundup(d->Cout, 4) <= d->y_cs, "conv bf16: the output slice must own its 4-channel padding");
     UNET_CHECK_ARG(unet::aligned16(d->y) && (!d->res || unet::aligned16(d->res)) && (!d->mask || unet::aligned16(d->mask)),
@@ -389,7 +741,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
     const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
-    if (p.hit == 6) rc = launch_bn<32, 6>(p, y_f32, st);
+    if (p.hit == 6) rc = launch_t256(p, y_f32, st);
     else rc = (p.hit == 10) ? launch_tw<10>(p, y_f32, st) : launch_tw<4>(p, y_f32, st);
     if (rc != UNET_OK || p.splits <= 1) return rc;
     return splitk_reduce(d, p, st);

@@ -111,7 +111,7 @@ def _check_function(name: str, body) -> Tuple[int, List[str]]:
         nonlocal nloads
         cur = dict(inflight)
         for ln, code, in_asm in blocks[i]:
-            if in_asm and code.startswith("global_load"):
+            if in_asm and code.startswith(("global_load", "buffer_load")):
                 ops = code.split(None, 1)[1].split(",")
                 dst = _regs(ops[0])
                 if report:
