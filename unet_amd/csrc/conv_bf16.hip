@@ -321,19 +321,25 @@ __device__ __forceinline__ void gld_bn(v4f (&d)[4], unsigned v0, unsigned v2, un
                      "global_load_dwordx4 %2, %4, %5"
                      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(v0), "v"(SH ? vs : v2), "s"(p));
 }
-// six halo items through a buffer descriptor (EXEC-masked like gld_halo: executed in the first tap of every chunk, fetches when `fetch`)
-__device__ __forceinline__ void gld_halo6_buf(v4f (&h)[6], const unsigned (&vo)[6], v4i rs, int soff, bool fetch) {
-    const u64 on = sgpr_ptr(reinterpret_cast<const void*>(fetch ? ~0ull : 0ull));
-    u64 sv;
-    asm volatile("s_and_saveexec_b64 %[sv], %[on]\n\ts_nop 4\n\t"
+// six halo items through a buffer descriptor; out-of-range offsets read as zero
+__device__ __forceinline__ void gld_halo6_buf(v4f (&h)[6], const unsigned (&vo)[6], v4i rs, int soff) {
+    asm volatile("s_nop 4\n\t"
                  "buffer_load_dwordx4 %[h0], %[o0], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h1], %[o1], %[rs], %[so] offen\n\t"
                  "buffer_load_dwordx4 %[h2], %[o2], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h3], %[o3], %[rs], %[so] offen\n\t"
-                 "buffer_load_dwordx4 %[h4], %[o4], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h5], %[o5], %[rs], %[so] offen\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]), [sv] "=&s"(sv)
-                 : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]), [rs] "s"(rs), [so] "s"(soff),
-                   [on] "s"(on)
-                 : "scc");
+                 "buffer_load_dwordx4 %[h4], %[o4], %[rs], %[so] offen\n\tbuffer_load_dwordx4 %[h5], %[o5], %[rs], %[so] offen"
+                 : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5])
+                 : [o0] "v"(vo[0]), [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5]), [rs] "s"(rs), [so] "s"(soff));
+}
+
+// s_waitcnt vmcnt(N) that "defines" the filter-tile set (and, with H, the halo registers) it completes: all but the N youngest loads have
+// landed; no consumer of those registers can be scheduled above it
+template <int N, bool H>
+__device__ __forceinline__ void wait_cnt(v4f (&x)[4], v4f (&h)[6]) {
+    if constexpr (H)
+        asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]),
+                     "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]) : [n] "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : [n] "n"(N));
 }
 
 #ifdef UNET_STAMPS
@@ -341,7 +347,7 @@ __device__ __forceinline__ void gld_halo6_buf(v4f (&h)[6], const unsigned (&vo)[
 // prologue, main loop and epilogue and the clocks it spent inside the per-stage vmcnt waits and the chunk barriers
 __device__ unsigned long long* g_stamps = nullptr;
 #define STAMP() __builtin_amdgcn_s_memtime()
-#define STAMP_WAIT(x_) do { const unsigned long long w0_ = STAMP(); x_; stw_ += STAMP() - w0_; } while (0)
+#define STAMP_WAIT(x_) do { const unsigned long long w0_ = STAMP(); x_; const unsigned long long d_ = STAMP() - w0_; stw_ += d_; stwt_[stt_] += d_; } while (0)
 #define STAMP_BAR(x_) do { const unsigned long long w0_ = STAMP(); x_; stb_ += STAMP() - w0_; } while (0)
 #else
 #define STAMP_WAIT(x_) x_
@@ -364,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const TapSet& ts = a.taps[0];
 #ifdef UNET_STAMPS
     const unsigned long long st0_ = STAMP();
-    unsigned long long stw_ = 0, stb_ = 0;
+    unsigned long long stw_ = 0, stb_ = 0, stwt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int stt_ = 9;          // tap of the stage whose wait is being stamped (9: folded tail)
 #endif
 
     const int per_xcd = (int)(gridDim.x >> 3);
@@ -407,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     v4f hreg[HIT];
 #pragma unroll
     for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
-#define T256_LOAD_HALO(chunk_, on_) do { unsigned vo_[HIT]; const bool cut_ = tail_cut && (chunk_) == last; \
+#define T256_LOAD_HALO(chunk_, on_) do { unsigned vo_[HIT]; const bool cut_ = !(on_) || (tail_cut && (chunk_) == last); \
         _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = cut_ ? OOB : goff[it]; \
-        gld_halo6_buf(hreg, vo_, rs, (chunk_) * (KCB * 2), (on_)); } while (0)
+        gld_halo6_buf(hreg, vo_, rs, (on_) ? (chunk_) * (KCB * 2) : 0); } while (0)
     const unsigned vst = (unsigned)((tid >> 2) * T256_ROWB + (tid & 3) * 16);
     const bool st5 = tid + 5 * NTH < T256_HPIX * 4;
 #define T256_STORE_HALO(buf_) do { char* d_ = lds + (buf_) * T256_BUFB + vst; \
@@ -450,7 +457,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         vfold[j] = (unsigned)(((pos / 3) * T256_HW + pos % 3) * T256_ROWB) - 16u * (unsigned)kq;
     }
 
-    // one stage: 2 halves x (4 pixel tiles from LDS, up to 4 x 4 MFMAs)
+    // One stage: 2 halves x (4 pixel tiles from LDS, up to 4 x 4 MFMAs).  (Reading the pixel tiles half a stage ahead into a second
+    // register set -- 234 instead of 216 VGPRs -- was built and measured against this form on one box: equal within 1 %; the partner wave
+    // of the SIMD already covers the LDS round trip.)
 #define T256_MFMA(bu_, addr_) do { \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
             bf16x8 pv_[MH]; \
@@ -484,14 +493,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         const bool next_any = more || fold;              // another halo tile is needed
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+#ifdef UNET_STAMPS
+            stt_ = t;
+#endif
             // the NEXT stage's filter tiles (after the last stage: a dummy fetch of the first slab keeps the load / wait pattern fixed)
             if (t < 8) wcur += tap_step;
             else wcur = more ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
             if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wcur); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wcur);
-            if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);
-            // (sched_barrier: the wait names only the registers being loaded, nothing else keeps it behind the stage's MFMAs)
-            if (t & 1) { T256_MFMA(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); STAMP_WAIT(wait_loads(b0, hreg)); }
-            else { T256_MFMA(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); STAMP_WAIT(wait_loads(b1, hreg)); }
+            if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);        // (nothing follows: out-of-range offsets, the load count stays the same)
+            // The wait for the next stage's filter tiles (sched_barrier: it names only the registers being loaded, nothing else keeps it
+            // behind the stage's MFMAs).  vmcnt counts in issue order and the halo items were issued BEHIND the tiles of tap 1: tap 0 ends
+            // with vmcnt(6) and leaves them in flight until the end of tap 1 -- two stages for the HBM latency instead of one (stamps by
+            // tap: the wait of tap 1 is the longest, ~530 clocks per chunk, the others 50-150).  Every chunk issues the same loads (after
+            // the last one with out-of-range halo offsets), so the count is a literal.
+            if (t & 1) { T256_MFMA(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 1) STAMP_WAIT((wait_cnt<0, true>(b0, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b0, hreg))); }
+            else { T256_MFMA(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 0) STAMP_WAIT((wait_cnt<HIT, false>(b1, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b1, hreg))); }
         }
         // the ninth stage loaded b1: the next chunk starts with b0 again
 #pragma unroll
@@ -503,6 +519,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         }
     }
     if (fold) {
+#ifdef UNET_STAMPS
+        stt_ = 9;
+#endif
         gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wfold + slab_b);
         T256_MFMA(b0, vcur + vfold[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -590,7 +609,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #ifdef UNET_STAMPS
     if (g_stamps != nullptr && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores of this wave have left
-        unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+        unsigned long long* o = g_stamps + (size_t)blockIdx.x * 24;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[8 + i] = stwt_[i];
         o[0] = st0_; o[1] = st1_; o[2] = st2_; o[3] = STAMP(); o[4] = stw_; o[5] = stb_; o[6] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
         o[7] = 1;
     }
