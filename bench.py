@@ -148,7 +148,7 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # fp32: conv_igemm16_kernel<32,2,2,2,2,4> (all wide 3x3 / 1x1 convs, fwd and dgrad); bf16: conv_bf16_kernel<32,4,2,2,2,6> (the 256-pixel tile)
+    # fp32: conv_igemm16_kernel<32,2,2,2,2,4> (all wide 3x3 / 1x1 convs, fwd and dgrad); bf16: conv_bf16_t256_kernel (the 256-pixel tile of the wide 3x3 layers)
     pr = None
     if probe:
         _ops.CONV_PROBE = pr = _ops.ConvProbe(32 * 10000 + 128 * 10 + (0 if dtype == "f32" else 7))
@@ -188,11 +188,12 @@ def roofline_of(ps, dtype, dt, steps, pmc):
                 "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
                 "traffic": pmc.get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"), **common}
     achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "conv_bf16_kernel<32,4,2,2,2,6> (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM: every wide "
-                                      "3x3/1x1 conv, forward and input-gradient); algorithmic bytes = every operand tensor once in, the "
-                                      "result once out, the packed filter once",
+    return {"bound": "hbm", "kernel": "conv_bf16_t256_kernel (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM, 256-pixel x 128-channel tile: "
+                                      "every wide 3x3 conv, forward and input-gradient; rocprofv3 lists its instantiations <6>, <7>, <8> = "
+                                      "16-wide channel tiles per block); algorithmic bytes = every operand tensor once in, the result once "
+                                      "out, the packed filter once",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-            "traffic": pmc.get("conv_bf16_kernel<32,4,2,2,2,6>", {}).get("hbm_bytes_per_launch"),
+            "traffic": pmc.get("conv_bf16_t256_kernel", {}).get("hbm_bytes_per_launch"),
             "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1),
             "mfma_frac_of_bf16_peak": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), **common}
 

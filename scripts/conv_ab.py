@@ -1,4 +1,5 @@
-"""A/B of two settings of unet_set_bf16_big_tile on one box, interleaved: python scripts/conv_ab.py A B [reps]"""
+"""Isolated bf16 3x3 launches at 16 x 512^2 under several settings of unet_set_bf16_big_tile on one box, interleaved (1 = the 256-pixel tile with its
+own choice of tiles per workgroup, 100 + n = n tiles per workgroup, 0 = the 128-pixel tile): python scripts/conv_ab.py 1 101 108 [reps]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -6,8 +7,8 @@ from unet_amd import ops
 from unet_amd.ops import TS
 import unet_amd._lib as L
 
-A, B = int(sys.argv[1]), int(sys.argv[2])
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+settings = [int(v) for v in sys.argv[1:] if int(v) >= 0 and (int(v) == 0 or int(v) == 1 or int(v) >= 100)] or [1]
+reps = 3
 dt = torch.bfloat16
 N, H = 16, 512
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -36,11 +37,10 @@ def run(k, n=20):
 res = {}
 for r in range(reps):
     for k in shapes:
-        for v in (A, B):
+        for v in settings:
             L.lib.unet_set_bf16_big_tile(v)
             res.setdefault((k, v), []).append(run(k))
 for k in shapes:
     fl = 2.0 * N * H * H * k[0] * k[1] * 9
-    ta, tb = min(res[(k, A)]), min(res[(k, B)])
-    print(f"{k[0]:4d}->{k[1]:4d}  setting {A}: {ta:7.3f} ms {fl / ta / 1e9:7.1f} TF   setting {B}: {tb:7.3f} ms {fl / tb / 1e9:7.1f} TF   B/A time {tb / ta:.3f}", flush=True)
+    print(f"{k[0]:4d}->{k[1]:4d} " + "   ".join(f"[{v}] {min(res[(k, v)]):6.3f} ms {fl / min(res[(k, v)]) / 1e9:6.0f} TF" for v in settings), flush=True)
 L.lib.unet_set_bf16_big_tile(1)

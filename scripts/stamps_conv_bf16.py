@@ -25,9 +25,9 @@ for Cin, Cout in [(96, 96), (100, 100), (128, 128)]:
     fn(None)
     s = buf.cpu().numpy().reshape(-1, 24)
     s = s[s[:, 7] == 1]
-    life, pro, loop, epi, waits, bars = s[:, 3] - s[:, 0], s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4], s[:, 5]
+    life, pro, loop, epi, waits, bars, nt = s[:, 3] - s[:, 0], s[:, 1] - s[:, 0], s[:, 2], s[:, 18], s[:, 4], s[:, 5], s[:, 19]
     med = lambda a: float(np.median(a))
     span = (s[:, 6].max() - s[:, 6].min()) / 100.0   # realtime: 100 MHz -> us
-    print(f"{Cin}->{Cout}: {len(s)} workgroups, kernel span {span:.0f} us; per workgroup (median shader clocks): life {med(life):.0f}  prologue {med(pro):.0f}  "
-          f"main loop {med(loop):.0f} (in vmcnt waits {med(waits):.0f}, in chunk barriers {med(bars):.0f})  epilogue {med(epi):.0f}", flush=True)
+    print(f"{Cin}->{Cout}: {len(s)} workgroups of {med(nt):.0f} tiles, kernel span {span:.0f} us; per workgroup (median shader clocks): life {med(life):.0f}  first prologue {med(pro):.0f}  "
+          f"main loops {med(loop):.0f} (in vmcnt waits {med(waits):.0f}, in chunk barriers {med(bars):.0f})  epilogues (next tile's loads in flight) {med(epi):.0f}", flush=True)
     print("   waits by tap 0..8, folded tail:", " ".join(f"{med(s[:, 8 + i]):.0f}" for i in range(10)), flush=True)

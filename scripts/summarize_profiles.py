@@ -20,7 +20,9 @@ def short(name: str) -> str:
     name = name.split("(")[0].replace(" ", "")
     # conv_igemm16_kernel<..., SLV>: the sliver instantiation (the 3 launches per step with a 16 n + 4 output width) is the same kernel
     # template as the plain one; the PMC summary and pmc_traffic.json aggregate both under the name without the flag
-    return re.sub(r"^(conv_igemm16_kernel<[0-9,]+),(?:true|false)>$", r"\1>", name)
+    name = re.sub(r"^(conv_igemm16_kernel<[0-9,]+),(?:true|false)>$", r"\1>", name)
+    # conv_bf16_t256_kernel<NTOT>: one kernel template, instantiated per channel-tile count of the 128-wide block; aggregated under the bare name
+    return re.sub(r"^conv_bf16_t256_kernel<[0-9]+>$", "conv_bf16_t256_kernel", name)
 
 
 def pmc(dirname):

@@ -357,8 +357,10 @@ __device__ unsigned long long* g_stamps = nullptr;
 // NTOT = 16-wide channel tiles of the workgroup (5..8), dealt round-robin to the two waves of a pixel row: NF = NTOT / 2 full tiles per
 // wave, and an odd last tile SHARED -- each wave multiplies it with the first half of ITS pixel tiles, wave wn = 1 numbers its halves
 // swapped (`r`), so the code of the two waves is the same and the stage body has no branch at all.
+// A workgroup walks `tpw` consecutive output tiles: the first halo tile and filter tiles of tile i + 1 are requested BEFORE the epilogue
+// of tile i, so the HBM latency of a tile's prologue (14 % of a one-tile workgroup's life in the stamps) hides behind the stores.
 template <int NTOT>
-__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32) {
+__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw) {
     constexpr int TW = 32, TH = 8, BN = 128, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
     constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
     static_assert(NTOT >= 5 && NTOT <= 8, "channel tiles of the 128-wide block");
@@ -370,45 +372,56 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const TapSet& ts = a.taps[0];
 #ifdef UNET_STAMPS
     const unsigned long long st0_ = STAMP();
-    unsigned long long stw_ = 0, stb_ = 0, stwt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stw_ = 0, stb_ = 0, stl_ = 0, ste_ = 0, stwt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st1_ = 0;
     int stt_ = 9;          // tap of the stage whose wait is being stamped (9: folded tail)
 #endif
 
+    // XCD-aware order (see conv_igemm16_kernel): every XCD owns one contiguous range of workgroups, a workgroup `tpw` consecutive tiles
     const int per_xcd = (int)(gridDim.x >> 3);
-    int bid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (bid >= a.mtiles * a.ntn) return;
-    const int nt = __builtin_amdgcn_readfirstlane(bid % a.ntn); bid /= a.ntn;
-    const int tx_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_x); bid /= a.tiles_x;
-    const int ty_t = __builtin_amdgcn_readfirstlane(bid % a.tiles_y);
-    const int img = __builtin_amdgcn_readfirstlane(bid / a.tiles_y);
-    const int oy0 = ty_t * TH, ox0 = tx_t * TW;
-    const int n0 = a.n_base + nt * BN;
+    const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int ntiles = a.mtiles * a.ntn;
+    int tile = wg * tpw;
+    const int tend = tile + tpw < ntiles ? tile + tpw : ntiles;
+    if (tile >= tend) return;
     const int kc0 = a.cps ? (int)blockIdx.y * a.cps : 0;
     const int kc1 = a.cps ? (kc0 + a.cps < a.nchunks ? kc0 + a.cps : a.nchunks) : a.nchunks;
     const int rev = a.sliver;                                  // taps in LDS order: the input gradient reads the filter slabs backwards
     const int fold = a.fold, last = a.nchunks - 1;
     const int kend = fold ? last : kc1;                        // chunks [kc0, kend) run nine plain stages; a folded tail chunk three
+    const bool first_fold = fold && kc0 == last;
 
-    // ---- halo items: byte offsets inside the image, out-of-image items far beyond the descriptor's range (they read as zero) ----
+    // ---- per-tile state: output origin, channel block, filter slabs, halo items ----
+    // halo items are byte offsets inside the image; out-of-image items lie far beyond the descriptor's range (they read as zero)
     constexpr unsigned OOB = 0x80000000u;
-    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * 2;
+    int oy0, ox0, n0, img;
+    const char *wbase, *w0, *wfold;
     v4i rs;
-    {
-        const u64 b = sgpr_ptr(xb);
-        rs[0] = (int)(unsigned)b; rs[1] = (int)(unsigned)(b >> 32);
-        rs[2] = __builtin_amdgcn_readfirstlane(a.IH * a.IW * a.x_cs * 2); rs[3] = 0x00020000;
-    }
-    const int iy0 = oy0 + ts.min_dy, ix0 = ox0 + ts.min_dx;
     unsigned goff[HIT];
-#pragma unroll
-    for (int it = 0; it < HIT; ++it) {
-        const int e = tid + it * NTH;
-        const int p = e >> 2, q = e & 3;
-        const int hy = p / T256_HW, hx = p - hy * T256_HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool inb = (e < T256_HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        goff[it] = inb ? (unsigned)((iy * a.IW + ix) * a.x_cs + a.x_co + 8 * q) * 2u : OOB;
-    }
+    const size_t slab_b = (size_t)a.coutPad * KCB * 2;
+    const long long tap_step = (rev ? -1ll : 1ll) * (long long)a.nchunks * (long long)slab_b;
+#define T256_SETUP(tile_) do { \
+        int id_ = (tile_); \
+        const int nt_ = __builtin_amdgcn_readfirstlane(id_ % a.ntn); id_ /= a.ntn; \
+        const int tx_ = __builtin_amdgcn_readfirstlane(id_ % a.tiles_x); id_ /= a.tiles_x; \
+        const int ty_ = __builtin_amdgcn_readfirstlane(id_ % a.tiles_y); \
+        img = __builtin_amdgcn_readfirstlane(id_ / a.tiles_y); \
+        oy0 = ty_ * TH; ox0 = tx_ * TW; n0 = a.n_base + nt_ * BN; \
+        wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2)); \
+        w0 = wbase + (rev ? 8ll * a.nchunks * (long long)slab_b : 0ll);       /* slab of LDS tap 0, chunk 0 */ \
+        wfold = wbase + (size_t)9 * a.nchunks * slab_b; \
+        const u64 xb_ = sgpr_ptr(reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * 2); \
+        rs[0] = (int)(unsigned)xb_; rs[1] = (int)(unsigned)(xb_ >> 32); \
+        rs[2] = __builtin_amdgcn_readfirstlane(a.IH * a.IW * a.x_cs * 2); rs[3] = 0x00020000; \
+        const int iy0_ = oy0 + ts.min_dy, ix0_ = ox0 + ts.min_dx; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) { \
+            const int e = tid + it * NTH; \
+            const int p = e >> 2, q = e & 3; \
+            const int hy = p / T256_HW, hx = p - hy * T256_HW; \
+            const int iy = iy0_ + hy, ix = ix0_ + hx; \
+            const bool inb = (e < T256_HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; \
+            goff[it] = inb ? (unsigned)((iy * a.IW + ix) * a.x_cs + a.x_co + 8 * q) * 2u : OOB; \
+        } } while (0)
     // channels of the tail chunk beyond the (8-padded) input width belong to a neighbouring slice: this thread's channel group (tid & 3)
     const bool tail_cut = last * KCB + 8 * (tid & 3) >= a.Cin4;
     v4f hreg[HIT];
@@ -429,11 +442,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const unsigned voff = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
     const unsigned voff2 = voff + 4096u;
     const unsigned voffs = (NL > 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
-    const size_t slab_b = (size_t)a.coutPad * KCB * 2;
-    const char* wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2));
-    const long long tap_step = (rev ? -1ll : 1ll) * (long long)a.nchunks * (long long)slab_b;
-    const char* w0 = wbase + (rev ? 8ll * a.nchunks * (long long)slab_b : 0ll);       // slab of LDS tap 0, chunk 0
-    const char* wfold = wbase + (size_t)9 * a.nchunks * slab_b;
     v4f b0[N16], b1[N16];
 
     f32x4 acc[M16][N16];
@@ -475,136 +483,163 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
             } \
         } } while (0)
 
-    // ---- prologue: first halo tile, first filter tiles ----
-    const bool first_fold = fold && kc0 == last;
+    // ---- first tile: halo tile of the first chunk, filter tiles of the first stage ----
+    T256_SETUP(tile);
     T256_LOAD_HALO(kc0, true);
     gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, first_fold ? wfold : w0 + (size_t)kc0 * slab_b);
-    wait_loads(b0, hreg);
-    T256_STORE_HALO(kc0 & 1);
-    __syncthreads();
+
+    for (;;) {
+        wait_cnt<0, true>(b0, hreg);
+        __syncthreads();                    // (every wave has left the LDS buffers of the previous tile)
+        T256_STORE_HALO(kc0 & 1);
+        __syncthreads();
 #ifdef UNET_STAMPS
-    const unsigned long long st1_ = STAMP();
+        const unsigned long long sl0_ = STAMP();
+        if (st1_ == 0) st1_ = sl0_;
 #endif
 
-    const char* wcur = w0 + (size_t)kc0 * slab_b;
-    unsigned vcur = vbase + (unsigned)((kc0 & 1) * T256_BUFB);
-    for (int chunk = kc0; chunk < kend; ++chunk) {
-        const bool more = chunk + 1 < kend;
-        const bool next_any = more || fold;              // another halo tile is needed
+        const char* wcur = w0 + (size_t)kc0 * slab_b;
+        unsigned vcur = vbase + (unsigned)((kc0 & 1) * T256_BUFB);
+        for (int chunk = kc0; chunk < kend; ++chunk) {
+            const bool more = chunk + 1 < kend;
+            const bool next_any = more || fold;              // another halo tile is needed
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < 9; ++t) {
 #ifdef UNET_STAMPS
-            stt_ = t;
+                stt_ = t;
 #endif
-            // the NEXT stage's filter tiles (after the last stage: a dummy fetch of the first slab keeps the load / wait pattern fixed)
-            if (t < 8) wcur += tap_step;
-            else wcur = more ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
-            if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wcur); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wcur);
-            if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);        // (nothing follows: out-of-range offsets, the load count stays the same)
-            // The wait for the next stage's filter tiles (sched_barrier: it names only the registers being loaded, nothing else keeps it
-            // behind the stage's MFMAs).  vmcnt counts in issue order and the halo items were issued BEHIND the tiles of tap 1: tap 0 ends
-            // with vmcnt(6) and leaves them in flight until the end of tap 1 -- two stages for the HBM latency instead of one (stamps by
-            // tap: the wait of tap 1 is the longest, ~530 clocks per chunk, the others 50-150).  Every chunk issues the same loads (after
-            // the last one with out-of-range halo offsets), so the count is a literal.
-            if (t & 1) { T256_MFMA(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 1) STAMP_WAIT((wait_cnt<0, true>(b0, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b0, hreg))); }
-            else { T256_MFMA(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 0) STAMP_WAIT((wait_cnt<HIT, false>(b1, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b1, hreg))); }
-        }
-        // the ninth stage loaded b1: the next chunk starts with b0 again
+                // the NEXT stage's filter tiles (after the last stage: a dummy fetch of the first slab keeps the load / wait pattern fixed)
+                if (t < 8) wcur += tap_step;
+                else wcur = more ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
+                if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wcur); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wcur);
+                if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);        // (nothing follows: out-of-range offsets, the load count stays the same)
+                // The wait for the next stage's filter tiles (sched_barrier: it names only the registers being loaded, nothing else keeps
+                // it behind the stage's MFMAs).  vmcnt counts in issue order and the halo items were issued BEHIND the tiles of tap 1: tap 0
+                // ends with vmcnt(6) and leaves them in flight until the end of tap 1 -- two stages for the HBM latency instead of one
+                // (stamps by tap: the wait of tap 1 is the longest, ~530 clocks per chunk, the others 50-150).  Every chunk issues the
+                // same loads (after the last one with out-of-range halo offsets), so the count is a literal.
+                if (t & 1) { T256_MFMA(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 1) STAMP_WAIT((wait_cnt<0, true>(b0, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b0, hreg))); }
+                else { T256_MFMA(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); if (t == 0) STAMP_WAIT((wait_cnt<HIT, false>(b1, hreg))); else STAMP_WAIT((wait_cnt<0, false>(b1, hreg))); }
+            }
+            // the ninth stage loaded b1: the next chunk starts with b0 again
 #pragma unroll
-        for (int n = 0; n < N16; ++n) b0[n] = b1[n];
-        if (next_any) {
-            T256_STORE_HALO((chunk + 1) & 1);
-            STAMP_BAR(__syncthreads());
-            vcur = vbase + (unsigned)(((chunk + 1) & 1) * T256_BUFB);
+            for (int n = 0; n < N16; ++n) b0[n] = b1[n];
+            if (next_any) {
+                T256_STORE_HALO((chunk + 1) & 1);
+                STAMP_BAR(__syncthreads());
+                vcur = vbase + (unsigned)(((chunk + 1) & 1) * T256_BUFB);
+            }
         }
-    }
-    if (fold) {
+        if (fold) {
 #ifdef UNET_STAMPS
-        stt_ = 9;
+            stt_ = 9;
 #endif
-        gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wfold + slab_b);
-        T256_MFMA(b0, vcur + vfold[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP_WAIT(wait_loads(b1, hreg));
-        gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wfold + 2 * slab_b);
-        T256_MFMA(b1, vcur + vfold[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP_WAIT(wait_loads(b0, hreg));
-        T256_MFMA(b0, vcur + vfold[2]);
+            gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wfold + slab_b);
+            T256_MFMA(b0, vcur + vfold[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_WAIT((wait_cnt<0, false>(b1, hreg)));
+            gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wfold + 2 * slab_b);
+            T256_MFMA(b1, vcur + vfold[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_WAIT((wait_cnt<0, false>(b0, hreg)));
+            T256_MFMA(b0, vcur + vfold[2]);
+        }
+#ifdef UNET_STAMPS
+        const unsigned long long se0_ = STAMP();
+        stl_ += se0_ - sl0_;
+#endif
+
+        // ---- the next tile's first loads go out before this tile's epilogue (after the last tile: out-of-range halo offsets and the
+        //      first slab again, so that the load / wait pattern is the same) ----
+        const int oy0c = oy0, ox0c = ox0, n0c = n0, imgc = img;
+        ++tile;
+        const bool more_tiles = tile < tend;
+        T256_SETUP(more_tiles ? tile : tile - 1);
+        T256_LOAD_HALO(kc0, more_tiles);
+        gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, first_fold ? wfold : w0 + (size_t)kc0 * slab_b);
+
+        // ---- epilogue: lane (pixel l15 of every pixel tile) x (4 consecutive channels 4kq.. of every channel tile), half the pixel
+        //      tiles at a time (the next tile's 40 load registers are live here) ----
+        const bool relu = a.flags & UNET_CONV_RELU;
+        const size_t img_pix = (size_t)imgc * a.OH * a.OW;
+        const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
+        const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int pidx[MH];
+            bool pval[MH];
+#pragma unroll
+            for (int m = 0; m < MH; ++m) {
+                const int pix = (wm * M16 + ((h * MH + m) ^ (r * MH))) * 16 + l15;
+                const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
+                pval[m] = oy < a.OH && ox < a.OW;
+                pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
+            }
+#pragma unroll
+            for (int n = 0; n < NL; ++n) {
+                if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
+                const int c4 = n0c + TILE_COL(n) + 4 * kq;
+                const bool cvalid = c4 < a.n_end;
+                const int cc = cvalid ? c4 : 0;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr && cvalid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+                }
+                f32x4 v[MH];
+#pragma unroll
+                for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bv;
+                if (resb != nullptr) {
+                    f32x4 rv[MH];
+#pragma unroll
+                    for (int m = 0; m < MH; ++m) rv[m] = ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+#pragma unroll
+                    for (int m = 0; m < MH; ++m) v[m] += rv[m];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[m][q] = fmaxf(v[m][q], 0.f);
+                }
+                if (maskb != nullptr) {
+                    f32x4 mv[MH];
+#pragma unroll
+                    for (int m = 0; m < MH; ++m) mv[m] = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[m][q] = mv[m][q] > 0.f ? v[m][q] : 0.f;
+                }
+                if (y_f32) {
+                    float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+                        if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
+                } else {
+                    u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+                        if (cvalid && pval[m]) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
+                }
+            }
+        }
+#ifdef UNET_STAMPS
+        ste_ += STAMP() - se0_;
+#endif
+        if (!more_tiles) break;
+#pragma unroll
+        for (int m = 0; m < M16; ++m)
+#pragma unroll
+            for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    wait_cnt<0, true>(b0, hreg);             // (the dummy loads issued after the last tile)
 #undef T256_MFMA
 #undef T256_LOAD_HALO
 #undef T256_STORE_HALO
+#undef T256_SETUP
 #undef MOFF
 #undef TOFF
-
-#ifdef UNET_STAMPS
-    const unsigned long long st2_ = STAMP();
-#endif
-    // ---- epilogue: lane (pixel l15 of every pixel tile) x (4 consecutive channels 4kq.. of every channel tile) ----
-    const bool relu = a.flags & UNET_CONV_RELU;
-    const size_t img_pix = (size_t)img * a.OH * a.OW;
-    const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
-    const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
-    int pidx[M16];
-    bool pval[M16];
-#pragma unroll
-    for (int m = 0; m < M16; ++m) {
-        const int pix = (wm * M16 + (m ^ (r * MH))) * 16 + l15;
-        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
-        pval[m] = oy < a.OH && ox < a.OW;
-        pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
-    }
-#pragma unroll
-    for (int n = 0; n < N16; ++n) {
-        if (n >= NL) continue;
-        const int c4 = n0 + TILE_COL(n) + 4 * kq;
-        constexpr int m_lo = 0;
-        const int m_hi = (n == NF) ? MH : M16;   // this wave's share of tile n
-        const bool cvalid = c4 < a.n_end;
-        const int cc = cvalid ? c4 : 0;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr && cvalid) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (c4 + r < a.Cout) ? a.bias[c4 + r] : 0.f;
-        }
-        f32x4 v[M16];
-#pragma unroll
-        for (int m = 0; m < M16; ++m) v[m] = acc[m][n] + bv;
-        if (resb != nullptr) {
-            f32x4 rv[M16];
-#pragma unroll
-            for (int m = 0; m < M16; ++m) rv[m] = ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
-#pragma unroll
-            for (int m = 0; m < M16; ++m) v[m] += rv[m];
-        }
-        if (relu) {
-#pragma unroll
-            for (int m = 0; m < M16; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.f);
-        }
-        if (maskb != nullptr) {
-            f32x4 mv[M16];
-#pragma unroll
-            for (int m = 0; m < M16; ++m) mv[m] = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
-#pragma unroll
-            for (int m = 0; m < M16; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[m][r] = mv[m][r] > 0.f ? v[m][r] : 0.f;
-        }
-        if (y_f32) {
-            float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
-#pragma unroll
-            for (int m = 0; m < M16; ++m)
-                if (cvalid && pval[m] && m >= m_lo && m < m_hi) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
-        } else {
-            u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
-#pragma unroll
-            for (int m = 0; m < M16; ++m)
-                if (cvalid && pval[m] && m >= m_lo && m < m_hi) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
-        }
-    }
 #undef TILE_COL
 #ifdef UNET_STAMPS
     if (g_stamps != nullptr && tid == 0) {
@@ -612,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         unsigned long long* o = g_stamps + (size_t)blockIdx.x * 24;
 #pragma unroll
         for (int i = 0; i < 10; ++i) o[8 + i] = stwt_[i];
-        o[0] = st0_; o[1] = st1_; o[2] = st2_; o[3] = STAMP(); o[4] = stw_; o[5] = stb_; o[6] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
-        o[7] = 1;
+        o[0] = st0_; o[1] = st1_; o[2] = stl_; o[3] = STAMP(); o[4] = stw_; o[5] = stb_; o[6] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        o[7] = 1; o[18] = ste_; o[19] = (unsigned long long)(tend - wg * tpw);
     }
 #endif
 }
@@ -624,13 +659,21 @@ extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
 }
 #endif
 
+int g_t256_tpw = 0;        // tiles per workgroup of conv_bf16_t256_kernel (0: chosen per launch; unet_set_bf16_big_tile(100 + n) forces n)
+
 template <int NTOT>
 int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
     auto kern = conv_bf16_t256_kernel<NTOT>;
     static unsigned long long configured = 0;
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kern, p.grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32);
+    // consecutive tiles per workgroup: as many as leave >= 4 workgroups for each of the 512 slots of the chip (2 per CU)
+    const int ntiles = p.k.mtiles * p.k.ntn;
+    int tpw = g_t256_tpw > 0 ? g_t256_tpw : ntiles / 2048;
+    tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+    dim3 grid = p.grid;
+    grid.x = (unsigned)unet::roundup(unet::cdiv(ntiles, tpw), 8);
+    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32, tpw);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
@@ -778,6 +821,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
 }  // namespace unetconv
 
 extern "C" int unet_set_bf16_big_tile(int on) {
+    g_t256_tpw = on >= 100 ? on - 100 : 0;
     g_big_tile = on ? 1 : 0;
     return UNET_OK;
 }
