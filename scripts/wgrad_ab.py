@@ -1,0 +1,49 @@
+"""bf16 3x3 weight gradients at 16 x 512^2 / 256^2 / 128^2: wgrad_bf16_k4_kernel (on) against wgrad_bf16_kernel<32,1,3> (off), interleaved on one box"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from unet_amd import ops
+from unet_amd.ops import TS
+import unet_amd._lib as L
+
+dt = torch.bfloat16
+N = 16
+g = torch.Generator(device="cuda").manual_seed(0)
+shapes = [(512, 100, 100), (512, 96, 96), (512, 100, 96), (256, 192, 96), (256, 96, 128), (128, 256, 256), (64, 384, 384)]
+data = {}
+for H, Cin, Cout in shapes:
+    x = TS(torch.randn((N, H, H, ops.rupv(Cin, dt)), device="cuda", generator=g).to(dt), 0, Cin)
+    dy = TS(torch.randn((N, H, H, ops.rupv(Cout, dt)), device="cuda", generator=g).to(dt), 0, Cout)
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    ws = torch.empty(ops.wgrad_workspace(x, dy, 3, 1), device="cuda")
+    data[(H, Cin, Cout)] = (x, dy, dw, ws)
+
+
+def run(k, n=10):
+    x, dy, dw, ws = data[k]
+    for _ in range(2):
+        ops.conv2d_wgrad(x, dy, dw, 3, 1, ws)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        ops.conv2d_wgrad(x, dy, dw, 3, 1, ws)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+res = {}
+ref = {}
+for r in range(3):
+    for k in shapes:
+        for v in (-2, -1):
+            L.lib.unet_set_wgrad_mfma_shape(v)
+            res.setdefault((k, v), []).append(run(k))
+            if r == 0:
+                ref[(k, v)] = data[k][2].clone()
+for k in shapes:
+    H, Cin, Cout = k
+    fl = 2.0 * N * H * H * Cin * Cout * 9
+    d = (ref[(k, -2)] - ref[(k, -1)]).abs().max().item() / ref[(k, -1)].abs().max().item()
+    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. reduce)  rel diff {d:.1e}", flush=True)
+L.lib.unet_set_wgrad_mfma_shape(-2)

@@ -225,6 +225,17 @@ def test_conv_bf16_t256_kernel(case):
         assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
     ops.conv2d_dgrad(dyt, wpd, dxt, 3, 1, res=_ts(rr), mask=_ts(m, cs=ci + 16, co=16))
     assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-5
+    # weight + bias gradient (wgrad_bf16_k4_kernel: 3x3 / stride 1 / 32-wide pixel tiles; blocks of 3 or 4 output-channel tiles, image
+    # edges through the buffer range check and the two column flags, operands in slices with non-zero neighbours), fp32 result
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    db = torch.empty(Cout, device="cuda")
+    n = ops.wgrad_workspace(xt, dyt, 3, 1, with_bias=True)
+    ops.conv2d_wgrad(xt, dyt, dw, 3, 1, torch.empty(n, device="cuda"), dbias=db)
+    torch.cuda.synchronize()
+    assert (dw.cpu().double() - dw_ref).abs().max().item() <= 5e-5 * dw_ref.abs().max().item(), "wgrad"
+    dbr = dy.double().sum((0, 2, 3))
+    assert (db.cpu().double() - dbr).abs().max().item() <= 5e-5 * dbr.abs().max().item() + 1e-5
 
 
 def test_conv_epilogue_slices_residual_relu_mask_bf16():

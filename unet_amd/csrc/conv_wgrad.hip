@@ -793,6 +793,174 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same bf16 weight gradient for the shape that carries the step (3x3, stride 1, 32-pixel-wide tiles), with the two things the
+// ISA of wgrad_bf16_kernel<32,1,3> showed to bind it taken out (per 128-pixel tile and wave: 144 MFMAs next to 179 LDS and ~730
+// scalar / vector / branch instructions -- ~4200 issue clocks against 2304 MFMA clocks, two waves per SIMD):
+//   * wave decomposition KV x 1 instead of 2 x 2 tiles: a wave owns ONE 16-wide input-channel tile and all (up to four) 16-wide
+//     output-channel tiles of the block.  The dy fragments of a k-block serve all nine taps (8 transposed reads per 36 MFMAs), each x fragment four
+//     MFMAs: 26 LDS reads per 36 MFMAs instead of 40 -- the 2 x 2 form needs 139 B/clk/CU of LDS bandwidth at full MFMA rate, more
+//     than the array delivers;
+//   * no address arithmetic in the loops: every LDS operand address is one lane register + an immediate; the global loads are
+//     buffer loads whose per-lane offsets are computed ONCE (tile-invariant part, the two column-edge flags in the free low bits),
+//     a tile adds its origin (4 VALU per 16-byte item; rows outside the image leave the descriptor's range and read as zero);
+//   * the output-channel block is KV x 16 channels wide, KV = 1..4 chosen per launch so that Cout is padded least (96 = 2 x 48,
+//     128 = 2 x 64, 100 -> 2 x 64): one branch-free body per instantiation (two bodies in one kernel made the allocator spill).
+// Same split-K over pixel tiles and the same partial layout as wgrad_bf16_kernel: a drop-in for <32, 1, 3>.
+template <int KV>       // 16-wide output-channel tiles per block (a.kt blocks of 16 KV channels: the launcher picks the KV that pads Cout least)
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
+    constexpr int PTW = 32, PTH = 4, PT = 128, KB = 4, T = 9, HH = PTH + 2, HW = PTW + 2, HPIX = HH * HW;
+    constexpr int RS = 160;                                      // LDS row stride in bytes (64 channels = 128 bytes + pad), both images
+    constexpr int DIT = PT * 8 / 256, XIT = (HPIX * 8 + 255) / 256;    // 16-byte items per thread: 4 of dy, 7 of x
+    constexpr unsigned OOB = 0x80000000u;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smemb[];
+    char* dyT = smemb;                      // [PT][RS]
+    char* xh = smemb + PT * RS;             // [HPIX][RS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = l15 & 3;
+    int bx = blockIdx.x, split = blockIdx.y;
+    if (a.xcd_map) {                        // the channel blocks of one pixel split on one XCD (see wgrad_bf16_kernel)
+        const int cols = gridDim.x, lin = blockIdx.x + cols * blockIdx.y;
+        const int qq = lin >> 3;
+        bx = qq % cols;
+        split = (lin & 7) + 8 * (qq / cols);
+    }
+    const int kblk = bx / a.ct, cblk = bx % a.ct;
+    const int k0 = kblk * (16 * KV), c0 = cblk * BC;
+    const int tile_begin = split * a.tiles_per_block;
+    int tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    if (tile_begin >= a.total_tiles) return;          // padding of the split count to a multiple of 8 (uniform per workgroup)
+    const bool cvw = c0 + 16 * wave < a.Cin;                                         // this wave's input-channel tile holds real channels
+
+    f32x4 acc[KV][T];
+#pragma unroll
+    for (int i = 0; i < KV; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tile-invariant byte offsets of this thread's items relative to the tile origin; bit 0: the item lies in the tile's first halo
+    // column (outside the image for the first tile of a row), bit 1: at or beyond the image's last column in the LAST tile of a row
+    // (kept in LDS behind the two images, [item][thread]: 11 registers that the accumulators need)
+    unsigned* rel = reinterpret_cast<unsigned*>(smemb + PT * RS + HPIX * RS) + tid;
+#define RELD(j_) rel[(j_) * 256]
+#define RELX(j_) rel[(DIT + (j_)) * 256]
+    const int last_ox0 = (a.tiles_x - 1) * PTW;
+#pragma unroll
+    for (int j = 0; j < DIT; ++j) {
+        const int e = tid + j * 256;
+        const int p = e >> 3, qq = e & 7;
+        const bool chan = 8 * qq < 16 * KV && (k0 + 8 * qq) < a.Cout4;
+        const unsigned off = (unsigned)(((p / PTW) * a.OW + p % PTW) * a.dy_cs + a.dy_co + k0 + 8 * qq) * 2u;
+        RELD(j) = chan ? (off | (last_ox0 + p % PTW >= a.OW ? 2u : 0u)) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < XIT; ++j) {
+        const int e = tid + j * 256;
+        const int p = e >> 3, qq = e & 7;
+        const int hx = p % HW;
+        const bool chan = (e < HPIX * 8) && (c0 + 8 * qq) < a.Cin4;
+        const unsigned off = (unsigned)(((p / HW) * a.IW + hx) * a.x_cs + a.x_co + c0 + 8 * qq) * 2u;
+        RELX(j) = chan ? (off | (hx == 0 ? 1u : 0u) | (last_ox0 - 1 + hx >= a.IW ? 2u : 0u)) : OOB;
+    }
+    uint4 rd[DIT], rx[XIT];
+    const unsigned dy_img_b = (unsigned)(a.OH * a.OW * a.dy_cs) * 2u, x_img_b = (unsigned)(a.IH * a.IW * a.x_cs) * 2u;
+    auto load_tile = [&](int tile) {
+        int b = tile;
+        const int tx = __builtin_amdgcn_readfirstlane(b % a.tiles_x); b /= a.tiles_x;
+        const int ty = __builtin_amdgcn_readfirstlane(b % a.tiles_y);
+        const int img = __builtin_amdgcn_readfirstlane(b / a.tiles_y);
+        const int oy0 = ty * PTH, ox0 = tx * PTW;
+        const unsigned edge = (tx == 0 ? 1u : 0u) | (tx == a.tiles_x - 1 ? 2u : 0u);
+        u16* dyb = const_cast<u16*>(reinterpret_cast<const u16*>(a.dy)) + (size_t)img * a.OH * a.OW * a.dy_cs;
+        u16* xb = const_cast<u16*>(reinterpret_cast<const u16*>(a.x)) + (size_t)img * a.IH * a.IW * a.x_cs;
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(dyb, 0, (int)dy_img_b, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)x_img_b, 0x00020000);
+        const unsigned based = (unsigned)((oy0 * a.OW + ox0) * a.dy_cs) * 2u;
+        const unsigned basex = (unsigned)(((oy0 - 1) * a.IW + ox0 - 1) * a.x_cs) * 2u;      // (first tile row / column: wraps far out of range)
+#pragma unroll
+        for (int j = 0; j < DIT; ++j) {
+            const unsigned rl = RELD(j);
+            const unsigned vo = (rl & (edge & 2u)) ? OOB : ((rl & ~15u) + based) | (rl & OOB);
+            rd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)vo, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < XIT; ++j) {
+            const unsigned rl = RELX(j);
+            const unsigned vo = (rl & edge) ? OOB : ((rl & ~15u) + basex) | (rl & OOB);
+            rx[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, 0, 0));
+        }
+    };
+    char* std_ = dyT + (tid >> 3) * RS + (tid & 7) * 16;
+    char* stx_ = xh + (tid >> 3) * RS + (tid & 7) * 16;
+    const bool x6 = tid + 6 * 256 < HPIX * 8;
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < DIT; ++j) *reinterpret_cast<uint4*>(std_ + j * 32 * RS) = rd[j];
+#pragma unroll
+        for (int j = 0; j < XIT; ++j)
+            if (j < 6 || x6) *reinterpret_cast<uint4*>(stx_ + j * 32 * RS) = rx[j];
+    };
+
+    // per-lane transposed-read addresses inside k-block 0: this lane supplies pixel row P1 = 4g + q (first read) / P2 = 16 + 4g + q
+    // (second), columns 4pp..4pp+3 of its tile; k-block kb = tile row kb: + kb * 32 rows of dy, + kb * HW rows of x (immediates)
+    const int P1 = 4 * g + q, P2 = 16 + 4 * g + q;
+    const char* a1 = dyT + P1 * RS + (4 * pp) * 2;
+    const char* a2 = dyT + P2 * RS + (4 * pp) * 2;
+    const char* x1 = xh + P1 * RS + (wave * 16 + 4 * pp) * 2;
+    const char* x2 = xh + P2 * RS + (wave * 16 + 4 * pp) * 2;
+
+    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < 16 * KV;
+    float bsum = 0.f;
+    load_tile(tile_begin);
+    store_tile();
+    __syncthreads();
+#define K4_BODY(KV_) do { \
+        _Pragma("nounroll") for (int kb = 0; kb < KB; ++kb) { \
+            bf16x8 av_[KV_]; \
+            _Pragma("unroll") for (int i = 0; i < KV_; ++i) av_[i] = ld_tr_pair(a1 + kb * 32 * RS + 32 * i, a2 + kb * 32 * RS + 32 * i); \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r) \
+                _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) { \
+                    const bf16x8 bv_ = ld_tr_pair(x1 + (kb * HW + r * HW + s_) * RS, x2 + (kb * HW + r * HW + s_) * RS); \
+                    _Pragma("unroll") for (int i = 0; i < KV_; ++i) \
+                        acc[i][r * 3 + s_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av_[i], bv_, acc[i][r * 3 + s_], 0, 0, 0); \
+                } \
+        } } while (0)
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) load_tile(tile + 1);
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) bsum += __uint_as_float((unsigned)*reinterpret_cast<const u16*>(dyT + p * RS + tid * 2) << 16);
+        }
+        if (cvw) {
+            K4_BODY(KV);
+        }
+        __syncthreads();                  // every wave is done reading this tile
+        if (has_next) store_tile();
+        __syncthreads();
+    }
+#undef K4_BODY
+#undef RELD
+#undef RELX
+
+    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    const size_t KC_ = (size_t)a.Cout * a.Cin;
+    float* pb = a.part + (size_t)split * T * KC_;
+    const int c = c0 + wave * 16 + l15;
+#pragma unroll
+    for (int i = 0; i < KV; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 16 * i + 4 * g + r;
+                if (k < a.Cout && c < a.Cin) pb[(size_t)t * KC_ + (size_t)k * a.Cin + c] = acc[i][t][r];
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 weight gradient = a plain GEMM dW[k][c] = sum_p dy[p][k] x[p][c] over FLAT pixels (PixelShuffle_ICNR convs,
 // identity-path convs, head, self-attention products).  The 64x64-tiled kernel stages 512 B per pixel for 8 kFLOP
 // (L2->LDS bound, ~46 TFLOP/s); here a workgroup owns 128 x 128 channels (each wave 64 x 64 = 2x2 MFMA tiles, 64
@@ -1146,8 +1314,43 @@ int launch_w(const WPlan& p, hipStream_t st) {
     return UNET_OK;
 }
 
+static int g_wgrad_k4 = 1;           // 3x3 / stride 1 / 32-wide tiles on wgrad_bf16_k4_kernel (unet_set_wgrad_mfma_shape(-1) turns it off, -2 on)
+
+template <int KV>
+int launch_wb_k4n(const WPlan& p, hipStream_t st) {
+    auto kern = wgrad_bf16_k4_kernel<KV>;
+    static unsigned long long configured = 0;   // one bit per device
+    if (unet::first_use_on_device(&configured))
+        UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    WArgs k = p.k;
+    k.kt = unet::cdiv(p.k.Cout, 16 * KV);
+    k.xcd_map = p.splits >= 8 ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(k.kt * p.k.ct, k.xcd_map ? unet::roundup(p.splits, 8) : p.splits), dim3(256), p.lds_bytes + 11 * 256 * sizeof(unsigned),
+                       st, k);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+int launch_wb_k4(const WPlan& p, hipStream_t st) {
+    // tiles per block: 3 or 4, whichever pads the 16-wide tiles of Cout less (4 on a tie: fewer reads of x per MFMA; narrower blocks
+    // only when Cout itself is that narrow -- at KV = 1 every x fragment would serve a single MFMA)
+    const int tiles = unet::cdiv(p.k.Cout, 16);
+    const int kv = tiles <= 2 ? tiles : (unet::roundup(tiles, 3) < unet::roundup(tiles, 4) ? 3 : 4);
+    switch (kv) {
+        case 1: return launch_wb_k4n<1>(p, st);
+        case 2: return launch_wb_k4n<2>(p, st);
+        case 3: return launch_wb_k4n<3>(p, st);
+        default: return launch_wb_k4n<4>(p, st);
+    }
+}
+
 template <int PTW, int S, int KS>
 int launch_wb(const WPlan& p, hipStream_t st) {
+    if constexpr (PTW == 32 && S == 1 && KS == 3) {
+        // (its in-image byte offsets are 32-bit with bit 31 = out of range: one image of either tensor within 2 GiB)
+        if (g_wgrad_k4 && (long long)p.k.IH * p.k.IW * p.k.x_cs * 2 < (1ll << 31) - 65536 && (long long)p.k.OH * p.k.OW * p.k.dy_cs * 2 < (1ll << 31) - 65536)
+            return launch_wb_k4(p, st);
+    }
     auto kern = wgrad_bf16_kernel<PTW, S, KS>;
     static unsigned long long configured = 0;   // one bit per device
     if (unet::first_use_on_device(&configured)) {
@@ -1177,6 +1380,7 @@ int launch_w_ptw(const WPlan& p, int ks, int stride, hipStream_t st) {
 }  // namespace
 
 extern "C" int unet_set_wgrad_mfma_shape(int shape) {
+    if (shape < 0) { g_wgrad_k4 = shape == -2 ? 1 : 0; return UNET_OK; }        // bf16: wgrad_bf16_k4_kernel off (-1) / on (-2)
     UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
     g_wgrad_mfma_shape = shape;
     return UNET_OK;
