@@ -238,6 +238,36 @@ def test_conv_bf16_t256_kernel(case):
     assert (db.cpu().double() - dbr).abs().max().item() <= 5e-5 * dbr.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("K,Cout", [(5, 100), (8, 24)])
+def test_conv1x1_small_reduction_kernel_bf16(K, Cout):
+    """conv1x1_smallk_kernel with bf16 storage (variant id 9): gradient form with residual + mask, forward form with bias + ReLU"""
+    from unet_amd import ops
+    N, H, W = 2, 37, 29
+    g = torch.Generator().manual_seed(K * 100 + Cout)
+    wf = torch.randn(K, Cout, 1, 1, generator=g)
+    wb = _bf(wf)
+    dy = _bf(torch.randn(N, K, H, W, generator=g))
+    r = _bf(torch.randn(N, Cout, H, W, generator=g))
+    act = _bf(F.relu(torch.randn(N, Cout, H, W, generator=g)))
+    ref = (torch.nn.grad.conv2d_input((N, Cout, H, W), wb.double(), dy.double()) + r.double()) * (act > 0)
+    co = ops.rupv(Cout, torch.bfloat16)
+    dxt = _empty(N, H, W, Cout, cs=co + 24, co=16)
+    dyt = _ts(dy, cs=24, co=8)
+    wpd = ops.pack_weights(wf.cuda(), 1, dtype=torch.bfloat16)
+    assert ops.conv2d_variant(dyt, wpd, dxt, 1, 1, kind=1) == 9
+    ops.conv2d_dgrad(dyt, wpd, dxt, 1, 1, res=_ts(r), mask=_ts(act, cs=co + 8, co=8))
+    assert (_back(dxt).double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6
+    full = dxt.buf.float().cpu()
+    assert bool((full[..., :16] == 7.25).all()) and bool((full[..., 16 + co:] == 7.25).all()), "wrote outside the slice"
+    w = torch.randn(Cout, K, 1, 1, generator=g)
+    b = torch.randn(Cout, generator=g)
+    x = _bf(torch.randn(N, K, H, W, generator=g))
+    yt = _empty(N, H, W, Cout)
+    ops.conv2d(_ts(x), ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16), yt, 1, 1, bias=b.cuda(), relu=True)
+    ref2 = F.relu(F.conv2d(x.double(), _bf(w).double(), b.double()))
+    assert (_back(yt).double() - ref2).abs().max().item() <= 2.0 ** -8 * ref2.abs().max().item() + 1e-6
+
+
 def test_conv_epilogue_slices_residual_relu_mask_bf16():
     """channel-sliced operands (concat elimination), bias + residual + ReLU forward epilogue, residual + ReLU-mask dgrad epilogue"""
     from unet_amd import ops

@@ -243,6 +243,35 @@ def test_conv_dgrad_mask_res(ops):
     torch.cuda.synchronize()
     assert_close(from_ts(dxt), ref, rtol=2e-4, what="dgrad+res+mask")
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,Cout", [(5, 100), (2, 99), (8, 16), (7, 130)])
+def test_conv1x1_small_reduction_kernel(ops, K, Cout):
+    """conv1x1_smallk_kernel (the segmentation head's input gradient, 5 -> 100): variant id 9; forward form with bias + residual + ReLU
+    into a channel slice, gradient form with residual + mask; against torch on the CPU"""
+    N, H, W = 2, 37, 29
+    g = torch.Generator().manual_seed(K * 100 + Cout)
+    x = torch.randn(N, K, H, W, generator=g)
+    w = torch.randn(Cout, K, 1, 1, generator=g)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xt, rt = to_ts(x, cs=ops.rup4(K) + 8, co=4), to_ts(r, cs=ops.rup4(Cout) + 4, co=4)
+    yt = empty_ts(N, H, W, Cout, cs=ops.rup4(Cout) + 12, co=8)
+    wp = ops.pack_weights(w.cuda(), 0)
+    assert ops.conv2d_variant(xt, wp, yt, 1, 1) == 9
+    ops.conv2d(xt, wp, yt, 1, 1, bias=b.cuda(), res=rt, relu=True)
+    torch.cuda.synchronize()
+    assert_close(from_ts(yt), F.relu(F.conv2d(x, w, b) + r), rtol=1e-5, what="small-K fwd")
+    assert outside_untouched(yt)
+    # as an input gradient: reduction over the K "output" channels of a forward conv Cout -> K
+    wf = torch.randn(K, Cout, 1, 1, generator=g)
+    dy = torch.randn(N, K, H, W, generator=g)
+    act = F.relu(torch.randn(N, Cout, H, W, generator=g))
+    ref = (torch.nn.grad.conv2d_input((N, Cout, H, W), wf, dy) + r) * (act > 0)
+    dxt = empty_ts(N, H, W, Cout)
+    ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(wf.cuda(), 1), dxt, 1, 1, res=to_ts(r), mask=to_ts(act))
+    torch.cuda.synchronize()
+    assert_close(from_ts(dxt), ref, rtol=1e-5, what="small-K dgrad")
+
 
 WGRAD_CASES = [
     (2, 16, 16, 32, 32, 3, 1),

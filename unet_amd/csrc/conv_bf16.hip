@@ -804,6 +804,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     Plan p;
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
+    if (conv_smallk_applies(d)) return conv_smallk_bf16(d, st);
     const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
     if (p.hit == 6) rc = launch_t256(p, y_f32, st);
     else rc = (p.hit == 10) ? launch_tw<10>(p, y_f32, st) : launch_tw<4>(p, y_f32, st);
@@ -815,6 +816,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
     Plan p;
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
+    if (conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
     return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? 7 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
 

@@ -451,5 +451,8 @@ int splitk_reduce(const unet_conv_desc* d, const Plan& p, hipStream_t st);
 int conv2d_bf16(const unet_conv_desc* d, hipStream_t st);
 int conv2d_bf16_variant(const unet_conv_desc* d);
 int plan_bf16_public(const unet_conv_desc* d, Plan* p);
+// 1x1 convolutions with a reduction of at most 8 channels (conv_igemm.hip: conv1x1_smallk_kernel), both storage types
+bool conv_smallk_applies(const unet_conv_desc* d);
+int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
 
 }  // namespace unetconv

@@ -791,6 +791,7 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     Plan p;
     int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
+    if (unetconv::conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
     return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
 
@@ -855,6 +856,138 @@ int unetconv::splitk_reduce(const unet_conv_desc* d, const Plan& p, hipStream_t 
     return UNET_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution with a reduction of at most 8 channels and a wide output: the input gradient of the segmentation head (5 -> 100
+// at 16 x 512 x 512).  On the MFMA kernels this launch is one 16- / 32-channel chunk of zeros around 5 real channels in front of an
+// epilogue that writes 0.87 GB in 8-byte pieces (0.75 ms bf16, 1.1 ms fp32: 1.2 TB/s); it is an HBM-bound elementwise product.  Here a
+// thread owns one pixel x one 16-byte group of output channels: the pixel's (up to 8) inputs in registers, the filter in LDS, FMAs in
+// ascending channel order, residual / mask / result as 16-byte vectors, consecutive threads on consecutive groups of the same pixel.
+namespace {
+template <typename T> struct SmallK;
+template <> struct SmallK<float> {
+    static constexpr int VEC = 4;
+    __device__ static float w(const float* wp, int o, int r) { return wp[o * 16 + (r >> 2) + 4 * (r & 3)]; }       // one (tail) chunk, channel-transposed
+    __device__ static void ld(const float* p, float (&v)[VEC]) { const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+    __device__ static void st(float* p, const float (&v)[VEC]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct SmallK<unsigned short> {
+    static constexpr int VEC = 8;
+    __device__ static float w(const unsigned short* wp, int o, int r) { return __uint_as_float((unsigned)wp[o * 32 + r] << 16); }
+    __device__ static void ld(const unsigned short* p, float (&v)[VEC]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const unsigned q[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(q[i] << 16); v[2 * i + 1] = __uint_as_float(q[i] & 0xffff0000u); }
+    }
+    __device__ static void st(unsigned short* p, const float (&v)[VEC]) {
+        typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+        const bf16x8_ h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+        *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, h);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_smallk_kernel(const T* __restrict__ x, int x_cs, int x_co, const T* __restrict__ wp, int K,
+                                                             const float* __restrict__ bias, const T* __restrict__ res, int res_cs, int res_co,
+                                                             const T* __restrict__ mask, int mask_cs, int mask_co, T* __restrict__ y, int y_cs,
+                                                             int y_co, long long P, int cols, int groups, int relu) {
+    constexpr int VEC = SmallK<T>::VEC, XV = 8 / VEC;
+    __shared__ float wl[8 * 512];                       // [k][column], columns padded to the vector width
+    const int colsv = groups * VEC;
+    for (int i = threadIdx.x; i < 8 * colsv; i += 256) {
+        const int k = i / colsv, c = i - k * colsv;
+        wl[i] = (k < K && c < cols) ? SmallK<T>::w(wp, c, k) : 0.f;
+    }
+    __syncthreads();
+    const int ppb = 256 / groups;                       // pixels per workgroup pass
+    const int pl = (int)threadIdx.x / groups, gi = (int)threadIdx.x - pl * groups;
+    if (pl >= ppb) return;
+    const int c = gi * VEC;
+    float bv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bv[j] = (bias != nullptr && c + j < cols) ? bias[c + j] : 0.f;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < P; p += (long long)gridDim.x * ppb) {
+        float xv[8];
+#pragma unroll
+        for (int h = 0; h < XV; ++h) {
+            float t[VEC];
+            if (h * VEC < K) SmallK<T>::ld(x + (size_t)p * x_cs + x_co + h * VEC, t);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) t[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) xv[h * VEC + j] = t[j];
+        }
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = fmaf(xv[k], wl[k * colsv + c + j], o[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += bv[j];
+        if (res != nullptr) {
+            float t[VEC];
+            SmallK<T>::ld(res + (size_t)p * res_cs + res_co + c, t);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] += t[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = fmaxf(o[j], 0.f);
+        }
+        if (mask != nullptr) {
+            float t[VEC];
+            SmallK<T>::ld(mask + (size_t)p * mask_cs + mask_co + c, t);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = t[j] > 0.f ? o[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = c + j < cols ? o[j] : 0.f;
+        T* yo = y + (size_t)p * y_cs + y_co + c;
+        if (VEC == 8 || c + VEC <= cols) SmallK<T>::st(yo, o);      // (bf16 slices own their 8-channel padding: zeros; fp32 padding lanes are left alone)
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (c + j < cols) unetconv::st_act(yo + j, o[j]);
+        }
+    }
+}
+
+// the launches this kernel takes (both storage types; everything else about the descriptor was validated by the planner)
+bool smallk_applies(const unet_conv_desc* d) {
+    const int vec = d->dtype == UNET_BF16 ? 8 : 4;
+    return d->ks == 1 && d->stride == 1 && d->Cin <= 8 && d->Cout >= 16 && unet::roundup(d->Cout, vec) <= 512 && d->colsum == nullptr &&
+           d->colsumsq == nullptr && d->cout_begin == 0 && (d->cout_count == 0 || d->cout_count == d->Cout) && d->wp_img_stride == 0 &&
+           !(d->dtype == UNET_BF16 && d->y_f32) && unet::roundup(d->Cout, vec) <= d->y_cs - d->y_co &&
+           (d->res == nullptr || unet::roundup(d->Cout, vec) <= d->res_cs - d->res_co) &&
+           (!(d->flags & UNET_CONV_MASK) || unet::roundup(d->Cout, vec) <= d->mask_cs - d->mask_co);
+}
+
+template <typename T>
+int launch_smallk(const unet_conv_desc* d, hipStream_t st) {
+    const long long P = (long long)d->N * d->OH * d->OW;
+    const int groups = unet::cdiv(d->Cout, SmallK<T>::VEC), ppb = 256 / groups;
+    long long blocks = (P + ppb - 1) / ppb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((conv1x1_smallk_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)d->x, d->x_cs, d->x_co, (const T*)d->wp, d->Cin,
+                       d->bias, (const T*)d->res, d->res_cs, d->res_co, (d->flags & UNET_CONV_MASK) ? (const T*)d->mask : (const T*)nullptr, d->mask_cs,
+                       d->mask_co, (T*)d->y, d->y_cs, d->y_co, P, d->Cout, groups, (d->flags & UNET_CONV_RELU) ? 1 : 0);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+}  // namespace
+
+namespace unetconv {
+bool conv_smallk_applies(const unet_conv_desc* d) { return smallk_applies(d); }
+int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st) { return launch_smallk<unsigned short>(d, st); }
+}
+
 // plan with split-K when the caller brought a workspace for it, else the plain plan
 static int make_plan_ws(const unet_conv_desc* d, Plan* p) {
     int rc = make_plan(d, p);
@@ -875,6 +1008,7 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (smallk_applies(d)) return launch_smallk<float>(d, st);
     rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
     if (rc != UNET_OK || p.splits <= 1) return rc;
     return unetconv::splitk_reduce(d, p, st);
