@@ -455,15 +455,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const unsigned hsw = (unsigned)(r * 2 * T256_HW * T256_ROWB);           // (pixel tiles 4..7 lie two tile rows below tiles 0..3)
 #define MOFF(m_) ((((m_) >> 1) * T256_HW + ((m_) & 1) * 16) * T256_ROWB)
 #define TOFF(t_) ((((t_) / 3) * T256_HW + (t_) % 3) * T256_ROWB)
-    // folded tail: lane group kq reads channel group 0 of the tail chunk at ITS tap 4 j + kq (tap index in filter order)
-    unsigned vfold[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    // folded tail: lane group kq reads channel group 0 of the tail chunk at ITS tap 4 j + kq (tap index in filter order); computed where
+    // it is used (three registers that the main loop does not have to carry)
+    auto vfold = [&](int j) -> unsigned {
         int tl = 4 * j + kq;
         tl = tl < 9 ? tl : 0;                   // (beyond the taps the fold slab holds zeros)
         const int pos = rev ? 8 - tl : tl;
-        vfold[j] = (unsigned)(((pos / 3) * T256_HW + pos % 3) * T256_ROWB) - 16u * (unsigned)kq;
-    }
+        return (unsigned)(((pos / 3) * T256_HW + pos % 3) * T256_ROWB) - 16u * (unsigned)kq;
+    };
 
     // One stage: 2 halves x (4 pixel tiles from LDS, up to 4 x 4 MFMAs).  (Reading the pixel tiles half a stage ahead into a second
     // register set -- 234 instead of 216 VGPRs -- was built and measured against this form on one box: equal within 1 %; the partner wave
@@ -535,14 +534,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
             stt_ = 9;
 #endif
             gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wfold + slab_b);
-            T256_MFMA(b0, vcur + vfold[0]);
+            T256_MFMA(b0, vcur + vfold(0));
             __builtin_amdgcn_sched_barrier(0);
             STAMP_WAIT((wait_cnt<0, false>(b1, hreg)));
             gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wfold + 2 * slab_b);
-            T256_MFMA(b1, vcur + vfold[1]);
+            T256_MFMA(b1, vcur + vfold(1));
             __builtin_amdgcn_sched_barrier(0);
             STAMP_WAIT((wait_cnt<0, false>(b0, hreg)));
-            T256_MFMA(b0, vcur + vfold[2]);
+            T256_MFMA(b0, vcur + vfold(2));
         }
 #ifdef UNET_STAMPS
         const unsigned long long se0_ = STAMP();
@@ -559,30 +558,88 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, first_fold ? wfold : w0 + (size_t)kc0 * slab_b);
 
         // ---- epilogue: lane (pixel l15 of every pixel tile) x (4 consecutive channels 4kq.. of every channel tile), half the pixel
-        //      tiles at a time (the next tile's 40 load registers are live here) ----
+        //      tiles at a time (the next tile's 40 load registers are live here).  bf16 results move as 16-byte vectors: the lanes of
+        //      16-lane rows kq and kq ^ 1 exchange halves of two pixel tiles (v_permlane16_swap_b32: odd rows of the first operand <->
+        //      even rows of the second), after which lane (l15, kq) holds channels 8 (kq >> 1) .. + 7 of pixel tile 2 j + (kq & 1); the
+        //      residual and the mask are fetched in that form and swapped back.  Half as many memory instructions, each 16 bytes a lane.
         const bool relu = a.flags & UNET_CONV_RELU;
         const size_t img_pix = (size_t)imgc * a.OH * a.OW;
         const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
         const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+        auto unpack = [](unsigned lo, unsigned hi) -> f32x4 {
+            return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+        };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            int pidx[MH];
-            bool pval[MH];
+            if (y_f32) {
+                int pidx[MH];
+                bool pval[MH];
 #pragma unroll
-            for (int m = 0; m < MH; ++m) {
-                const int pix = (wm * M16 + ((h * MH + m) ^ (r * MH))) * 16 + l15;
-                const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
-                pval[m] = oy < a.OH && ox < a.OW;
-                pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
+                for (int m = 0; m < MH; ++m) {
+                    const int pix = (wm * M16 + ((h * MH + m) ^ (r * MH))) * 16 + l15;
+                    const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
+                    pval[m] = oy < a.OH && ox < a.OW;
+                    pidx[m] = pval[m] ? (oy * a.OW + ox) : 0;
+                }
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
+                    const int c4 = n0c + TILE_COL(n) + 4 * kq;
+                    const bool cvalid = c4 < a.n_end;
+                    const int cc = cvalid ? c4 : 0;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias != nullptr && cvalid) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+                    }
+                    f32x4 v[MH];
+#pragma unroll
+                    for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bv;
+                    if (resb != nullptr) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m) v[m] += ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[m][q] = fmaxf(v[m][q], 0.f);
+                    }
+                    if (maskb != nullptr) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m) {
+                            const f32x4 mv = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[m][q] = mv[q] > 0.f ? v[m][q] : 0.f;
+                        }
+                    }
+                    float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+                        if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
+                }
+                continue;
             }
+            // the pixel this lane moves for pixel-tile pair j: tile 2 j + (kq & 1)
+            int pidx2[MH / 2];
+            bool pval2[MH / 2];
+#pragma unroll
+            for (int j = 0; j < MH / 2; ++j) {
+                const int pix = (wm * M16 + ((h * MH + 2 * j + (kq & 1)) ^ (r * MH))) * 16 + l15;
+                const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
+                pval2[j] = oy < a.OH && ox < a.OW;
+                pidx2[j] = pval2[j] ? (oy * a.OW + ox) : 0;
+            }
+            u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
                 const int c4 = n0c + TILE_COL(n) + 4 * kq;
-                const bool cvalid = c4 < a.n_end;
-                const int cc = cvalid ? c4 : 0;
+                const int c8 = n0c + TILE_COL(n) + 8 * (kq >> 1);          // the 8 channels this lane moves
+                const bool cvalid8 = c8 < a.n_end;
+                const int cc8 = cvalid8 ? c8 : 0;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr && cvalid) {
+                if (a.bias != nullptr) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
                 }
@@ -590,11 +647,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #pragma unroll
                 for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bv;
                 if (resb != nullptr) {
-                    f32x4 rv[MH];
+                    uint4 rr[MH / 2];
 #pragma unroll
-                    for (int m = 0; m < MH; ++m) rv[m] = ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(resb + (size_t)pidx2[j] * a.res_cs + cc8);
 #pragma unroll
-                    for (int m = 0; m < MH; ++m) v[m] += rv[m];
+                    for (int j = 0; j < MH / 2; ++j) {
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j].x, rr[j].z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(rr[j].y, rr[j].w, false, false);
+                        v[2 * j] += unpack(s0[0], s1[0]);
+                        v[2 * j + 1] += unpack(s0[1], s1[1]);
+                    }
                 }
                 if (relu) {
 #pragma unroll
@@ -603,24 +665,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                         for (int q = 0; q < 4; ++q) v[m][q] = fmaxf(v[m][q], 0.f);
                 }
                 if (maskb != nullptr) {
-                    f32x4 mv[MH];
+                    uint4 rr[MH / 2];
 #pragma unroll
-                    for (int m = 0; m < MH; ++m) mv[m] = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(maskb + (size_t)pidx2[j] * a.mask_cs + cc8);
 #pragma unroll
-                    for (int m = 0; m < MH; ++m)
+                    for (int j = 0; j < MH / 2; ++j) {
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j].x, rr[j].z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(rr[j].y, rr[j].w, false, false);
+                        const f32x4 m0 = unpack(s0[0], s1[0]), m1 = unpack(s0[1], s1[1]);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[m][q] = mv[m][q] > 0.f ? v[m][q] : 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * j][q] = m0[q] > 0.f ? v[2 * j][q] : 0.f;
+                            v[2 * j + 1][q] = m1[q] > 0.f ? v[2 * j + 1][q] : 0.f;
+                        }
+                    }
                 }
-                if (y_f32) {
-                    float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
 #pragma unroll
-                    for (int m = 0; m < MH; ++m)
-                        if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
-                } else {
-                    u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
-#pragma unroll
-                    for (int m = 0; m < MH; ++m)
-                        if (cvalid && pval[m]) st_bf16x4(yb + (size_t)pidx[m] * a.y_cs + c4, v[m]);
+                for (int j = 0; j < MH / 2; ++j) {
+                    const bf16x4 x_ = {(__bf16)v[2 * j][0], (__bf16)v[2 * j][1], (__bf16)v[2 * j][2], (__bf16)v[2 * j][3]};
+                    const bf16x4 y_ = {(__bf16)v[2 * j + 1][0], (__bf16)v[2 * j + 1][1], (__bf16)v[2 * j + 1][2], (__bf16)v[2 * j + 1][3]};
+                    const uint2 xu = __builtin_bit_cast(uint2, x_), yu = __builtin_bit_cast(uint2, y_);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(xu.x, yu.x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(xu.y, yu.y, false, false);
+                    if (cvalid8 && pval2[j]) *reinterpret_cast<uint4*>(yb + (size_t)pidx2[j] * a.y_cs + c8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 }
             }
         }
