@@ -9,25 +9,25 @@ import unet_amd._lib as L
 dt = torch.bfloat16
 N = 16
 g = torch.Generator(device="cuda").manual_seed(0)
-shapes = [(512, 100, 100), (512, 96, 96), (512, 100, 96), (256, 192, 96), (256, 96, 128), (128, 256, 256), (64, 384, 384)]
+shapes = [(512, 100, 100, 3), (512, 96, 96, 3), (256, 192, 96, 3), (128, 256, 256, 3), (64, 384, 384, 3), (256, 96, 384, 1), (128, 256, 512, 1), (64, 384, 768, 1), (512, 100, 5, 1)]
 data = {}
-for H, Cin, Cout in shapes:
+for H, Cin, Cout, ks in shapes:
     x = TS(torch.randn((N, H, H, ops.rupv(Cin, dt)), device="cuda", generator=g).to(dt), 0, Cin)
     dy = TS(torch.randn((N, H, H, ops.rupv(Cout, dt)), device="cuda", generator=g).to(dt), 0, Cout)
-    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
-    ws = torch.empty(ops.wgrad_workspace(x, dy, 3, 1), device="cuda")
-    data[(H, Cin, Cout)] = (x, dy, dw, ws)
+    dw = torch.empty(Cout, Cin, ks, ks, device="cuda")
+    ws = torch.empty(ops.wgrad_workspace(x, dy, ks, 1), device="cuda")
+    data[(H, Cin, Cout, ks)] = (x, dy, dw, ws)
 
 
 def run(k, n=10):
     x, dy, dw, ws = data[k]
     for _ in range(2):
-        ops.conv2d_wgrad(x, dy, dw, 3, 1, ws)
+        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
-        ops.conv2d_wgrad(x, dy, dw, 3, 1, ws)
+        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 
@@ -42,8 +42,8 @@ for r in range(3):
             if r == 0:
                 ref[(k, v)] = data[k][2].clone()
 for k in shapes:
-    H, Cin, Cout = k
-    fl = 2.0 * N * H * H * Cin * Cout * 9
+    H, Cin, Cout, ks = k
+    fl = 2.0 * N * H * H * Cin * Cout * ks * ks
     d = (ref[(k, -2)] - ref[(k, -1)]).abs().max().item() / ref[(k, -1)].abs().max().item()
-    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. reduce)  rel diff {d:.1e}", flush=True)
+    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. reduce)  rel diff {d:.1e}", flush=True)
 L.lib.unet_set_wgrad_mfma_shape(-2)

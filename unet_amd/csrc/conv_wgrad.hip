@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same bf16 weight gradient for the shape that carries the step (3x3, stride 1, 32-pixel-wide tiles), with the two things the
+// The same bf16 weight gradient for the shapes that carry the step (3x3 and 1x1, stride 1, 32-pixel-wide tiles), with the two things the
 // ISA of wgrad_bf16_kernel<32,1,3> showed to bind it taken out (per 128-pixel tile and wave: 144 MFMAs next to 179 LDS and ~730
 // scalar / vector / branch instructions -- ~4200 issue clocks against 2304 MFMA clocks, two waves per SIMD):
 //   * wave decomposition KV x 1 instead of 2 x 2 tiles: a wave owns ONE 16-wide input-channel tile and all (up to four) 16-wide
@@ -806,9 +806,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
 //   * the output-channel block is KV x 16 channels wide, KV = 1..4 chosen per launch so that Cout is padded least (96 = 2 x 48,
 //     128 = 2 x 64, 100 -> 2 x 64): one branch-free body per instantiation (two bodies in one kernel made the allocator spill).
 // Same split-K over pixel tiles and the same partial layout as wgrad_bf16_kernel: a drop-in for <32, 1, 3>.
-template <int KV>       // 16-wide output-channel tiles per block (a.kt blocks of 16 KV channels: the launcher picks the KV that pads Cout least)
+template <int KV, int KS>       // KV: 16-wide output-channel tiles per block (a.kt blocks of 16 KV channels: the launcher picks the KV that pads Cout least); KS: 3 | 1
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
-    constexpr int PTW = 32, PTH = 4, PT = 128, KB = 4, T = 9, HH = PTH + 2, HW = PTW + 2, HPIX = HH * HW;
+    constexpr int PTW = 32, PTH = 4, PT = 128, KB = 4, T = KS * KS, PAD = (KS - 1) / 2, HH = PTH + 2 * PAD, HW = PTW + 2 * PAD, HPIX = HH * HW;
     constexpr int RS = 160;                                      // LDS row stride in bytes (64 channels = 128 bytes + pad), both images
     constexpr int DIT = PT * 8 / 256, XIT = (HPIX * 8 + 255) / 256;    // 16-byte items per thread: 4 of dy, 7 of x
     constexpr unsigned OOB = 0x80000000u;
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
         const int hx = p % HW;
         const bool chan = (e < HPIX * 8) && (c0 + 8 * qq) < a.Cin4;
         const unsigned off = (unsigned)(((p / HW) * a.IW + hx) * a.x_cs + a.x_co + c0 + 8 * qq) * 2u;
-        RELX(j) = chan ? (off | (hx == 0 ? 1u : 0u) | (last_ox0 - 1 + hx >= a.IW ? 2u : 0u)) : OOB;
+        RELX(j) = chan ? (off | (hx < PAD ? 1u : 0u) | (last_ox0 - PAD + hx >= a.IW ? 2u : 0u)) : OOB;
     }
     uint4 rd[DIT], rx[XIT];
     const unsigned dy_img_b = (unsigned)(a.OH * a.OW * a.dy_cs) * 2u, x_img_b = (unsigned)(a.IH * a.IW * a.x_cs) * 2u;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
         const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(dyb, 0, (int)dy_img_b, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)x_img_b, 0x00020000);
         const unsigned based = (unsigned)((oy0 * a.OW + ox0) * a.dy_cs) * 2u;
-        const unsigned basex = (unsigned)(((oy0 - 1) * a.IW + ox0 - 1) * a.x_cs) * 2u;      // (first tile row / column: wraps far out of range)
+        const unsigned basex = (unsigned)(((oy0 - PAD) * a.IW + ox0 - PAD) * a.x_cs) * 2u;      // (first tile row / column: wraps far out of range)
 #pragma unroll
         for (int j = 0; j < DIT; ++j) {
             const unsigned rl = RELD(j);
@@ -894,13 +894,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
     };
     char* std_ = dyT + (tid >> 3) * RS + (tid & 7) * 16;
     char* stx_ = xh + (tid >> 3) * RS + (tid & 7) * 16;
-    const bool x6 = tid + 6 * 256 < HPIX * 8;
+    const bool xlast = tid + (XIT - 1) * 256 < HPIX * 8;
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < DIT; ++j) *reinterpret_cast<uint4*>(std_ + j * 32 * RS) = rd[j];
 #pragma unroll
         for (int j = 0; j < XIT; ++j)
-            if (j < 6 || x6) *reinterpret_cast<uint4*>(stx_ + j * 32 * RS) = rx[j];
+            if (j < XIT - 1 || xlast) *reinterpret_cast<uint4*>(stx_ + j * 32 * RS) = rx[j];
     };
 
     // per-lane transposed-read addresses inside k-block 0: this lane supplies pixel row P1 = 4g + q (first read) / P2 = 16 + 4g + q
@@ -920,11 +920,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_k4_kernel(const WArgs a) {
         _Pragma("nounroll") for (int kb = 0; kb < KB; ++kb) { \
             bf16x8 av_[KV_]; \
             _Pragma("unroll") for (int i = 0; i < KV_; ++i) av_[i] = ld_tr_pair(a1 + kb * 32 * RS + 32 * i, a2 + kb * 32 * RS + 32 * i); \
-            _Pragma("unroll") for (int r = 0; r < 3; ++r) \
-                _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) { \
+            _Pragma("unroll") for (int r = 0; r < KS; ++r) \
+                _Pragma("unroll") for (int s_ = 0; s_ < KS; ++s_) { \
                     const bf16x8 bv_ = ld_tr_pair(x1 + (kb * HW + r * HW + s_) * RS, x2 + (kb * HW + r * HW + s_) * RS); \
                     _Pragma("unroll") for (int i = 0; i < KV_; ++i) \
-                        acc[i][r * 3 + s_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av_[i], bv_, acc[i][r * 3 + s_], 0, 0, 0); \
+                        acc[i][r * KS + s_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av_[i], bv_, acc[i][r * KS + s_], 0, 0, 0); \
                 } \
         } } while (0)
     for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -1316,9 +1316,9 @@ int launch_w(const WPlan& p, hipStream_t st) {
 
 static int g_wgrad_k4 = 1;           // 3x3 / stride 1 / 32-wide tiles on wgrad_bf16_k4_kernel (unet_set_wgrad_mfma_shape(-1) turns it off, -2 on)
 
-template <int KV>
+template <int KV, int KS>
 int launch_wb_k4n(const WPlan& p, hipStream_t st) {
-    auto kern = wgrad_bf16_k4_kernel<KV>;
+    auto kern = wgrad_bf16_k4_kernel<KV, KS>;
     static unsigned long long configured = 0;   // one bit per device
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1331,25 +1331,26 @@ int launch_wb_k4n(const WPlan& p, hipStream_t st) {
     return UNET_OK;
 }
 
+template <int KS>
 int launch_wb_k4(const WPlan& p, hipStream_t st) {
     // tiles per block: 3 or 4, whichever pads the 16-wide tiles of Cout less (4 on a tie: fewer reads of x per MFMA; narrower blocks
     // only when Cout itself is that narrow -- at KV = 1 every x fragment would serve a single MFMA)
     const int tiles = unet::cdiv(p.k.Cout, 16);
     const int kv = tiles <= 2 ? tiles : (unet::roundup(tiles, 3) < unet::roundup(tiles, 4) ? 3 : 4);
     switch (kv) {
-        case 1: return launch_wb_k4n<1>(p, st);
-        case 2: return launch_wb_k4n<2>(p, st);
-        case 3: return launch_wb_k4n<3>(p, st);
-        default: return launch_wb_k4n<4>(p, st);
+        case 1: return launch_wb_k4n<1, KS>(p, st);
+        case 2: return launch_wb_k4n<2, KS>(p, st);
+        case 3: return launch_wb_k4n<3, KS>(p, st);
+        default: return launch_wb_k4n<4, KS>(p, st);
     }
 }
 
 template <int PTW, int S, int KS>
 int launch_wb(const WPlan& p, hipStream_t st) {
-    if constexpr (PTW == 32 && S == 1 && KS == 3) {
+    if constexpr (PTW == 32 && S == 1) {
         // (its in-image byte offsets are 32-bit with bit 31 = out of range: one image of either tensor within 2 GiB)
         if (g_wgrad_k4 && (long long)p.k.IH * p.k.IW * p.k.x_cs * 2 < (1ll << 31) - 65536 && (long long)p.k.OH * p.k.OW * p.k.dy_cs * 2 < (1ll << 31) - 65536)
-            return launch_wb_k4(p, st);
+            return launch_wb_k4<KS>(p, st);
     }
     auto kern = wgrad_bf16_kernel<PTW, S, KS>;
     static unsigned long long configured = 0;   // one bit per device
