@@ -15,19 +15,19 @@ for H, Cin, Cout, ks in shapes:
     x = TS(torch.randn((N, H, H, ops.rupv(Cin, dt)), device="cuda", generator=g).to(dt), 0, Cin)
     dy = TS(torch.randn((N, H, H, ops.rupv(Cout, dt)), device="cuda", generator=g).to(dt), 0, Cout)
     dw = torch.empty(Cout, Cin, ks, ks, device="cuda")
-    ws = torch.empty(ops.wgrad_workspace(x, dy, ks, 1), device="cuda")
-    data[(H, Cin, Cout, ks)] = (x, dy, dw, ws)
+    ws = torch.empty(ops.wgrad_workspace(x, dy, ks, 1, with_bias=True), device="cuda")
+    data[(H, Cin, Cout, ks)] = (x, dy, dw, ws, torch.empty(Cout, device="cuda"))
 
 
 def run(k, n=10):
-    x, dy, dw, ws = data[k]
+    x, dy, dw, ws, db = data[k]
     for _ in range(2):
-        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws)
+        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws, dbias=db)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
-        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws)
+        ops.conv2d_wgrad(x, dy, dw, k[3], 1, ws, dbias=db)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 
@@ -45,5 +45,5 @@ for k in shapes:
     H, Cin, Cout, ks = k
     fl = 2.0 * N * H * H * Cin * Cout * ks * ks
     d = (ref[(k, -2)] - ref[(k, -1)]).abs().max().item() / ref[(k, -1)].abs().max().item()
-    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. reduce)  rel diff {d:.1e}", flush=True)
+    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. bias gradient and reduce)  rel diff {d:.1e}", flush=True)
 L.lib.unet_set_wgrad_mfma_shape(-2)
