@@ -733,20 +733,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
     const bool mv1 = k0 + wk * 32 + 16 < a.Cout, nv1 = c0 + wc * 32 + 16 < a.Cin;
     const bool mv0 = k0 + wk * 32 < a.Cout, nv0 = c0 + wc * 32 < a.Cin;
 
-    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
-    float bsum = 0.f;
+    // bias gradient = column sums of dy: every thread adds up the 8 channels of its own dy items as they pass through its registers, the 32
+    // threads of a channel group meet once at the end (see wgrad_bf16_k4_kernel: a serial walk of the staged tile cost a 1x1 tile's MFMAs)
+    const bool do_bias = a.bpart != nullptr && cblk == 0;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto bias_add = [&]() {
+#pragma unroll
+        for (int j = 0; j < DIT; ++j) {
+            const unsigned w[4] = {rd[j].x, rd[j].y, rd[j].z, rd[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bs[2 * i] += __uint_as_float(w[i] << 16); bs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+        }
+    };
     if (tile_begin < tile_end) {
         load_tile(tile_begin);
+        if (do_bias) bias_add();
         store_tile();
     }
     __syncthreads();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         if (has_next) load_tile(tile + 1);
-        if (do_bias) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) bsum += __uint_as_float((unsigned)*reinterpret_cast<const u16*>(dyT + p * RSD + tid * 2) << 16);
-        }
         if (mv0 && nv0) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -770,11 +777,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WArgs a) {
             }
         }
         __syncthreads();                  // every wave is done reading this tile
-        if (has_next) store_tile();
+        if (has_next) {
+            if (do_bias) bias_add();
+            store_tile();
+        }
         __syncthreads();
     }
 
-    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    if (do_bias) {          // (the images are dead: [32 rows of the item map][64 channels] floats, summed in row order)
+        float* red = reinterpret_cast<float*>(smemb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[(tid >> 3) * 64 + (tid & 7) * 8 + i] = bs[i];
+        __syncthreads();
+        if (tid < BK && k0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) t += red[rr * 64 + tid];
+            a.bpart[(size_t)split * a.Cout + k0 + tid] = t;
+        }
+    }
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * T * KC_;
 #pragma unroll
