@@ -470,9 +470,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
             if (e < HW * Q) *reinterpret_cast<float4*>(dst + e * 4) = r[j];
         }
     };
+    // bias gradient = column sums of dy, by the first workgroup column: every thread adds the channel quads of ITS dy items, as they pass
+    // through its registers, to sums of its own in LDS behind the tiles (item it of thread tid is always the same quad; the 42-accumulator
+    // form has no registers left for them); all items meet once at the end.  (One thread per output channel walking the staged tile --
+    // 32 dependent LDS reads per tile in front of the barrier -- cost 6.5 % of a 100 -> 100 launch.)
+    const bool do_bias = a.bpart != nullptr && bx == 0;
+    float4* bred = reinterpret_cast<float4*>(smem + (PT + HPIX) * LD) + tid;          // [DIT][256] float4
+    if (do_bias) {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) bred[it * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto bias_add = [&](const float4 (&r)[DIT]) {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            float4 v = bred[it * 256];
+            v.x += r[it].x; v.y += r[it].y; v.z += r[it].z; v.w += r[it].w;
+            bred[it * 256] = v;
+        }
+    };
     auto stage_rows = [&](const TilePos& t, int hy0) {
         float4 rd[DIT];
         load_dy(t, rd);
+        if (do_bias) bias_add(rd);
         store_dy(rd);
         for (int hy = hy0; hy < 3; ++hy) {
             float4 rx[RIT];
@@ -534,9 +553,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         }
     };
 
-    // bias gradient: the first workgroup column sums the staged dy tile (one thread per output channel)
-    const bool do_bias = a.bpart != nullptr && bx == 0 && tid < a.Cout;
-    float bsum = 0.f;
     if (tile_begin < tile_end) {
         const TilePos t0 = tile_pos(tile_begin);
         stage_rows(t0, 0);
@@ -550,10 +566,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         TilePos nx;
         float4 pd[DIT], px[RIT];
         if (has_next) nx = tile_pos(tile + 1);
-        if (PF && rolling) prefetch_rolling(nx, pd, px);
-        if (do_bias) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) bsum += dyT[p * LD + tid];
+        if (PF && rolling) {
+            prefetch_rolling(nx, pd, px);
+            if (do_bias) bias_add(pd);
         }
         int bq[NTW];
 #pragma unroll
@@ -588,7 +603,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         }
     }
 
-    if (do_bias) a.bpart[(size_t)split * a.Cout + tid] = bsum;
+    if (do_bias) {          // channel c adds the item sums of its quad in item order
+        __syncthreads();
+        const float* red = smem + (PT + HPIX) * LD;
+        if (tid < a.Cout) {
+            float t = 0.f;
+            for (int e = tid >> 2; e < PT * Q; e += Q) t += red[e * 4 + (tid & 3)];
+            a.bpart[(size_t)split * a.Cout + tid] = t;
+        }
+    }
     // ---- write partials: part[split][tap][k][c] ----
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * 9 * KC_;
@@ -1488,7 +1511,7 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
         UNET_CHECK_LAUNCH();
         rc = UNET_OK;
     } else if (p.narrow) {
-        const size_t lds = (size_t)(32 + 3 * 34) * 112 * sizeof(float);
+        const size_t lds = (size_t)(32 + 3 * 34) * 112 * sizeof(float) + (size_t)4 * 256 * 16;      // the two tiles + the bias item sums [DIT = 4][256] float4
         const dim3 grid(unet::cdiv(d->Cin, p.k.cw) * p.k.nnb, unet::roundup(p.splits, 8));
         static unsigned long long configured = 0;   // one bit per device
         if (unet::first_use_on_device(&configured)) {
