@@ -363,6 +363,7 @@ template <int NTOT>
 __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw) {
     constexpr int TW = 32, TH = 8, BN = 128, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
     constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
+    constexpr int NST = NF * 4 + (NTOT & 1) * 2;                  // 16-byte result stores a wave issues per tile (bf16 output)
     static_assert(NTOT >= 5 && NTOT <= 8, "channel tiles of the 128-wide block");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -488,6 +489,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, first_fold ? wfold : w0 + (size_t)kc0 * slab_b);
 
     for (;;) {
+        // ONE wait statement for the first loads of every tile, here: a second one on another path (after the epilogue, say) makes the
+        // compiler merge the two definitions of the load registers with copies placed BEFORE the wait -- of registers still in flight
+        // (caught by unet_amd/isa_check.py)
         wait_cnt<0, true>(b0, hreg);
         __syncthreads();                    // (every wave has left the LDS buffers of the previous tile)
         T256_STORE_HALO(kc0 & 1);
@@ -569,9 +573,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         auto unpack = [](unsigned lo, unsigned hi) -> f32x4 {
             return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
         };
+        if (y_f32) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (y_f32) {
+            for (int h = 0; h < 2; ++h) {
                 int pidx[MH];
                 bool pval[MH];
 #pragma unroll
@@ -618,8 +622,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                     for (int m = 0; m < MH; ++m)
                         if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
                 }
-                continue;
             }
+        } else {
+            // the bias of this wave's channel tiles, fetched once and first: a load between two result stores would make the compiler wait for
+            // the older store as well (one in-order counter) -- that wait, per channel tile, was most of the epilogue
+            f32x4 bvn[NL];
+#pragma unroll
+            for (int n = 0; n < NL; ++n) {
+                const int c4 = n0c + TILE_COL(n) + 4 * kq;
+                bvn[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr) {
+                    if (c4 + 3 < a.Cout) bvn[n] = *reinterpret_cast<const f32x4*>(a.bias + c4);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bvn[n][q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
             // the pixel this lane moves for pixel-tile pair j: tile 2 j + (kq & 1)
             int pidx2[MH / 2];
             bool pval2[MH / 2];
@@ -630,7 +651,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 pval2[j] = oy < a.OH && ox < a.OW;
                 pidx2[j] = pval2[j] ? (oy * a.OW + ox) : 0;
             }
-            u16* yb = reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co;
+            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co, 0,
+                                                                                  __builtin_amdgcn_readfirstlane(a.OH * a.OW * a.y_cs * 2), 0x00020000);
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
@@ -638,14 +660,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 const int c8 = n0c + TILE_COL(n) + 8 * (kq >> 1);          // the 8 channels this lane moves
                 const bool cvalid8 = c8 < a.n_end;
                 const int cc8 = cvalid8 ? c8 : 0;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
-                }
                 f32x4 v[MH];
 #pragma unroll
-                for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bv;
+                for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bvn[n];
                 if (resb != nullptr) {
                     uint4 rr[MH / 2];
 #pragma unroll
@@ -687,8 +704,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                     const uint2 xu = __builtin_bit_cast(uint2, x_), yu = __builtin_bit_cast(uint2, y_);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(xu.x, yu.x, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(xu.y, yu.y, false, false);
-                    if (cvalid8 && pval2[j]) *reinterpret_cast<uint4*>(yb + (size_t)pidx2[j] * a.y_cs + c8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const unsigned vo = (cvalid8 && pval2[j]) ? (unsigned)(pidx2[j] * a.y_cs + c8) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u){s0[0], s1[0], s0[1], s1[1]}, rsy, (int)vo, 0, 0);
                 }
+            }
             }
         }
 #ifdef UNET_STAMPS

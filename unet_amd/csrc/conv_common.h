@@ -390,7 +390,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
         if (p->bn == 128 && blocks(64, 128) < 400) p->bn = 64;
     }
     if (big_tile && d->ks == 3 && p->bm == 128 && p->bn == 128 && p->tw == 32 && k.S == 1 && p->nparity == 1 && blocks(256, 128) >= 512 &&
-        (long long)d->IH * d->IW * d->x_cs * 2 < (1ll << 31) - 65536) {      // (its halo items are buffer loads: one image within a 2 GiB descriptor)
+        (long long)d->IH * d->IW * d->x_cs * 2 < (1ll << 31) - 65536 && (long long)d->OH * d->OW * d->y_cs * 4 < (1ll << 31) - 65536) {      // (its halo items and result stores go through buffer descriptors: one image within 2 GiB)
         p->bm = 256;          // 8 x 32 pixel patch per workgroup, each wave 128 pixels x 64 channels
         p->hit = 6;
     }

@@ -1244,12 +1244,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ dbias, int splits, int Cout) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
+// dbias[c] = sum over the pixel splits of bpart[split][c], in double.  64 channels per workgroup, four threads per channel take every
+// fourth split and meet in LDS in a fixed order (one thread per channel walking up to 256 splits was a 22 us dependent chain, 18 times a step).
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ dbias, int splits, int Cout) {
+    __shared__ double part[4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int sp = 0; sp < splits; ++sp) s += (double)bpart[(size_t)sp * Cout + c];
-    dbias[c] = (float)s;
+    if (c < Cout)
+        for (int sp = q; sp < splits; sp += 4) s += (double)bpart[(size_t)sp * Cout + c];
+    part[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < Cout) dbias[c] = (float)(((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]);
 }
 
 // narrow-output kernel (wgrad_flat_kernel) for 80 < Cout <= 112; unet_set_wgrad_narrow(0) falls back to the 64x64-tiled kernel
@@ -1538,7 +1544,7 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
                            p.splits, p.T, KC_, d->accumulate);
     UNET_CHECK_LAUNCH();
     if (d->dbias != nullptr) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(unet::cdiv(d->Cout, 128)), dim3(128), 0, st, p.k.bpart, d->dbias, p.splits,
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(unet::cdiv(d->Cout, 64)), dim3(256), 0, st, p.k.bpart, d->dbias, p.splits,
                            d->Cout);
         UNET_CHECK_LAUNCH();
     }

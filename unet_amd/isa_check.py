@@ -104,8 +104,10 @@ def _check_function(name: str, body) -> Tuple[int, List[str]]:
 
     # State: {register: age}, age = number of asm loads issued AFTER the load that writes the register, minimised over all paths
     # (the youngest the load can be).  Loads return in issue order, so `s_waitcnt vmcnt(N)` retires every register of age >= N.
-    # Vector-memory instructions the compiler issues itself are not counted: they only make the hardware retire MORE than modelled.
+    # Vector-memory instructions the compiler issues itself count as younger entries of the same counter (see _VMEM below).
     _VMCNT = re.compile(r"vmcnt\((\d+)\)")
+    _VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_load", "scratch_store",
+             "flat_load", "flat_store")
 
     def transfer(i: int, inflight: Dict[int, int], report: bool) -> Dict[int, int]:
         nonlocal nloads
@@ -131,6 +133,15 @@ def _check_function(name: str, body) -> Tuple[int, List[str]]:
                     cur = {r: a for r, a in cur.items() if a < keep}
                 continue
             if in_asm:
+                continue
+            if code.startswith(_VMEM):
+                # a vector-memory instruction the compiler issues itself (epilogue loads / stores, spills) is one more YOUNGER entry of the
+                # same in-order counter: it ages every outstanding asm load (a counted wait behind N such instructions retires the loads)
+                if cur and report:
+                    hit = _regs(code) & cur.keys()
+                    if hit:
+                        bad.append(f"{name}:{ln}: touches in-flight v{sorted(hit)[0]}: {code}")
+                cur = {r: a + 1 for r, a in cur.items()}
                 continue
             if code.startswith("s_endpgm"):
                 if cur and report:
