@@ -102,11 +102,14 @@ int unet_conv2d(const unet_conv_desc* d, void* stream);
  * accumulation chains.  unet_set_conv_splitk(0) switches it off process-wide (A/B knob). */
 size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d);
 int unet_set_conv_splitk(int on);
-/* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) + 1000000 * splits -- for profilers / bench.py */
+/* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) + 1000000 * splits -- for profilers / bench.py;
+ * ...7: the 256-pixel tile of the bf16 path (3x3 stride 1: conv_bf16_t256_kernel); 9: conv1x1_smallk_kernel (1x1, reduction of <= 8 channels) */
 int unet_conv2d_variant(const unet_conv_desc* d);
 /* MFMA instruction shape used by the conv / wgrad kernels: 16 (v_mfma_f32_16x16x4_f32, 16-channel granularity, default)
  * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */
 int unet_set_mfma_shape(int shape);
+/* the same for the weight-gradient kernels; also the A/B switch of the bf16 weight gradient: -1 = wgrad_bf16_kernel (2 x 2 tiles per wave) for every
+ * shape, -2 = wgrad_bf16_k4_kernel for 3x3 / 1x1 stride-1 launches with 32-pixel-wide tiles (default); identical results */
 int unet_set_wgrad_mfma_shape(int shape);
 int unet_set_wgrad_1x1(int on);      /* 128x128-tiled GEMM kernel for 1x1 weight gradients on/off (default on) */
 int unet_set_wgrad_narrow(int on);   /* narrow-output (Cout <= 112) weight-gradient kernel on/off (default on) */
@@ -140,7 +143,8 @@ typedef struct {
 size_t unet_pack_batch_table_bytes(int njobs);
 int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int dtype, void* table_host, unsigned* total_blocks);
 int unet_pack_batch_run(const void* table_dev, int njobs, unsigned total_blocks, int dtype, void* stream);
-/* bf16 conv: 256-pixel x 128-channel workgroup tile for large layers on/off (default on; results identical, A/B knob) */
+/* bf16 conv: 256-pixel x 128-channel workgroup tile for large 3x3 layers on/off (default on; A/B knob: the input gradient sums its taps in the
+ * opposite order on the large tile, everything else is identical); 100 + n: on, with n consecutive tiles per workgroup instead of the launcher's choice */
 int unet_set_bf16_big_tile(int on);
 
 /* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
