@@ -533,3 +533,22 @@ def test_bf16_training_follows_the_fp32_hip_path():
     a, b = curves
     print("fp32 losses", [f"{v:.4f}" for v in a], "bf16 losses", [f"{v:.4f}" for v in b])
     assert b[-1] < b[0] and all(abs(u - v) <= 2e-2 * abs(u) for u, v in zip(a, b))
+
+
+def test_bf16_regression_step_follows_the_fp32_hip_path():
+    """enable_regression (n_out = 1, MSE on float targets; reference train.py:137-138,189-193) with bf16 storage: loss equal to the fp32 HIP
+    path within bf16 rounding, flat gradient cosine >= 0.99"""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(3)
+    ref = O.DynamicUnet("xresnet18", 4, 1, (64, 64))
+    O.randomize_bn_and_zero_gammas(ref, seed=4)
+    a = HipDynamicUnet("xresnet18", 4, 1, (64, 64)); a.load_state_dict(ref.state_dict()); a.train()
+    b = HipDynamicUnet("xresnet18", 4, 1, (64, 64), act_dtype="bf16"); b.load_state_dict(ref.state_dict()); b.train()
+    x, _ = O.synthetic_batch(2, 4, 64, 64, 2)
+    y = torch.rand(2, 64, 64, generator=torch.Generator().manual_seed(10)) * 3
+    la = a.forward_loss_backward(x.cuda(), y.cuda(), reg_kind="mse").item()
+    lb = b.forward_loss_backward(x.cuda(), y.cuda(), reg_kind="mse").item()
+    assert abs(la - lb) <= 2e-2 * max(1.0, abs(la)), (la, lb)
+    ga, gb = a.flat_grad.double(), b.flat_grad.double()
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    assert cos >= 0.99, cos

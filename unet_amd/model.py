@@ -424,7 +424,12 @@ class HipDynamicUnet(nn.Module):
                 dist.all_reduce(loss)
                 loss.div_(world)
                 grad_scale = grad_scale / world
-            ops.regloss_bwd(z, y, reg_kind, reg_beta, grad_scale, dz)
+            if dz.bf16:          # the loss kernels write fp32 (the logits are fp32 in both modes): one cast into the bf16 gradient slice
+                dz32 = ctx.act(self, "dlogits32", z.N, z.H, z.W, z.C, zero=True, dtype=torch.float32)
+                ops.regloss_bwd(z, y, reg_kind, reg_beta, grad_scale, dz32)
+                ops.cast_slice(dz32, dz)
+            else:
+                ops.regloss_bwd(z, y, reg_kind, reg_beta, grad_scale, dz)
         self._ensure_grad_views()
         self._hip_backward(dz)
         return loss
