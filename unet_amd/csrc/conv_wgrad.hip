@@ -121,11 +121,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         const TPos t = tile_pos(tile);
         static_for<DIT + XIT>([&](auto i) { load_item(t, i); });
     };
+    // bias gradient = column sums of dy, by the workgroups of the first input-channel block: every thread adds the channel quad of ITS dy
+    // items as it stores them (item it of thread tid is always quad tid & 15), the 16 threads of a quad meet once at the end.  (64 threads
+    // walking the staged tile, one dependent LDS read per pixel in front of the tile barrier, cost 1-2 % of a 3x3 launch.)
+    const bool do_bias = a.bpart != nullptr && cblk == 0;
+    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
             const int e = tid + it * 256;
             if (e < PT * 16) *reinterpret_cast<float4*>(dyT + e * 4) = rd[it];
+            if (do_bias) { bq4.x += rd[it].x; bq4.y += rd[it].y; bq4.z += rd[it].z; bq4.w += rd[it].w; }     // (items beyond the tile are zero)
         }
 #pragma unroll
         for (int j = 0; j < XIT; ++j) {
@@ -138,9 +144,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     const float* abase = dyT + h * BK + wk * 32 + l31;                  // + (2*step) * BK
     const float* bbase = xh + (h * S) * BC + wc * 32 + l31;             // + window offset
 
-    // bias gradient: threads 0..63 of the first channel-block column sum the staged dy tile (pads are zero)
-    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < BK;
-    float bsum = 0.f;
     if (tile_begin < tile_end) {
         load_tile(tile_begin);
         store_tile();
@@ -149,10 +152,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         const TPos nx = tile_pos(has_next ? tile + 1 : tile);
-        if (do_bias) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) bsum += dyT[p * BK + tid];
-        }
         // PT / 2 MFMA steps in groups of GS; in front of group g the prefetch items g * IPG .. are issued (scheduling barriers keep the
         // groups apart: a full unroll would otherwise hoist operand reads until the register file is full)
         constexpr int NG = 8, GS = (PT / 2) / NG, NIT = DIT + XIT, IPG = (NIT + NG - 1) / NG;
@@ -181,7 +180,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         __syncthreads();
     }
 
-    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    if (do_bias) {          // (the staged tiles are dead: [16 item rows][64 channels] floats, summed in row order)
+        reinterpret_cast<float4*>(smem)[tid] = bq4;
+        __syncthreads();
+        if (tid < BK && k0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) t += smem[rr * 64 + tid];
+            a.bpart[(size_t)split * a.Cout + k0 + tid] = t;
+        }
+    }
     // ---- write partials: part[split][tap][k][c] ----
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * T * KC_;
@@ -1071,19 +1079,22 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const WArgs a, long lo
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // bias gradient = column sums of dy (first input-channel block): every thread adds the channel quad of its dy items (always quad
+    // tid & 31) as it stores them; the 8 threads of a quad meet once at the end (see wgrad_kernel)
+    const bool do_bias = a.bpart != nullptr && cblk == 0;
+    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int e = tid + it * 256;
             *reinterpret_cast<float4*>(dyT + e * 4) = rd[it];
             *reinterpret_cast<float4*>(xT + e * 4) = rx[it];
+            if (do_bias) { bq4.x += rd[it].x; bq4.y += rd[it].y; bq4.z += rd[it].z; bq4.w += rd[it].w; }
         }
     };
 
     const float* abase = dyT + h * LDW + wk * 64 + l31;
     const float* bbase = xT + h * LDW + wc * 64 + l31;
-    const bool do_bias = a.bpart != nullptr && cblk == 0 && tid < 128;
-    float bsum = 0.f;
 
     if (tile_begin < tile_end) {
         load_tile(tile_begin);
@@ -1093,10 +1104,6 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const WArgs a, long lo
     for (long long tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         if (has_next) load_tile(tile + 1);
-        if (do_bias) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) bsum += dyT[p * LDW + tid];
-        }
 #pragma unroll
         for (int step = 0; step < PT / 2; ++step) {
             const float a0 = abase[(2 * step) * LDW], a1 = abase[(2 * step) * LDW + 32];
@@ -1111,7 +1118,16 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const WArgs a, long lo
         __syncthreads();
     }
 
-    if (do_bias && k0 + tid < a.Cout) a.bpart[(size_t)split * a.Cout + k0 + tid] = bsum;
+    if (do_bias) {          // (the staged tiles are dead: [8 item rows][128 channels] floats, summed in row order)
+        reinterpret_cast<float4*>(smem)[tid] = bq4;
+        __syncthreads();
+        if (tid < 128 && k0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) t += smem[rr * 128 + tid];
+            a.bpart[(size_t)split * a.Cout + k0 + tid] = t;
+        }
+    }
     const size_t KC_ = (size_t)a.Cout * a.Cin;
     float* pb = a.part + (size_t)split * KC_;
 #pragma unroll
