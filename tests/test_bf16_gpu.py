@@ -182,14 +182,15 @@ def test_conv_bf16_big_tile_shared_odd_tile(Cout):
     (112, 128, 256, 256),     # 8 tiles, zero-padded tail chunk (16 live channels of 32)
     (40, 228, 256, 256),      # two launches: a full block of 8 tiles + a narrow block of 7; folded tail of 8 channels
     (64, 160, 256, 256),      # 8 tiles + a 2-tile block (runs as 5 tiles over the zero filters of the padded image)
+    (256, 128, 32, 32, 16),   # a deep stage: 64 blocks of 256 pixels, the reduction split in two on top (fp32 slabs + reduce kernel)
 ])
 def test_conv_bf16_t256_kernel(case):
     """conv_bf16_t256_kernel (the 256-pixel tile of the large 3x3 layers, variant ...7): forward with bias + residual + ReLU into a channel
     slice, fp32 output, and the input gradient (filter slabs walked backwards) with residual + mask -- against fp64 on the same bf16 values.
     The input is a slice of a wider buffer whose neighbouring channels are NOT zero: a tail chunk must not read them."""
     from unet_amd import ops
-    Cin, Cout, H, W = case
-    N = 2
+    Cin, Cout, H, W = case[:4]
+    N = case[4] if len(case) > 4 else 2
     g = torch.Generator().manual_seed(Cin * 1000 + Cout)
     x = _bf(torch.randn(N, Cin, H, W, generator=g))
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5

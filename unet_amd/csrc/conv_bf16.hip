@@ -911,7 +911,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
 
 extern "C" int unet_set_bf16_big_tile(int on) {
     g_t256_tpw = on >= 100 ? on - 100 : 0;
-    g_big_tile = on ? 1 : 0;
+    g_big_tile = (on >= 2 && on < 100) ? on : (on ? 1 : 0);          // 2: the planner order of round 3's first half; 3..: the 256-pixel tile from 64 (on - 2) blocks up
     return UNET_OK;
 }
 
