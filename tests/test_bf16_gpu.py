@@ -183,6 +183,10 @@ def test_conv_bf16_big_tile_shared_odd_tile(Cout):
     (40, 228, 256, 256),      # two launches: a full block of 8 tiles + a narrow block of 7; folded tail of 8 channels
     (64, 160, 256, 256),      # 8 tiles + a 2-tile block (runs as 5 tiles over the zero filters of the padded image)
     (256, 128, 32, 32, 16),   # a deep stage: 64 blocks of 256 pixels, the reduction split in two on top (fp32 slabs + reduce kernel)
+    (64, 64, 64, 64, 16),     # 64-wide channel block: 4 tiles, two per wave
+    (32, 40, 128, 64, 4),     # 3 tiles: one per wave + a shared one
+    (24, 32, 64, 64, 16),     # 32-wide block: one tile per wave
+    (32, 16, 64, 96, 8),      # a single tile shared by the two waves of a pixel row
 ])
 def test_conv_bf16_t256_kernel(case):
     """conv_bf16_t256_kernel (the 256-pixel tile of the large 3x3 layers, variant ...7): forward with bias + residual + ReLU into a channel
@@ -222,8 +226,7 @@ def test_conv_bf16_t256_kernel(case):
     dxt = _empty(N, H, W, Cin, cs=ci + 8, co=8)
     wpd = ops.pack_weights(w.cuda(), 1, dtype=torch.bfloat16)
     dyt = _ts(dy, cs=co + 24, co=8)
-    if Cin > 64:
-        assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
+    assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
     ops.conv2d_dgrad(dyt, wpd, dxt, 3, 1, res=_ts(rr), mask=_ts(m, cs=ci + 16, co=16))
     assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-5
     # weight + bias gradient (wgrad_bf16_k4_kernel: 3x3 / stride 1 / 32-wide pixel tiles; blocks of 3 or 4 output-channel tiles, image

@@ -311,15 +311,20 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // NL filter tiles of one stage at p + lane offset + {0, 2048, 4096, 6144}; the last one through `vs` when it is the shared tile (SH)
 template <int NL, int SH>
 __device__ __forceinline__ void gld_bn(v4f (&d)[4], unsigned v0, unsigned v2, unsigned vs, const char* p) {
-    static_assert(NL == 3 || NL == 4, "filter tiles per wave");
+    static_assert(NL >= 1 && NL <= 4, "filter tiles per wave");
     if constexpr (NL == 4)
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %7\n\tglobal_load_dwordx4 %1, %4, %7 offset:2048\n\t"
                      "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %6, %7 offset:2048"
                      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(v0), "v"(v2), "v"(SH ? vs : v2), "s"(p));
-    else
+    else if constexpr (NL == 3)
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %5\n\tglobal_load_dwordx4 %1, %3, %5 offset:2048\n\t"
                      "global_load_dwordx4 %2, %4, %5"
                      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(v0), "v"(SH ? vs : v2), "s"(p));
+    else if constexpr (NL == 2)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:2048"
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(v0), "v"(SH ? vs : v0), "s"(p));
+    else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(d[0]) : "v"(SH ? vs : v0), "s"(p));
 }
 // six halo items through a buffer descriptor; out-of-range offsets read as zero
 __device__ __forceinline__ void gld_halo6_buf(v4f (&h)[6], const unsigned (&vo)[6], v4i rs, int soff) {
@@ -360,11 +365,11 @@ __device__ unsigned long long* g_stamps = nullptr;
 // A workgroup walks `tpw` consecutive output tiles: the first halo tile and filter tiles of tile i + 1 are requested BEFORE the epilogue
 // of tile i, so the HBM latency of a tile's prologue (14 % of a one-tile workgroup's life in the stamps) hides behind the stores.
 template <int NTOT>
-__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw) {
-    constexpr int TW = 32, TH = 8, BN = 128, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
+__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw, const int bn) {
+    constexpr int TW = 32, TH = 8, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
     constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
     constexpr int NST = NF * 4 + (NTOT & 1) * 2;                  // 16-byte result stores a wave issues per tile (bf16 output)
-    static_assert(NTOT >= 5 && NTOT <= 8, "channel tiles of the 128-wide block");
+    static_assert(NTOT >= 1 && NTOT <= 8, "channel tiles of the (32- / 64- / 128-wide) block");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         const int tx_ = __builtin_amdgcn_readfirstlane(id_ % a.tiles_x); id_ /= a.tiles_x; \
         const int ty_ = __builtin_amdgcn_readfirstlane(id_ % a.tiles_y); \
         img = __builtin_amdgcn_readfirstlane(id_ / a.tiles_y); \
-        oy0 = ty_ * TH; ox0 = tx_ * TW; n0 = a.n_base + nt_ * BN; \
+        oy0 = ty_ * TH; ox0 = tx_ * TW; n0 = a.n_base + nt_ * bn; \
         wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2)); \
         w0 = wbase + (rev ? 8ll * a.nchunks * (long long)slab_b : 0ll);       /* slab of LDS tap 0, chunk 0 */ \
         wfold = wbase + (size_t)9 * a.nchunks * slab_b; \
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #define TILE_COL(n_) (((n_) == NF ? (n_) * 2 : (n_) * 2 + wn) * 16)
     const unsigned voff = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
     const unsigned voff2 = voff + 4096u;
-    const unsigned voffs = (NL > 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
+    const unsigned voffs = (NF >= 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
     v4f b0[N16], b1[N16];
 
     f32x4 acc[M16][N16];
@@ -760,35 +765,37 @@ int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
     tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
     dim3 grid = p.grid;
     grid.x = (unsigned)unet::roundup(unet::cdiv(ntiles, tpw), 8);
-    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32, tpw);
+    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32, tpw, p.bn);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
 
-// the channel-tile count is a template parameter: a launch whose last 128-wide channel block is narrower than the others (Cout = 228:
-// 8 + 7 tiles) is issued as two launches over disjoint channel ranges
+// the channel-tile count of a block is a template parameter: a launch whose last channel block is narrower than the others (Cout = 228 in
+// 128-wide blocks: 8 + 7 tiles) is issued as two launches over disjoint channel ranges
 int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
-    const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn;
-    const int last_tiles = (cols - (nblk - 1) * 128 + 15) / 16;
+    const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn, full = p.bn / 16;
+    const int last_tiles = (cols - (nblk - 1) * p.bn + 15) / 16;
     auto one = [&](const Plan& q, int tiles) {
-        switch (tiles < 5 ? 5 : tiles) {         // (a narrower block multiplies the zero filters of the padded image: results beyond n_end are not stored)
+        switch (tiles) {
             case 8: return launch_t256n<8>(q, y_f32, st);
             case 7: return launch_t256n<7>(q, y_f32, st);
             case 6: return launch_t256n<6>(q, y_f32, st);
             case 5: return launch_t256n<5>(q, y_f32, st);
+            case 4: return launch_t256n<4>(q, y_f32, st);
+            case 3: return launch_t256n<3>(q, y_f32, st);
+            case 2: return launch_t256n<2>(q, y_f32, st);
+            case 1: return launch_t256n<1>(q, y_f32, st);
         }
-        unet::set_error("conv bf16: %d channel tiles in a 128-wide block of the 256-pixel tile", tiles);
+        unet::set_error("conv bf16: %d channel tiles in a block of the 256-pixel tile", tiles);
         return (int)UNET_E_UNSUPPORTED;
     };
-    if (nblk == 1 || last_tiles == 8) return one(p, nblk == 1 ? last_tiles : 8);
+    if (nblk == 1 || last_tiles == full) return one(p, nblk == 1 ? last_tiles : full);
     Plan q = p;                                       // the full blocks
-    q.k.ntn = nblk - 1; q.k.n_end = p.k.n_base + (nblk - 1) * 128;
-    q.grid.x = (unsigned)unet::roundup(q.k.mtiles * q.k.ntn, 8);
-    int rc = one(q, 8);
+    q.k.ntn = nblk - 1; q.k.n_end = p.k.n_base + (nblk - 1) * p.bn;
+    int rc = one(q, full);
     if (rc != UNET_OK) return rc;
     q = p;                                            // the narrow last block
-    q.k.ntn = 1; q.k.n_base = p.k.n_base + (nblk - 1) * 128;
-    q.grid.x = (unsigned)unet::roundup(q.k.mtiles, 8);
+    q.k.ntn = 1; q.k.n_base = p.k.n_base + (nblk - 1) * p.bn;
     return one(q, last_tiles);
 }
 
