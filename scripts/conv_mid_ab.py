@@ -10,7 +10,7 @@ settings = [int(v) for v in sys.argv[1:]] or [1, 4, 6]
 dt = torch.bfloat16
 N = 16
 g = torch.Generator(device="cuda").manual_seed(0)
-shapes = [(32, 512, 512), (32, 256, 256), (32, 128, 256), (64, 128, 128), (128, 64, 64), (256, 64, 64), (256, 32, 32), (256, 32, 64), (128, 64, 128), (64, 384, 384)]
+shapes = [(16, 512, 512), (16, 1024, 512), (32, 512, 512), (32, 256, 256), (32, 128, 256), (64, 128, 128), (128, 64, 64), (256, 64, 64), (256, 32, 32), (256, 32, 64), (128, 64, 128), (64, 384, 384)]
 data = {}
 for H, Cin, Cout in shapes:
     x = TS(torch.randn((N, H, H, Cin), device="cuda", generator=g).to(dt), 0, Cin)

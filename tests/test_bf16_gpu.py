@@ -187,6 +187,8 @@ def test_conv_bf16_big_tile_shared_odd_tile(Cout):
     (32, 40, 128, 64, 4),     # 3 tiles: one per wave + a shared one
     (24, 32, 64, 64, 16),     # 32-wide block: one tile per wave
     (32, 16, 64, 96, 8),      # a single tile shared by the two waves of a pixel row
+    (100, 72, 32, 24, 16),    # 16-pixel-wide patches (outputs 16..31 pixels wide), ragged second patch column, folded tail
+    (256, 512, 16, 16, 16),   # a 16 x 16 stage: 16 patches x 4 channel blocks
 ])
 def test_conv_bf16_t256_kernel(case):
     """conv_bf16_t256_kernel (the 256-pixel tile of the large 3x3 layers, variant ...7): forward with bias + residual + ReLU into a channel
@@ -226,7 +228,8 @@ def test_conv_bf16_t256_kernel(case):
     dxt = _empty(N, H, W, Cin, cs=ci + 8, co=8)
     wpd = ops.pack_weights(w.cuda(), 1, dtype=torch.bfloat16)
     dyt = _ts(dy, cs=co + 24, co=8)
-    assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
+    if not (H == 16 and Cin < 512):          # (the 16 x 16 gradient launch over 256 channels has 32 blocks: generic kernel)
+        assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
     ops.conv2d_dgrad(dyt, wpd, dxt, 3, 1, res=_ts(rr), mask=_ts(m, cs=ci + 16, co=16))
     assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-5
     # weight + bias gradient (wgrad_bf16_k4_kernel: 3x3 / stride 1 / 32-wide pixel tiles; blocks of 3 or 4 output-channel tiles, image

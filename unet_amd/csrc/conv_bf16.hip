@@ -305,7 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64, HIT == 4 ? 3 : 2) void conv_bf16_kerne
 //   * halo items are buffer loads (out-of-image and channel-tail items read as zero through the descriptor's range check: no
 //     clamping, no select before the LDS store), issued in the first tap of a chunk only;
 //   * only the third / fourth channel tile of a wave can be absent or shared: two wave-uniform branches per half stage.
-constexpr int T256_HW = 34, T256_HPIX = 10 * 34, T256_ROWB = 4 * LDKB, T256_BUFB = T256_HPIX * T256_ROWB;
+constexpr int T256_ROWB = 4 * LDKB;          // bytes per halo pixel in LDS (64 of channels + 32 pad)
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // NL filter tiles of one stage at p + lane offset + {0, 2048, 4096, 6144}; the last one through `vs` when it is the shared tile (SH)
@@ -364,9 +364,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 // swapped (`r`), so the code of the two waves is the same and the stage body has no branch at all.
 // A workgroup walks `tpw` consecutive output tiles: the first halo tile and filter tiles of tile i + 1 are requested BEFORE the epilogue
 // of tile i, so the HBM latency of a tile's prologue (14 % of a one-tile workgroup's life in the stamps) hides behind the stores.
-template <int NTOT>
+// TW = 32 (an 8 x 32 pixel patch) or 16 (16 x 16: the stages whose output is 16..31 pixels wide).
+template <int NTOT, int TW>
 __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw, const int bn) {
-    constexpr int TW = 32, TH = 8, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
+    constexpr int TH = 256 / TW, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
+    constexpr int T256_HW = TW + 2, T256_HPIX = (TH + 2) * T256_HW, T256_BUFB = T256_HPIX * T256_ROWB;
+    static_assert((TW == 32 || TW == 16) && T256_HPIX * 4 <= HIT * NTH, "pixel patch of the 256-pixel tile");
     constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
     constexpr int NST = NF * 4 + (NTOT & 1) * 2;                  // 16-byte result stores a wave issues per tile (bf16 output)
     static_assert(NTOT >= 1 && NTOT <= 8, "channel tiles of the (32- / 64- / 128-wide) block");
@@ -457,9 +460,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         for (int n = 0; n < N16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // LDS operand address of pixel tile 0, tap 0 in buffer 0 (bytes); pixel tile m: + MOFF(m), tap t: + TOFF(t) -- immediates
-    const unsigned vbase = (unsigned)(((wm * 4) * T256_HW + l15) * T256_ROWB + 16 * kq);
-    const unsigned hsw = (unsigned)(r * 2 * T256_HW * T256_ROWB);           // (pixel tiles 4..7 lie two tile rows below tiles 0..3)
-#define MOFF(m_) ((((m_) >> 1) * T256_HW + ((m_) & 1) * 16) * T256_ROWB)
+    const unsigned vbase = (unsigned)(((wm * 128 / TW) * T256_HW + l15) * T256_ROWB + 16 * kq);
+    constexpr int HALF_B = (64 / TW) * T256_HW * T256_ROWB;              // pixel tiles 4..7 lie 64 / TW patch rows below tiles 0..3
+    const unsigned hsw = (unsigned)(r * HALF_B);
+#define MOFF(m_) (((((m_) * 16) / TW) * T256_HW + ((m_) * 16) % TW) * T256_ROWB)
 #define TOFF(t_) ((((t_) / 3) * T256_HW + (t_) % 3) * T256_ROWB)
     // folded tail: lane group kq reads channel group 0 of the tail chunk at ITS tap 4 j + kq (tap index in filter order); computed where
     // it is used (three registers that the main loop does not have to carry)
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #define T256_MFMA(bu_, addr_) do { \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
             bf16x8 pv_[MH]; \
-            const unsigned ah_ = (addr_) + (h == 0 ? hsw : 2 * T256_HW * T256_ROWB - hsw); \
+            const unsigned ah_ = (addr_) + (h == 0 ? hsw : HALF_B - hsw); \
             _Pragma("unroll") for (int m = 0; m < MH; ++m) \
                 pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(lds + ah_ + MOFF(m))); \
             _Pragma("unroll") for (int n = 0; n < NL; ++n) { \
@@ -753,9 +757,9 @@ extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
 
 int g_t256_tpw = 0;        // tiles per workgroup of conv_bf16_t256_kernel (0: chosen per launch; unet_set_bf16_big_tile(100 + n) forces n)
 
-template <int NTOT>
+template <int NTOT, int TW>
 int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
-    auto kern = conv_bf16_t256_kernel<NTOT>;
+    auto kern = conv_bf16_t256_kernel<NTOT, TW>;
     static unsigned long long configured = 0;
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -765,7 +769,7 @@ int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
     tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
     dim3 grid = p.grid;
     grid.x = (unsigned)unet::roundup(unet::cdiv(ntiles, tpw), 8);
-    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)2 * T256_BUFB, st, p.k, y_f32, tpw, p.bn);
+    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)2 * (256 / TW + 2) * (TW + 2) * T256_ROWB, st, p.k, y_f32, tpw, p.bn);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
@@ -776,17 +780,30 @@ int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
     const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn, full = p.bn / 16;
     const int last_tiles = (cols - (nblk - 1) * p.bn + 15) / 16;
     auto one = [&](const Plan& q, int tiles) {
-        switch (tiles) {
-            case 8: return launch_t256n<8>(q, y_f32, st);
-            case 7: return launch_t256n<7>(q, y_f32, st);
-            case 6: return launch_t256n<6>(q, y_f32, st);
-            case 5: return launch_t256n<5>(q, y_f32, st);
-            case 4: return launch_t256n<4>(q, y_f32, st);
-            case 3: return launch_t256n<3>(q, y_f32, st);
-            case 2: return launch_t256n<2>(q, y_f32, st);
-            case 1: return launch_t256n<1>(q, y_f32, st);
+        if (q.tw == 32) {
+            switch (tiles) {
+                case 8: return launch_t256n<8, 32>(q, y_f32, st);
+                case 7: return launch_t256n<7, 32>(q, y_f32, st);
+                case 6: return launch_t256n<6, 32>(q, y_f32, st);
+                case 5: return launch_t256n<5, 32>(q, y_f32, st);
+                case 4: return launch_t256n<4, 32>(q, y_f32, st);
+                case 3: return launch_t256n<3, 32>(q, y_f32, st);
+                case 2: return launch_t256n<2, 32>(q, y_f32, st);
+                case 1: return launch_t256n<1, 32>(q, y_f32, st);
+            }
+        } else if (q.tw == 16) {
+            switch (tiles) {
+                case 8: return launch_t256n<8, 16>(q, y_f32, st);
+                case 7: return launch_t256n<7, 16>(q, y_f32, st);
+                case 6: return launch_t256n<6, 16>(q, y_f32, st);
+                case 5: return launch_t256n<5, 16>(q, y_f32, st);
+                case 4: return launch_t256n<4, 16>(q, y_f32, st);
+                case 3: return launch_t256n<3, 16>(q, y_f32, st);
+                case 2: return launch_t256n<2, 16>(q, y_f32, st);
+                case 1: return launch_t256n<1, 16>(q, y_f32, st);
+            }
         }
-        unet::set_error("conv bf16: %d channel tiles in a block of the 256-pixel tile", tiles);
+        unet::set_error("conv bf16: %d channel tiles / tile width %d in the 256-pixel tile", tiles, q.tw);
         return (int)UNET_E_UNSUPPORTED;
     };
     if (nblk == 1 || last_tiles == full) return one(p, nblk == 1 ? last_tiles : full);

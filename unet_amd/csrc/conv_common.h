@@ -388,7 +388,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // bf16: the 256-pixel x 128-channel tile (conv_bf16_t256_kernel) for 3x3 / stride-1 launches from 64 blocks up -- on the deep 32 x 32
     // stages (a quarter of the chip's workgroup slots) it still beats the generic 128- / 64-pixel tiles by 1.2-1.7x, 512 -> 512: 109 -> 65 us,
     // with or without a split reduction on top (scripts/conv_mid_ab.py).  big_tile == 2: the order of round 3's first half (shrink first).
-    const bool big_ok = big_tile && d->ks == 3 && p->bm == 128 && (p->bn == 128 || big_tile != 2) && p->tw == 32 && k.S == 1 && p->nparity == 1 &&
+    const bool big_ok = big_tile && d->ks == 3 && p->bm == 128 && (p->bn == 128 || big_tile != 2) && (p->tw == 32 || (p->tw == 16 && big_tile != 2)) && k.S == 1 && p->nparity == 1 &&
                         blocks(256, p->bn) >= (big_tile >= 3 ? 64 * (big_tile - 2) : (big_tile == 2 ? 512 : 64)) &&
                         (long long)d->IH * d->IW * d->x_cs * 2 < (1ll << 31) - 65536 &&
                         (long long)d->OH * d->OW * d->y_cs * 4 < (1ll << 31) - 65536;       // (its halo items and result stores go through buffer descriptors: one image within 2 GiB)
