@@ -176,6 +176,16 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
 def roofline_of(ps, dtype, dt, steps, pmc):
     """dominant kernel over ALL its launches in the timed region: algorithmic FLOPs (fp32: MFMA roofline) or algorithmic bytes (bf16
     storage: HBM roofline) / summed launch durations (events on the launch stream)"""
+    def traffic_of(name):
+        """HBM bytes per launch of the kernel from the counter passes (profiles/pmc_traffic.json), per launch AS COUNTED HERE: a conv call
+        that the library issues as two kernel launches (a narrow last channel block, a split reduction) is one launch of the probe"""
+        t = pmc.get(name)
+        if not t or not t.get("hbm_bytes_per_launch"):
+            return None
+        per_step = t.get("launches_sampled", 0) / max(1, t.get("steps_sampled", 0)) if t.get("steps_sampled") else None
+        mine = ps["launches"] / max(1, steps)
+        return int(t["hbm_bytes_per_launch"] * (per_step / mine if per_step and mine else 1.0))
+
     common = {"launches_per_step": ps["launches"] // max(1, steps), "avg_launch_ms": round(ps["avg_ms"], 4),
               "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
               "avg_launch_alg_bytes": int(ps["bytes"] / max(1, ps["launches"])),
@@ -186,14 +196,14 @@ def roofline_of(ps, dtype, dt, steps, pmc):
                                            "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> and "
                                            "<...,true> = the launches whose last 4 of 100 output channels run on v_mfma_4x4x1)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
-                "traffic": pmc.get("conv_igemm16_kernel<32,2,2,2,2,4>", {}).get("hbm_bytes_per_launch"), **common}
+                "traffic": traffic_of("conv_igemm16_kernel<32,2,2,2,2,4>"), **common}
     achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "conv_bf16_t256_kernel (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM, 256-pixel x 128-channel tile: "
                                       "every wide 3x3 conv, forward and input-gradient; rocprofv3 lists its instantiations <6>, <7>, <8> = "
                                       "16-wide channel tiles per block); algorithmic bytes = every operand tensor once in, the result once "
                                       "out, the packed filter once",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-            "traffic": pmc.get("conv_bf16_t256_kernel", {}).get("hbm_bytes_per_launch"),
+            "traffic": traffic_of("conv_bf16_t256_kernel"),
             "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1),
             "mfma_frac_of_bf16_peak": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), **common}
 

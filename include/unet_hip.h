@@ -103,7 +103,8 @@ int unet_conv2d(const unet_conv_desc* d, void* stream);
 size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d);
 int unet_set_conv_splitk(int on);
 /* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) + 1000000 * splits -- for profilers / bench.py;
- * ...7: the 256-pixel tile of the bf16 path (3x3 stride 1: conv_bf16_t256_kernel); 9: conv1x1_smallk_kernel (1x1, reduction of <= 8 channels) */
+ * ...7 / ...6: the 256-pixel tile of the bf16 path (3x3 stride 1: conv_bf16_t256_kernel; 7 = 128-wide blocks, 32-pixel patches, >= 512 blocks,
+ * 6 = its narrow-block / 16-pixel-patch / small-grid launches); 9: conv1x1_smallk_kernel (1x1, reduction of <= 8 channels) */
 int unet_conv2d_variant(const unet_conv_desc* d);
 /* MFMA instruction shape used by the conv / wgrad kernels: 16 (v_mfma_f32_16x16x4_f32, 16-channel granularity, default)
  * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */

@@ -21,8 +21,19 @@ def short(name: str) -> str:
     # conv_igemm16_kernel<..., SLV>: the sliver instantiation (the 3 launches per step with a 16 n + 4 output width) is the same kernel
     # template as the plain one; the PMC summary and pmc_traffic.json aggregate both under the name without the flag
     name = re.sub(r"^(conv_igemm16_kernel<[0-9,]+),(?:true|false)>$", r"\1>", name)
-    # conv_bf16_t256_kernel<NTOT>: one kernel template, instantiated per channel-tile count of the 128-wide block; aggregated under the bare name
-    return re.sub(r"^conv_bf16_t256_kernel<[0-9]+>$", "conv_bf16_t256_kernel", name)
+    # conv_bf16_t256_kernel<NTOT,TW>: one kernel template, instantiated per channel-tile count of the block and patch width; aggregated under the bare name
+    return re.sub(r"^conv_bf16_t256_kernel<[0-9,]+>$", "conv_bf16_t256_kernel", name)
+
+
+def keyed(name: str, grid_threads: int) -> str:
+    """conv_bf16_t256_kernel serves the large layers (>= 512 workgroups: the launches bench.py's roofline follows, variant ...7) and, since the
+    second half of round 3, narrow-block / small-grid launches (variant ...6): two rows, split by grid size"""
+    k = short(name)
+    if k == "conv_bf16_t256_kernel":
+        m = re.search(r"conv_bf16_t256_kernel<\s*(\d+),\s*(\d+)>", name)
+        large = m is not None and int(m.group(1)) >= 5 and int(m.group(2)) == 32 and grid_threads >= 512 * 256
+        return k if large else "conv_bf16_t256_kernel[narrow / small]"
+    return k
 
 
 def pmc(dirname):
@@ -31,7 +42,7 @@ def pmc(dirname):
     if not f:
         return out
     for r in csv.DictReader(open(f[0])):
-        out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out[keyed(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
@@ -40,7 +51,7 @@ def durations(dirname):
     f = sorted(glob.glob(str(src / dirname / "*" / "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
     if f:
         for r in csv.DictReader(open(f[0])):
-            out[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            out[keyed(r["Kernel_Name"], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return out
 
 
@@ -48,6 +59,10 @@ shutil.copy(src / "bench.json", dst / f"{tag}_bench.json")
 stats = sorted(glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)[0]
 shutil.copy(stats, dst / f"{tag}_bench_kernel_stats.csv")
 
+sd = durations("stats")
+split = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2), "total_ms": round(sum(v) / 1e6, 3)} for k, v in sd.items() if k.startswith("conv_bf16_t256_kernel")}
+if split:
+    json.dump(split, open(dst / f"{tag}_t256_by_grid.json", "w"), indent=1)
 fetch, write, sq, sqdur, lds = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), durations("pmc_sq"), pmc("pmc_lds")
 traffic = {}
 rows = []
@@ -59,7 +74,7 @@ for k in sorted(set(fetch) | set(write) | set(sq) | set(lds)):
         f_avg, w_avg = sum(fa) / len(fa), sum(wa) / len(wa)
         hbm = (2 * f_avg + w_avg) * 1024
         row.update(FETCH_SIZE_KB_avg=round(f_avg, 1), WRITE_SIZE_KB_avg=round(w_avg, 1), hbm_bytes_per_launch=int(hbm))
-        traffic[k] = {"launches_sampled": len(fa), "FETCH_SIZE_KB_avg": round(f_avg, 1), "WRITE_SIZE_KB_avg": round(w_avg, 1),
+        traffic[k] = {"launches_sampled": len(fa), "steps_sampled": 3, "FETCH_SIZE_KB_avg": round(f_avg, 1), "WRITE_SIZE_KB_avg": round(w_avg, 1),
                       "hbm_bytes_per_launch": int(hbm),
                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B reads as 64 B); WRITE_SIZE as is"}
     if k in sq and sq[k].get("SQ_BUSY_CU_CYCLES"):

@@ -209,7 +209,7 @@ def test_conv_bf16_t256_kernel(case):
     rt = _ts(r, cs=co + 16, co=16)
     yt = _empty(N, H, W, Cout, cs=co + 40, co=32)
     wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
-    assert ops.conv2d_variant(xt, wp, yt, 3, 1) % 10 == 7
+    assert ops.conv2d_variant(xt, wp, yt, 3, 1) % 10 in (6, 7)          # the 256-pixel tile (7: a large layer, 6: narrow / small)
     ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True)
     got = _back(yt)
     assert (got.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-5
@@ -229,7 +229,7 @@ def test_conv_bf16_t256_kernel(case):
     wpd = ops.pack_weights(w.cuda(), 1, dtype=torch.bfloat16)
     dyt = _ts(dy, cs=co + 24, co=8)
     if not (H == 16 and Cin < 512):          # (the 16 x 16 gradient launch over 256 channels has 32 blocks: generic kernel)
-        assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 == 7
+        assert ops.conv2d_variant(dyt, wpd, dxt, 3, 1, kind=1) % 10 in (6, 7)
     ops.conv2d_dgrad(dyt, wpd, dxt, 3, 1, res=_ts(rr), mask=_ts(m, cs=ci + 16, co=16))
     assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-5
     # weight + bias gradient (wgrad_bf16_k4_kernel: 3x3 / stride 1 / 32-wide pixel tiles; blocks of 3 or 4 output-channel tiles, image

@@ -928,7 +928,10 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? 7 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
+    // 256-pixel tile: ...7 = the large layers (128-wide blocks, 32-pixel patches, >= 512 blocks: the launches bench.py's roofline follows), ...6 = its
+    // narrow-block / 16-pixel-patch / small-grid launches
+    const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? (large ? 7 : 6) : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
 
 }  // namespace unetconv
