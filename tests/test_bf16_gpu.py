@@ -559,3 +559,40 @@ def test_bf16_regression_step_follows_the_fp32_hip_path():
     ga, gb = a.flat_grad.double(), b.flat_grad.double()
     cos = (ga @ gb / (ga.norm() * gb.norm())).item()
     assert cos >= 0.99, cos
+
+
+def test_bf16_xresnet34_deep_ragged_decoder_widths():
+    """xresnet34_deep with bf16 storage: the last UnetBlock up-samples 140 channels and the dense merge follows 102 -- not multiples of the
+    8-channel vector, so the concat buffers carry a gap and the consumers' filters zero rows / columns for it (modules._ConvExec.set_gaps).
+    Loss equal to the fp32 HIP path within bf16 rounding; the gradients of the four gapped layers (filters AND biases: live rows / columns
+    scattered back from the gapped gradient) agree to cosine >= 0.999; flat gradient cosine >= 0.97 (measured 0.980: this encoder's two
+    extra stages are 4 x 4 and 2 x 2 pixels at 256 x 256 -- BatchNorm over 8..32 values makes the encoder's small gradients noisy in bf16,
+    the standard xresnet34 reaches 0.99996); eval masks >= 98 % identical."""
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(5)
+    S = 256
+    ref = O.DynamicUnet("xresnet34_deep", 4, 5, (S, S))
+    O.randomize_bn_and_zero_gammas(ref, seed=6)
+    a = HipDynamicUnet("xresnet34_deep", 4, 5, (S, S)); a.load_state_dict(ref.state_dict()); a.train()
+    b = HipDynamicUnet("xresnet34_deep", 4, 5, (S, S), act_dtype="bf16"); b.load_state_dict(ref.state_dict()); b.train()
+    assert (b.up_c, b.up_off, b.cat_c, b.cat_p) == (102, 104, 106, 108) and (b.layers[9].cu, b.layers[9].cu_off) == (140, 144)
+    x, y = O.synthetic_batch(2, 4, S, S, 5, seed=7)
+    w = torch.full((5,), 0.2, device="cuda")
+    la = a.forward_loss_backward(x.cuda(), y.cuda(), w).item()
+    lb = b.forward_loss_backward(x.cuda(), y.cuda(), w).item()
+    assert abs(la - lb) <= 2e-2 * max(1.0, abs(la)), (la, lb)
+    ga, gb = a.flat_grad.double(), b.flat_grad.double()
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    assert cos >= 0.97, cos
+    seen = 0
+    for (n, p), (_, q) in zip(b.named_parameters(), a.named_parameters()):
+        if n.startswith(("layers.9.conv1.", "layers.13.", "layers.14.")):
+            pg, qg = p.grad.double().flatten(), q.grad.double().flatten()
+            c = (pg @ qg / (pg.norm() * qg.norm() + 1e-30)).item()
+            assert c >= 0.999, (n, c)
+            seen += 1
+    assert seen == 8
+    a.eval(); b.eval()
+    with torch.no_grad():
+        ma, mb = a.predict_probs(x.cuda())[1], b.predict_probs(x.cuda())[1]
+    assert (ma == mb).float().mean().item() >= 0.98

@@ -85,12 +85,29 @@ class HipDynamicUnet(nn.Module):
         _kaiming_init(layers[3], layers[-2])
         self.layers = nn.ModuleList(layers)
         self.cat_c = xc
-        # every concat inside a UnetBlock is two channel slices of one buffer: the second starts at a multiple of the vector width
+        # every concat inside a UnetBlock is two channel slices of one buffer: the second starts at a multiple of the vector width.  bf16
+        # storage (8-channel vectors) of an encoder whose decoder widths are not multiples of 8 (xresnet34_deep: 140 in the last UnetBlock, 102
+        # in front of the dense merge) leaves a GAP of dead channels there: the consumers' filters carry zero rows / columns for them
         vec = 8 if act_dtype == "bf16" else 4
-        ragged = [b.cu for b in layers[4:4 + len(self.sz_chg_idxs)] if b.cu % vec] + ([self.up_c] if act_dtype == "bf16" and self.up_c % vec else [])
-        if ragged:
-            raise ValueError(f"{arch}: decoder widths {ragged} are not multiples of {vec} channels"
-                             + (" (bf16 storage): use act_dtype='f32' for this encoder" if act_dtype == "bf16" else ""))
+        blocks = layers[4:4 + len(self.sz_chg_idxs)]
+        ragged = [b.cu for b in blocks if b.cu % vec] + ([self.up_c] if act_dtype == "bf16" and self.up_c % vec else [])      # (fp32: the dense merge takes any width)
+        self.up_off, self.cat_p = self.up_c, self.cat_c          # physical offset of the network-input slice / width of the dense merge
+        if ragged and act_dtype == "bf16":
+            for b in blocks:
+                if b.cu % vec:
+                    b.set_gap(vec)
+            if self.up_c % vec:
+                self.up_off = (self.up_c + vec - 1) // vec * vec
+                self.cat_p = self.up_off + n_in
+                gap = (self.up_c, self.up_off - self.up_c)
+                rb, head = layers[-2], layers[-1]
+                for cl in (rb.convpath[0], rb.convpath[1]):
+                    cl.cx.set_gaps(in_gap=gap, out_gap=gap)
+                    cl.nf = self.cat_p
+                rb.nf = self.cat_p
+                head.cx.set_gaps(in_gap=gap)
+        elif ragged:
+            raise ValueError(f"{arch}: decoder widths {ragged} are not multiples of {vec} channels")
         self._post_bx = _BNExec(post_bn)
         self._device = torch.device(device)
         self.ctx: Optional[Ctx] = None
@@ -164,10 +181,10 @@ class HipDynamicUnet(nn.Module):
             cx.ensure_buffers(training)
             ver = cx.version()
             if cx._ver_f != ver:
-                jobs.append((cx.conv.weight.data, cx.wp_f, 0, cx.fold_scale()))
+                jobs.append((cx.wsrc(), cx.wp_f, 0, cx.fold_scale()))
                 marks.append((cx, 0, ver))
             if training and cx._ver_d != ver:
-                jobs.append((cx.conv.weight.data, cx.wp_d, 1, None))
+                jobs.append((cx.wsrc(), cx.wp_d, 1, None))
                 marks.append((cx, 1, ver))
         if not jobs:
             return
@@ -252,9 +269,9 @@ class HipDynamicUnet(nn.Module):
         for k, idx in enumerate(self.sz_chg_idxs):
             h = L[4 + k].hip_fwd(ctx, h, skips[idx])
         nb = 4 + len(self.sz_chg_idxs)
-        X = ctx.act(self, "xcat", N, H, W, self.cat_c, zero=True)
+        X = ctx.act(self, "xcat", N, H, W, self.cat_p, zero=True)
         L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
-        put(X.buf, self.up_c)                       # after the shuffle: a ragged up_c leaves its pad lanes inside these channels
+        put(X.buf, self.up_off)                     # after the shuffle: the up slice owns its padding lanes (a gap: zeros) in front of these channels
         o = L[nb + 3].hip_fwd(ctx, X)
         z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True, dtype=torch.float32)      # logits are fp32 in both modes
         head: ConvLayer = L[nb + 4]

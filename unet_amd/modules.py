@@ -158,6 +158,63 @@ class _ConvExec:
         self._ver_d = None
         self.ctx: Optional["Ctx"] = None   # set by HipDynamicUnet once the tree is built
         self.fold: Optional["_BNExec"] = None       # the BatchNorm that follows this conv (ConvLayer with norm), folded in eval mode
+        # Channel gaps (bf16 storage of a concat whose first part is not a multiple of 8 channels wide: xresnet34_deep).  The tensors carry
+        # `gap` dead channels at [at, at + gap) of the input and / or output dimension; the kernels see filters / a bias with zeros there.
+        self.in_gap: Optional[Tuple[int, int]] = None      # (at, gap)
+        self.out_gap: Optional[Tuple[int, int]] = None
+        self._wpad = self._bpad = self._gwpad = self._gbpad = None
+        self._ver_pad = None
+
+    def set_gaps(self, in_gap=None, out_gap=None):
+        self.in_gap = in_gap if in_gap and in_gap[1] else None
+        self.out_gap = out_gap if out_gap and out_gap[1] else None
+        self._wpad = None
+
+    @property
+    def gapped(self) -> bool:
+        return self.in_gap is not None or self.out_gap is not None
+
+    @staticmethod
+    def _segs(n, gap):
+        """[(logical slice, physical slice)] of a dimension of n logical channels"""
+        if gap is None:
+            return [(slice(0, n), slice(0, n))], n
+        at, g = gap
+        return [(slice(0, at), slice(0, at)), (slice(at, n), slice(at + g, n + g))], n + g
+
+    def wsrc(self) -> torch.Tensor:
+        """the filter the kernels pack: the parameter itself, or its copy with zero rows / columns for the gap channels"""
+        w = self.conv.weight.data
+        if not self.gapped:
+            return w
+        Cout, Cin = w.shape[:2]
+        si, ci = self._segs(Cin, self.in_gap)
+        so, co = self._segs(Cout, self.out_gap)
+        if self._wpad is None:
+            self._wpad = torch.zeros((co, ci) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            self._gwpad = torch.zeros_like(self._wpad)
+            if self.conv.bias is not None:
+                self._bpad = torch.zeros(co, dtype=w.dtype, device=w.device)
+                self._gbpad = torch.zeros_like(self._bpad)
+            self._ver_pad = None
+        ver = (self.conv.weight._version, w.data_ptr(), 0 if self.ctx is None else self.ctx.weights_epoch)
+        if self._ver_pad != ver:
+            for lo, po in so:
+                for li, pi in si:
+                    self._wpad[po, pi].copy_(w[lo, li])
+                if self._bpad is not None:
+                    self._bpad[po].copy_(self.conv.bias.data[lo])
+            self._ver_pad = ver
+        return self._wpad
+
+    def bsrc(self) -> Optional[torch.Tensor]:
+        b = self.conv.bias
+        if b is None:
+            return None
+        if not self.gapped:
+            return b.data
+        self.wsrc()
+        return self._bpad
 
     def fold_scale(self) -> Optional[torch.Tensor]:
         """per-output-channel factor of the forward image: the eval-mode BatchNorm scale when this forward folds it, else None"""
@@ -170,12 +227,12 @@ class _ConvExec:
         if mode == 0:
             if self.wp_f is None or self._ver_f != ver:
                 self.ensure_buffers(False)
-                ops.pack_jobs([(self.conv.weight.data, self.wp_f, 0, self.fold_scale())], self.wp_f.dtype == torch.bfloat16, self.wp_f.device)
+                ops.pack_jobs([(self.wsrc(), self.wp_f, 0, self.fold_scale())], self.wp_f.dtype == torch.bfloat16, self.wp_f.device)
                 self._ver_f = ver
             return self.wp_f
         if self.wp_d is None or self._ver_d != ver:
             self.ensure_buffers(True)
-            ops.pack_jobs([(self.conv.weight.data, self.wp_d, 1, None)], self.wp_d.dtype == torch.bfloat16, self.wp_d.device)
+            ops.pack_jobs([(self.wsrc(), self.wp_d, 1, None)], self.wp_d.dtype == torch.bfloat16, self.wp_d.device)
             self._ver_d = ver
         return self.wp_d
 
@@ -188,7 +245,7 @@ class _ConvExec:
     def ensure_buffers(self, with_dgrad: bool):
         """the persistent packed-image buffers (HipDynamicUnet packs all of them in one launch: unet_pack_batch_run)"""
         dt = torch.float32 if self.ctx is None else self.ctx.act_dtype
-        w = self.conv.weight
+        w = self.wsrc() if self.gapped else self.conv.weight
         Cout, Cin, ks, _ = w.shape
         size = ops.lib.unet_pack_weights_size_bf16 if dt == torch.bfloat16 else ops.lib.unet_pack_weights_size
         if self.wp_f is None or self.wp_f.dtype != dt:
@@ -202,8 +259,7 @@ class _ConvExec:
         return ops.conv_out_hw(H, W, self.ks, self.stride)
 
     def fwd(self, x: TS, y: TS, relu=False, res: Optional[TS] = None):
-        b = self.conv.bias
-        ops.conv2d(x, self.packed(0), y, self.ks, self.stride, bias=None if b is None else b.data, res=res, relu=relu)
+        ops.conv2d(x, self.packed(0), y, self.ks, self.stride, bias=self.bsrc(), res=res, relu=relu)
 
     def fwd_stats(self, ctx: Ctx, x: TS, y: TS):
         """conv whose epilogue also emits the per-wave partial column sums / sums of squares of y: the BatchNorm statistics of
@@ -220,6 +276,17 @@ class _ConvExec:
         """weight (+bias) gradient into the .grad views of the flat gradient buffer"""
         w, b = self.conv.weight, self.conv.bias
         n = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)
+        if self.gapped:          # gradient of the gapped filter, then its live rows / columns into the parameter's .grad
+            self.wsrc()
+            ops.conv2d_wgrad(x, dy, self._gwpad, self.ks, self.stride, ctx.workspace(n), dbias=None if b is None else self._gbpad)
+            si, _ = self._segs(w.shape[1], self.in_gap)
+            so, _ = self._segs(w.shape[0], self.out_gap)
+            for lo, po in so:
+                for li, pi in si:
+                    w.grad[lo, li].copy_(self._gwpad[po, pi])
+                if b is not None:
+                    b.grad[lo].copy_(self._gbpad[po])
+            return
         ops.conv2d_wgrad(x, dy, w.grad, self.ks, self.stride, ctx.workspace(n), dbias=None if b is None else b.grad)
 
     def bwd_x(self, dy: TS, dx: TS, res: Optional[TS] = None, mask: Optional[TS] = None):
@@ -782,17 +849,25 @@ class UnetBlock(nn.Module):
         self.relu = nn.ReLU()
         _kaiming_init(self.conv1, self.conv2[0])
         self.cu, self.cs, self.ni, self.out_channels = up_in_c // 2, x_in_c, ni, nf
+        self.cu_off, self.ni_p = self.cu, ni       # physical offset of the skip slice / width of the concat buffer (set_gap: bf16 storage)
         self.bx = _BNExec(self.bn)
         self.__dict__["sa"] = self.conv2[2] if self_attention else None
         # is the tensor this block up-samples a ReLU output (then the ReLU backward is fused as a dgrad mask)?  Not when the
         # previous block ends in self-attention.
         self.up_is_relu = up_is_relu
 
+    def set_gap(self, vec: int):
+        """concat buffer [up (cu) | gap | skip (cs)] with the skip slice at a multiple of `vec` channels; conv1 reads it with zero filters
+        for the gap channels (the up slice owns them as its padding: the shuffle kernel writes zeros there)"""
+        self.cu_off = (self.cu + vec - 1) // vec * vec
+        self.ni_p = self.cu_off + self.cs
+        self.conv1.cx.set_gaps(in_gap=(self.cu, self.cu_off - self.cu))
+
     def hip_fwd(self, ctx: Ctx, up_in: TS, s: TS) -> TS:
-        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
+        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni_p, zero=self.ni_p != self.ni)
         self.shuf.hip_fwd(ctx, up_in, X.sub(0, self.cu), (s.H, s.W))
         scale, shift = self.bx.coeffs(ctx, s)
-        ops.affine_act(s, X.sub(self.cu, self.cs), scale, shift, relu=True)
+        ops.affine_act(s, X.sub(self.cu_off, self.cs), scale, shift, relu=True)
         ctx.saved[(id(self), "s")] = s
         t1 = _bias_relu_layer_fwd(ctx, self.conv1, X)
         t2 = _bias_relu_layer_fwd(ctx, self.conv2, t1)
@@ -803,7 +878,7 @@ class UnetBlock(nn.Module):
         gradient w.r.t. the block output).  Writes dL/d(skip) into dskip and returns the gradient for the producer of up_in
         (masked by its ReLU when up_is_relu)."""
         s: TS = ctx.saved[(id(self), "s")]
-        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni)
+        X = ctx.act(self, "cat", s.N, s.H, s.W, self.ni_p)
         t1: TS = ctx.saved[(id(self.conv2), "x")]
         own = None
         if self.sa is not None:
@@ -817,7 +892,7 @@ class UnetBlock(nn.Module):
         dX = self.conv1.bwd_from_dy(ctx, dt1, mask=X)          # relu(cat) backward fused
         ctx.free(dt1)
         assert not dskip_accumulate
-        self.bx.bwd(ctx, dX.sub(self.cu, self.cs), None, s, dskip)
+        self.bx.bwd(ctx, dX.sub(self.cu_off, self.cs), None, s, dskip)
         d = self.shuf.hip_bwd(ctx, dX.sub(0, self.cu), mask_input=self.up_is_relu)
         ctx.free(dX)
         return d
