@@ -148,10 +148,10 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # fp32: conv_igemm16_kernel<32,2,2,2,2,4> (all wide 3x3 / 1x1 convs, fwd and dgrad); bf16: conv_bf16_t256_kernel (the 256-pixel tile of the wide 3x3 layers)
+    # both storage types: conv_bf16_t256_kernel (the 256-pixel tile of the wide 3x3 layers; variant ...7 = its large-layer launches), in its float or bf16 form
     pr = None
     if probe:
-        _ops.CONV_PROBE = pr = _ops.ConvProbe(32 * 10000 + 128 * 10 + (0 if dtype == "f32" else 7))
+        _ops.CONV_PROBE = pr = _ops.ConvProbe(32 * 10000 + 128 * 10 + 7)
     step.comm_events = [] if world > 1 else None
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -192,11 +192,11 @@ def roofline_of(ps, dtype, dt, steps, pmc):
               "share_of_step_time": round(ps["total_ms"] / (dt * 1e3), 4)}
     if dtype == "f32":
         achieved = ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "conv_igemm16_kernel<32,2,2,2,2,4> (fp32 v_mfma_16x16x4 implicit GEMM: every wide 3x3/1x1 "
-                                           "conv, forward and input-gradient; rocprofv3 lists its two instantiations <...,false> and "
-                                           "<...,true> = the launches whose last 4 of 100 output channels run on v_mfma_4x4x1)",
+        return {"bound": "mfma", "kernel": "conv_bf16_t256_kernel<NTOT, 32, float> (the fp32 form of the 256-pixel x 128-channel implicit-GEMM tile, "
+                                           "v_mfma_f32_16x16x4_f32: every wide 3x3 conv of the step, forward and input-gradient, incl. the 100-channel "
+                                           "layers -- 7 channel tiles, transposed reduction tail; rocprofv3 lists its instantiations <6..8, 32, float>)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
-                "traffic": traffic_of("conv_igemm16_kernel<32,2,2,2,2,4>"), **common}
+                "traffic": traffic_of("conv_bf16_t256_kernel<float>"), **common}
     achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "conv_bf16_t256_kernel (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM, 256-pixel x 128-channel tile: "
                                       "every wide 3x3 conv, forward and input-gradient; rocprofv3 lists its instantiations <6>, <7>, <8> = "

@@ -7,7 +7,10 @@ from unet_amd.ops import TS
 
 N = 16
 g = torch.Generator(device="cuda").manual_seed(0)
-for H, Cin, Cout in [(512, 100, 100), (512, 100, 96), (256, 192, 96), (256, 96, 96), (128, 256, 256), (64, 384, 384)]:
+import unet_amd._lib as L
+SW = int(sys.argv[1]) if len(sys.argv) > 1 else -2          # -2: the fp32 256-pixel tile on (default), -1: off
+L.lib.unet_set_mfma_shape(SW)
+for H, Cin, Cout in [(512, 96, 96), (256, 192, 96), (256, 96, 96), (256, 96, 128), (128, 256, 256), (128, 64, 64), (64, 384, 384), (64, 128, 128), (32, 512, 512), (32, 256, 256), (16, 512, 512)]:
     x = TS(torch.randn((N, H, H, ops.rup4(Cin)), device="cuda", generator=g), 0, Cin)
     y = TS(torch.empty((N, H, H, ops.rup4(Cout)), device="cuda"), 0, Cout)
     w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) / (Cin * 9) ** 0.5
@@ -25,4 +28,4 @@ for H, Cin, Cout in [(512, 100, 100), (512, 100, 96), (256, 192, 96), (256, 96, 
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 5)
     fl = 2.0 * N * H * H * Cin * Cout * 9
-    print(f"{H:4d}^2 {Cin:4d}->{Cout:4d}  {min(ts):7.3f} ms  {fl / min(ts) / 1e9:6.1f} TF", flush=True)
+    print(f"[{SW}] {H:4d}^2 {Cin:4d}->{Cout:4d}  {min(ts):7.3f} ms  {fl / min(ts) / 1e9:6.1f} TF  variant {ops.conv2d_variant(x, wp, y, 3, 1)}", flush=True)

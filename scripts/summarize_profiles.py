@@ -29,10 +29,11 @@ def keyed(name: str, grid_threads: int) -> str:
     """conv_bf16_t256_kernel serves the large layers (>= 512 workgroups: the launches bench.py's roofline follows, variant ...7) and, since the
     second half of round 3, narrow-block / small-grid launches (variant ...6): two rows, split by grid size"""
     k = short(name)
-    if k == "conv_bf16_t256_kernel":
-        m = re.search(r"conv_bf16_t256_kernel<\s*(\d+),\s*(\d+)>", name)
-        large = m is not None and int(m.group(1)) >= 5 and int(m.group(2)) == 32 and grid_threads >= 512 * 256
-        return k if large else "conv_bf16_t256_kernel[narrow / small]"
+    m = re.search(r"conv_bf16_t256_kernel<\s*(\d+),\s*(\d+)(?:,\s*([A-Za-z ]+))?>", name)
+    if m is not None:
+        base = "conv_bf16_t256_kernel<float>" if (m.group(3) and "float" in m.group(3)) else "conv_bf16_t256_kernel"     # (the fp32 form of the same template)
+        large = int(m.group(1)) >= 5 and int(m.group(2)) == 32 and grid_threads >= 512 * 256
+        return base if large else base + "[narrow / small]"
     return k
 
 

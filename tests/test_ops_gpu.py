@@ -101,6 +101,15 @@ def test_conv_sliver_last_channels_on_mfma4x4(ops, Cin, Cout):
     filters from the sliver image behind the packed one).  Forward with bias + residual + ReLU into a channel slice, ragged pixel
     tiles; then the input-gradient form (residual + ReLU mask) of a conv whose INPUT width is such a count."""
     N, H, W = 2, 150, 170                      # 400+ blocks of 128 pixels: the planner keeps the 128 x 128 tile
+    from unet_amd._lib import lib
+    lib.unet_set_mfma_shape(-1)                # (large grids now run the fp32 form of the 256-pixel kernel, 7 channel tiles for 100 outputs: this
+    try:                                       # test is about the sliver instantiation that smaller grids keep using)
+        _sliver_case(ops, Cin, Cout, N, H, W)
+    finally:
+        lib.unet_set_mfma_shape(-2)
+
+
+def _sliver_case(ops, Cin, Cout, N, H, W):
     g = torch.Generator().manual_seed(Cin * 1000 + Cout)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
@@ -271,6 +280,60 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
     ops.conv2d_dgrad(to_ts(dy), ops.pack_weights(wf.cuda(), 1), dxt, 1, 1, res=to_ts(r), mask=to_ts(act))
     torch.cuda.synchronize()
     assert_close(from_ts(dxt), ref, rtol=1e-5, what="small-K dgrad")
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (Cin, Cout, H, W, N): the 256-pixel tile in its fp32 form (conv_bf16_t256_kernel<.., float>): no reduction tail, no 4-channel sliver
+    (96, 96, 250, 270, 2),      # 6 channel tiles, ragged image edges
+    (32, 128, 256, 256, 2),     # 8 tiles, two chunks
+    (64, 72, 128, 128, 4),      # 5 tiles (shared third tile)
+    (128, 232, 64, 64, 16),     # two launches: a full block + a narrow one of 7 tiles (232 = 128 + 104)
+    (256, 128, 64, 64, 16),     # a deep stage at the fp32 threshold (256 blocks of 256 pixels)
+    (64, 64, 64, 64, 16),       # 64-wide channel block
+    (48, 32, 64, 64, 16),       # 32-wide block
+    (64, 128, 32, 24, 64),      # 16 x 16 pixel patches (outputs 16..31 pixels wide), ragged second patch column
+    (100, 100, 256, 256, 2),    # reduction tail of 4 channels (transposed chunk, one of four MFMA steps) and 7 channel tiles for 100 outputs
+    (40, 112, 128, 128, 4),     # tail of 8 channels (two steps)
+    (13, 96, 128, 128, 4),      # the tail is the only chunk
+])
+def test_conv_f32_t256_kernel(ops, case):
+    """forward with bias + residual + ReLU into a channel slice and the input gradient with residual + mask on the fp32 form of the 256-pixel
+    kernel (variant ...7 / ...6), against torch on the CPU and against the generic kernel (unet_set_mfma_shape(-1)) on the same operands"""
+    from unet_amd._lib import lib
+    Cin, Cout, H, W, N = case
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, padding=1) + r)
+    xt, rt = to_ts(x, cs=ops.rup4(Cin) + 8, co=4), to_ts(r, cs=ops.rup4(Cout) + 4, co=4)
+    wp = ops.pack_weights(w.cuda(), 0)
+    outs = []
+    for sw in (-2, -1):
+        lib.unet_set_mfma_shape(sw)
+        try:
+            yt = empty_ts(N, H, W, Cout, cs=ops.rup4(Cout) + 12, co=8)
+            if sw == -2:
+                assert ops.conv2d_variant(xt, wp, yt, 3, 1) % 10 in (6, 7)
+            ops.conv2d(xt, wp, yt, 3, 1, bias=b.cuda(), res=rt, relu=True)
+            torch.cuda.synchronize()
+            assert outside_untouched(yt)
+            outs.append(from_ts(yt))
+        finally:
+            lib.unet_set_mfma_shape(-2)
+    assert_close(outs[0], ref, rtol=2e-4, what="t256 f32 fwd")
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * ref.abs().max().item()          # same k-ordered chains, possibly another MFMA-internal order
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    act = F.relu(torch.randn(N, Cin, H, W, generator=g))
+    extra = torch.randn(N, Cin, H, W, generator=g)
+    if True:
+        dref = (torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, padding=1) + extra) * (act > 0)
+        dxt = empty_ts(N, H, W, Cin)
+        wpd = ops.pack_weights(w.cuda(), 1)
+        ops.conv2d_dgrad(to_ts(dy), wpd, dxt, 3, 1, res=to_ts(extra), mask=to_ts(act))
+        torch.cuda.synchronize()
+        assert_close(from_ts(dxt), dref, rtol=2e-4, what="t256 f32 dgrad")
 
 
 WGRAD_CASES = [

@@ -365,9 +365,16 @@ __device__ unsigned long long* g_stamps = nullptr;
 // A workgroup walks `tpw` consecutive output tiles: the first halo tile and filter tiles of tile i + 1 are requested BEFORE the epilogue
 // of tile i, so the HBM latency of a tile's prologue (14 % of a one-tile workgroup's life in the stamps) hides behind the stores.
 // TW = 32 (an 8 x 32 pixel patch) or 16 (16 x 16: the stages whose output is 16..31 pixels wide).
-template <int NTOT, int TW>
-__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32, const int tpw, const int bn) {
+// T = unsigned short (bf16 storage: a chunk is 32 channels, one v_mfma_f32_16x16x32_bf16 per tile pair and stage) or float (the fp32 parity
+// path, same bytes everywhere: a chunk is 16 channels = 64 bytes per pixel, the filter tile 16 columns x 64 B, four v_mfma_f32_16x16x4_f32 per
+// tile pair and stage with the operand roles of the bf16 form -- A = filter, B = pixels -- so that a lane again holds four consecutive
+// channels of one pixel and results move as 16-byte vectors; no reduction tail, no 4-channel sliver: the planner keeps those launches on
+// conv_igemm16_kernel).
+template <int NTOT, int TW, typename T>
+__global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32_arg, const int tpw, const int bn) {
     constexpr int TH = 256 / TW, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
+    constexpr int EB = (int)sizeof(T), VEC = 16 / EB, KCT = 64 / EB;       // bytes per element, channels per 16-byte item / per chunk
+    const int y_f32 = EB == 4 ? 1 : y_f32_arg;
     constexpr int T256_HW = TW + 2, T256_HPIX = (TH + 2) * T256_HW, T256_BUFB = T256_HPIX * T256_ROWB;
     static_assert((TW == 32 || TW == 16) && T256_HPIX * 4 <= HIT * NTH, "pixel patch of the 256-pixel tile");
     constexpr int NF = NTOT / 2, NL = NF + (NTOT & 1);            // full tiles per wave, filter tiles a wave loads per stage
@@ -397,7 +404,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const int kc1 = a.cps ? (kc0 + a.cps < a.nchunks ? kc0 + a.cps : a.nchunks) : a.nchunks;
     const int rev = a.sliver;                                  // taps in LDS order: the input gradient reads the filter slabs backwards
     const int fold = a.fold, last = a.nchunks - 1;
-    const int kend = fold ? last : kc1;                        // chunks [kc0, kend) run nine plain stages; a folded tail chunk three
+    // fp32: a reduction tail (Cin % 16 != 0: the 100-channel layers) is the last chunk, stored CHANNEL-TRANSPOSED in the filter image and in LDS
+    // (k-slot (kq, kk) = channel 4 kk + kq) so that MFMA step kk covers channels 4 kk .. 4 kk + 3 and the steps beyond the real channels are
+    // skipped (as in conv_igemm16_kernel); it runs in a section of its own behind the full chunks
+    const bool ftail = EB == 4 && (a.Cin & 15) != 0 && kc1 == a.nchunks;
+    const int kend = (fold || ftail) ? last : kc1;             // chunks [kc0, kend) run nine plain stages; a folded tail chunk three
     const bool first_fold = fold && kc0 == last;
 
     // ---- per-tile state: output origin, channel block, filter slabs, halo items ----
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     const char *wbase, *w0, *wfold;
     v4i rs;
     unsigned goff[HIT];
-    const size_t slab_b = (size_t)a.coutPad * KCB * 2;
+    const size_t slab_b = (size_t)a.coutPad * KCT * EB;
     const long long tap_step = (rev ? -1ll : 1ll) * (long long)a.nchunks * (long long)slab_b;
 #define T256_SETUP(tile_) do { \
         int id_ = (tile_); \
@@ -416,12 +427,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         const int ty_ = __builtin_amdgcn_readfirstlane(id_ % a.tiles_y); \
         img = __builtin_amdgcn_readfirstlane(id_ / a.tiles_y); \
         oy0 = ty_ * TH; ox0 = tx_ * TW; n0 = a.n_base + nt_ * bn; \
-        wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCB) * 2)); \
+        wbase = reinterpret_cast<const char*>(sgpr_ptr(reinterpret_cast<const char*>(a.wp) + ((size_t)img * a.wp_stride + (size_t)n0 * KCT) * EB)); \
         w0 = wbase + (rev ? 8ll * a.nchunks * (long long)slab_b : 0ll);       /* slab of LDS tap 0, chunk 0 */ \
         wfold = wbase + (size_t)9 * a.nchunks * slab_b; \
-        const u64 xb_ = sgpr_ptr(reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * 2); \
+        const u64 xb_ = sgpr_ptr(reinterpret_cast<const char*>(a.x) + (size_t)img * a.IH * a.IW * a.x_cs * EB); \
         rs[0] = (int)(unsigned)xb_; rs[1] = (int)(unsigned)(xb_ >> 32); \
-        rs[2] = __builtin_amdgcn_readfirstlane(a.IH * a.IW * a.x_cs * 2); rs[3] = 0x00020000; \
+        rs[2] = __builtin_amdgcn_readfirstlane(a.IH * a.IW * a.x_cs * EB); rs[3] = 0x00020000; \
         const int iy0_ = oy0 + ts.min_dy, ix0_ = ox0 + ts.min_dx; \
         _Pragma("unroll") for (int it = 0; it < HIT; ++it) { \
             const int e = tid + it * NTH; \
@@ -429,22 +440,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
             const int hy = p / T256_HW, hx = p - hy * T256_HW; \
             const int iy = iy0_ + hy, ix = ix0_ + hx; \
             const bool inb = (e < T256_HPIX * 4) && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; \
-            goff[it] = inb ? (unsigned)((iy * a.IW + ix) * a.x_cs + a.x_co + 8 * q) * 2u : OOB; \
+            goff[it] = inb ? (unsigned)((iy * a.IW + ix) * a.x_cs + a.x_co + VEC * q) * (unsigned)EB : OOB; \
         } } while (0)
     // channels of the tail chunk beyond the (8-padded) input width belong to a neighbouring slice: this thread's channel group (tid & 3)
-    const bool tail_cut = last * KCB + 8 * (tid & 3) >= a.Cin4;
+    const bool tail_cut = last * KCT + VEC * (tid & 3) >= a.Cin4;
     v4f hreg[HIT];
 #pragma unroll
     for (int it = 0; it < HIT; ++it) hreg[it] = (v4f){0.f, 0.f, 0.f, 0.f};
 #define T256_LOAD_HALO(chunk_, on_) do { unsigned vo_[HIT]; const bool cut_ = !(on_) || (tail_cut && (chunk_) == last); \
         _Pragma("unroll") for (int it = 0; it < HIT; ++it) vo_[it] = cut_ ? OOB : goff[it]; \
-        gld_halo6_buf(hreg, vo_, rs, (on_) ? (chunk_) * (KCB * 2) : 0); } while (0)
+        gld_halo6_buf(hreg, vo_, rs, (on_) ? (chunk_) * 64 : 0); } while (0)
     const unsigned vst = (unsigned)((tid >> 2) * T256_ROWB + (tid & 3) * 16);
     const bool st5 = tid + 5 * NTH < T256_HPIX * 4;
 #define T256_STORE_HALO(buf_) do { char* d_ = lds + (buf_) * T256_BUFB + vst; \
         _Pragma("unroll") for (int it = 0; it < HIT; ++it) \
             if (it < 5 || st5) *reinterpret_cast<v4f*>(d_ + it * (NTH / 4) * T256_ROWB) = hreg[it]; } while (0)
 
+#define T256_STORE_HALO_T(buf_) do { char* d_ = lds + (buf_) * T256_BUFB + (tid >> 2) * T256_ROWB + (tid & 3) * 4; \
+        _Pragma("unroll") for (int it = 0; it < HIT; ++it) \
+            if (it < 5 || st5) { float* r_ = reinterpret_cast<float*>(d_ + it * (NTH / 4) * T256_ROWB); \
+                r_[0] = hreg[it][0]; r_[4] = hreg[it][1]; r_[8] = hreg[it][2]; r_[12] = hreg[it][3]; } } while (0)
     // ---- channel tiles of this wave ----
     const int r = (NTOT & 1) ? wn : 0;                  // pixel-tile halves swapped (accumulator half h holds pixel tiles 4 (h ^ r) ..)
 #define TILE_COL(n_) (((n_) == NF ? (n_) * 2 : (n_) * 2 + wn) * 16)
@@ -479,15 +494,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
     // of the SIMD already covers the LDS round trip.)
 #define T256_MFMA(bu_, addr_) do { \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
-            bf16x8 pv_[MH]; \
+            v4f pv_[MH]; \
             const unsigned ah_ = (addr_) + (h == 0 ? hsw : HALF_B - hsw); \
             _Pragma("unroll") for (int m = 0; m < MH; ++m) \
-                pv_[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f*>(lds + ah_ + MOFF(m))); \
+                pv_[m] = *reinterpret_cast<const v4f*>(lds + ah_ + MOFF(m)); \
             _Pragma("unroll") for (int n = 0; n < NL; ++n) { \
                 if (n < NF || h == 0) { \
-                    const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
-                    _Pragma("unroll") for (int m = 0; m < MH; ++m) \
-                        acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, pv_[m], acc[h * MH + m][n], 0, 0, 0); \
+                    if constexpr (EB == 2) { \
+                        const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
+                        _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                            acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, __builtin_bit_cast(bf16x8, pv_[m]), acc[h * MH + m][n], 0, 0, 0); \
+                    } else { \
+                        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) \
+                            _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                                acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
+                    } \
                 } \
             } \
         } } while (0)
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         // (caught by unet_amd/isa_check.py)
         wait_cnt<0, true>(b0, hreg);
         __syncthreads();                    // (every wave has left the LDS buffers of the previous tile)
-        T256_STORE_HALO(kc0 & 1);
+        if (ftail && kc0 == last) T256_STORE_HALO_T(kc0 & 1); else T256_STORE_HALO(kc0 & 1);
         __syncthreads();
 #ifdef UNET_STAMPS
         const unsigned long long sl0_ = STAMP();
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         unsigned vcur = vbase + (unsigned)((kc0 & 1) * T256_BUFB);
         for (int chunk = kc0; chunk < kend; ++chunk) {
             const bool more = chunk + 1 < kend;
-            const bool next_any = more || fold;              // another halo tile is needed
+            const bool next_any = more || fold || ftail;     // another halo tile is needed
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
 #ifdef UNET_STAMPS
@@ -522,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #endif
                 // the NEXT stage's filter tiles (after the last stage: a dummy fetch of the first slab keeps the load / wait pattern fixed)
                 if (t < 8) wcur += tap_step;
-                else wcur = more ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
+                else wcur = (more || ftail) ? w0 + (size_t)(chunk + 1) * slab_b : (fold ? wfold : wbase);
                 if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wcur); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wcur);
                 if (t == 0) T256_LOAD_HALO(chunk + 1, next_any);        // (nothing follows: out-of-range offsets, the load count stays the same)
                 // The wait for the next stage's filter tiles (sched_barrier: it names only the registers being loaded, nothing else keeps
@@ -537,9 +558,39 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #pragma unroll
             for (int n = 0; n < N16; ++n) b0[n] = b1[n];
             if (next_any) {
-                T256_STORE_HALO((chunk + 1) & 1);
+                if (ftail && !more) T256_STORE_HALO_T((chunk + 1) & 1); else T256_STORE_HALO((chunk + 1) & 1);
                 STAMP_BAR(__syncthreads());
                 vcur = vbase + (unsigned)(((chunk + 1) & 1) * T256_BUFB);
+            }
+        }
+        if constexpr (EB == 4) {
+            if (ftail) {        // nine stages over the transposed tail chunk, `ks` of the four MFMA steps each; b0 holds its first filter tiles
+                const int ks = ((a.Cin - last * KCT) + 3) >> 2;
+                const char* wt = w0 + (size_t)last * slab_b;
+#define T256_MFMA_T(bu_, addr_) do { \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
+            v4f pv_[MH]; \
+            const unsigned ah_ = (addr_) + (h == 0 ? hsw : HALF_B - hsw); \
+            _Pragma("unroll") for (int m = 0; m < MH; ++m) pv_[m] = *reinterpret_cast<const v4f*>(lds + ah_ + MOFF(m)); \
+            _Pragma("unroll") for (int n = 0; n < NL; ++n) { \
+                if (n < NF || h == 0) { \
+                    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
+                        if (kk < ks) { \
+                            _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                                acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
+                        } \
+                    } \
+                } \
+            } \
+        } } while (0)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    wt = t < 8 ? wt + tap_step : wbase;          // (after the last stage: a dummy fetch, as in the main loop)
+                    if (t & 1) gld_bn<NL, NTOT & 1>(b0, voff, voff2, voffs, wt); else gld_bn<NL, NTOT & 1>(b1, voff, voff2, voffs, wt);
+                    if (t & 1) { T256_MFMA_T(b1, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); wait_cnt<0, false>(b0, hreg); }
+                    else { T256_MFMA_T(b0, vcur + TOFF(t)); __builtin_amdgcn_sched_barrier(0); wait_cnt<0, false>(b1, hreg); }
+                }
+#undef T256_MFMA_T
             }
         }
         if (fold) {
@@ -577,8 +628,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         //      residual and the mask are fetched in that form and swapped back.  Half as many memory instructions, each 16 bytes a lane.
         const bool relu = a.flags & UNET_CONV_RELU;
         const size_t img_pix = (size_t)imgc * a.OH * a.OW;
-        const u16* resb = a.res ? reinterpret_cast<const u16*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
-        const u16* maskb = a.mask ? reinterpret_cast<const u16*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+        const T* resb = a.res ? reinterpret_cast<const T*>(a.res) + img_pix * a.res_cs + a.res_co : nullptr;
+        const T* maskb = a.mask ? reinterpret_cast<const T*>(a.mask) + img_pix * a.mask_cs + a.mask_co : nullptr;
+        auto ld4 = [](const T* p_) -> f32x4 { if constexpr (EB == 2) return ld_bf16x4(p_); else return *reinterpret_cast<const f32x4*>(p_); };
         auto unpack = [](unsigned lo, unsigned hi) -> f32x4 {
             return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
         };
@@ -610,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                     for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bv;
                     if (resb != nullptr) {
 #pragma unroll
-                        for (int m = 0; m < MH; ++m) v[m] += ld_bf16x4(resb + (size_t)pidx[m] * a.res_cs + cc);
+                        for (int m = 0; m < MH; ++m) v[m] += ld4(resb + (size_t)pidx[m] * a.res_cs + cc);
                     }
                     if (relu) {
 #pragma unroll
@@ -621,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                     if (maskb != nullptr) {
 #pragma unroll
                         for (int m = 0; m < MH; ++m) {
-                            const f32x4 mv = ld_bf16x4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+                            const f32x4 mv = ld4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[m][q] = mv[q] > 0.f ? v[m][q] : 0.f;
                         }
@@ -632,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                         if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
                 }
             }
-        } else {
+        } else if constexpr (EB == 2) {
             // the bias of this wave's channel tiles, fetched once and first: a load between two result stores would make the compiler wait for
             // the older store as well (one in-order counter) -- that wait, per channel tile, was most of the epilogue
             f32x4 bvn[NL];
@@ -733,6 +785,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #undef T256_MFMA
 #undef T256_LOAD_HALO
 #undef T256_STORE_HALO
+#undef T256_STORE_HALO_T
 #undef T256_SETUP
 #undef MOFF
 #undef TOFF
@@ -757,9 +810,9 @@ extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
 
 int g_t256_tpw = 0;        // tiles per workgroup of conv_bf16_t256_kernel (0: chosen per launch; unet_set_bf16_big_tile(100 + n) forces n)
 
-template <int NTOT, int TW>
+template <int NTOT, int TW, typename T>
 int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
-    auto kern = conv_bf16_t256_kernel<NTOT, TW>;
+    auto kern = conv_bf16_t256_kernel<NTOT, TW, T>;
     static unsigned long long configured = 0;
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -776,31 +829,32 @@ int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
 
 // the channel-tile count of a block is a template parameter: a launch whose last channel block is narrower than the others (Cout = 228 in
 // 128-wide blocks: 8 + 7 tiles) is issued as two launches over disjoint channel ranges
+template <typename T>
 int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
     const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn, full = p.bn / 16;
     const int last_tiles = (cols - (nblk - 1) * p.bn + 15) / 16;
     auto one = [&](const Plan& q, int tiles) {
         if (q.tw == 32) {
             switch (tiles) {
-                case 8: return launch_t256n<8, 32>(q, y_f32, st);
-                case 7: return launch_t256n<7, 32>(q, y_f32, st);
-                case 6: return launch_t256n<6, 32>(q, y_f32, st);
-                case 5: return launch_t256n<5, 32>(q, y_f32, st);
-                case 4: return launch_t256n<4, 32>(q, y_f32, st);
-                case 3: return launch_t256n<3, 32>(q, y_f32, st);
-                case 2: return launch_t256n<2, 32>(q, y_f32, st);
-                case 1: return launch_t256n<1, 32>(q, y_f32, st);
+                case 8: return launch_t256n<8, 32, T>(q, y_f32, st);
+                case 7: return launch_t256n<7, 32, T>(q, y_f32, st);
+                case 6: return launch_t256n<6, 32, T>(q, y_f32, st);
+                case 5: return launch_t256n<5, 32, T>(q, y_f32, st);
+                case 4: return launch_t256n<4, 32, T>(q, y_f32, st);
+                case 3: return launch_t256n<3, 32, T>(q, y_f32, st);
+                case 2: return launch_t256n<2, 32, T>(q, y_f32, st);
+                case 1: return launch_t256n<1, 32, T>(q, y_f32, st);
             }
         } else if (q.tw == 16) {
             switch (tiles) {
-                case 8: return launch_t256n<8, 16>(q, y_f32, st);
-                case 7: return launch_t256n<7, 16>(q, y_f32, st);
-                case 6: return launch_t256n<6, 16>(q, y_f32, st);
-                case 5: return launch_t256n<5, 16>(q, y_f32, st);
-                case 4: return launch_t256n<4, 16>(q, y_f32, st);
-                case 3: return launch_t256n<3, 16>(q, y_f32, st);
-                case 2: return launch_t256n<2, 16>(q, y_f32, st);
-                case 1: return launch_t256n<1, 16>(q, y_f32, st);
+                case 8: return launch_t256n<8, 16, T>(q, y_f32, st);
+                case 7: return launch_t256n<7, 16, T>(q, y_f32, st);
+                case 6: return launch_t256n<6, 16, T>(q, y_f32, st);
+                case 5: return launch_t256n<5, 16, T>(q, y_f32, st);
+                case 4: return launch_t256n<4, 16, T>(q, y_f32, st);
+                case 3: return launch_t256n<3, 16, T>(q, y_f32, st);
+                case 2: return launch_t256n<2, 16, T>(q, y_f32, st);
+                case 1: return launch_t256n<1, 16, T>(q, y_f32, st);
             }
         }
         unet::set_error("conv bf16: %d channel tiles / tile width %d in the 256-pixel tile", tiles, q.tw);
@@ -917,10 +971,18 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return conv_smallk_bf16(d, st);
     const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
-    if (p.hit == 6) rc = launch_t256(p, y_f32, st);
+    if (p.hit == 6) rc = launch_t256<unsigned short>(p, y_f32, st);
     else rc = (p.hit == 10) ? launch_tw<10>(p, y_f32, st) : launch_tw<4>(p, y_f32, st);
     if (rc != UNET_OK || p.splits <= 1) return rc;
     return splitk_reduce(d, p, st);
+}
+
+// the fp32 launches the planner put on the 256-pixel tile (conv_igemm.hip: unet_conv2d)
+int conv2d_t256_f32(const Plan& p0, hipStream_t st) {
+    Plan p = p0;
+    p.k.sliver = p.k.taps[0].dy[0] > 0 ? 1 : 0;        // (this kernel reads the field as: the taps of the input gradient, filter slabs backwards)
+    p.k.fold = 0;
+    return launch_t256<float>(p, 1, st);
 }
 
 int conv2d_bf16_variant(const unet_conv_desc* d) {

@@ -388,8 +388,11 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // bf16: the 256-pixel x 128-channel tile (conv_bf16_t256_kernel) for 3x3 / stride-1 launches from 64 blocks up -- on the deep 32 x 32
     // stages (a quarter of the chip's workgroup slots) it still beats the generic 128- / 64-pixel tiles by 1.2-1.7x, 512 -> 512: 109 -> 65 us,
     // with or without a split reduction on top (scripts/conv_mid_ab.py).  big_tile == 2: the order of round 3's first half (shrink first).
-    const bool big_ok = big_tile && d->ks == 3 && p->bm == 128 && (p->bn == 128 || big_tile != 2) && (p->tw == 32 || (p->tw == 16 && big_tile != 2)) && k.S == 1 && p->nparity == 1 &&
-                        blocks(256, p->bn) >= (big_tile >= 3 ? 64 * (big_tile - 2) : (big_tile == 2 ? 512 : 64)) &&
+    // fp32 (kc == 16): the same kernel in its float form (a reduction tail runs transposed with its spare MFMA steps skipped; an output width of
+    // 16 n + 1..4 takes a whole channel tile there instead of the 4-channel sliver of conv_igemm16_kernel); not for launches that emit column sums
+    const bool f32_fit = kc != 16 || (mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr);
+    const bool big_ok = big_tile && f32_fit && d->ks == 3 && p->bm == 128 && (p->bn == 128 || big_tile != 2) && (p->tw == 32 || (p->tw == 16 && big_tile != 2)) && k.S == 1 && p->nparity == 1 &&
+                        blocks(256, p->bn) >= (big_tile >= 3 ? 64 * (big_tile - 2) : (big_tile == 2 ? 512 : (kc == 16 ? 256 : 64))) &&        // (fp32 is MFMA-bound either way: it wants every CU busy)
                         (long long)d->IH * d->IW * d->x_cs * 2 < (1ll << 31) - 65536 &&
                         (long long)d->OH * d->OW * d->y_cs * 4 < (1ll << 31) - 65536;       // (its halo items and result stores go through buffer descriptors: one image within 2 GiB)
     if (!split && !(big_ok && big_tile != 2) && p->bn >= 64 && blocks(128, p->bn) < 400) {
@@ -458,6 +461,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st);
 int conv2d_bf16_variant(const unet_conv_desc* d);
 int plan_bf16_public(const unet_conv_desc* d, Plan* p);
 // 1x1 convolutions with a reduction of at most 8 channels (conv_igemm.hip: conv1x1_smallk_kernel), both storage types
+int conv2d_t256_f32(const Plan& p, hipStream_t st);       // conv_bf16.hip: conv_bf16_t256_kernel<.., float>
 bool conv_smallk_applies(const unet_conv_desc* d);
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
 

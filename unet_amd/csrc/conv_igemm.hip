@@ -717,7 +717,8 @@ static int g_mfma_shape = 16;
 namespace unetconv { int g_splitk = 1; }
 namespace {
 
-static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_plan(d, p, KC, 4, g_mfma_shape); }
+int g_big_f32 = 1;         // the 256-pixel tile (conv_bf16_t256_kernel<.., float>) for eligible fp32 launches; unet_set_mfma_shape(-1 / -2) = off / on
+static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_plan(d, p, KC, 4, g_mfma_shape, g_big_f32); }
 
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
@@ -788,6 +789,7 @@ extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
 }
 
 extern "C" int unet_set_mfma_shape(int shape) {
+    if (shape < 0) { g_big_f32 = shape == -2 ? 1 : 0; return UNET_OK; }       // A/B switch of the fp32 256-pixel tile
     UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
     g_mfma_shape = shape;
     return UNET_OK;
@@ -801,7 +803,8 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (unetconv::conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
-    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
+    const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
+    return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? (large ? 7 : 6) : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
 
 // ------------------------------------------------------------------ split-K epilogue
@@ -1018,7 +1021,8 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     if (rc != UNET_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (smallk_applies(d)) return launch_smallk<float>(d, st);
-    rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
+    if (p.hit == 6) rc = unetconv::conv2d_t256_f32(p, st);          // the 256-pixel tile (conv_bf16.hip: conv_bf16_t256_kernel<.., float>)
+    else rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
     if (rc != UNET_OK || p.splits <= 1) return rc;
     return unetconv::splitk_reduce(d, p, st);
 }
