@@ -388,6 +388,13 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // bf16: the 256-pixel x 128-channel tile (conv_bf16_t256_kernel) for 3x3 / stride-1 launches from 64 blocks up -- on the deep 32 x 32
     // stages (a quarter of the chip's workgroup slots) it still beats the generic 128- / 64-pixel tiles by 1.2-1.7x, 512 -> 512: 109 -> 65 us,
     // with or without a split reduction on top (scripts/conv_mid_ab.py).  big_tile == 2: the order of round 3's first half (shrink first).
+    // fp32, a grid of fewer than 256 blocks of 256 pixels x 128 channels: narrower channel blocks (64, then 32) put a workgroup on every CU
+    // -- still the 256-pixel kernel, 1.2x the generic 64-pixel tile on the 32 x 32 stages (scripts/conv_f32_bias.py)
+    if (kc == 16 && big_tile && big_tile != 2 && !split && d->ks == 3 && k.S == 1 && p->nparity == 1 && mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr &&
+        (p->tw == 32 || p->tw == 16) && p->bn == 128 && blocks(256, 128) < 256) {
+        if (blocks(256, 64) >= 256) p->bn = 64;
+        else if (blocks(256, 32) >= 256) p->bn = 32;
+    }
     // fp32 (kc == 16): the same kernel in its float form (a reduction tail runs transposed with its spare MFMA steps skipped; an output width of
     // 16 n + 1..4 takes a whole channel tile there instead of the 4-channel sliver of conv_igemm16_kernel); not for launches that emit column sums
     const bool f32_fit = kc != 16 || (mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr);
