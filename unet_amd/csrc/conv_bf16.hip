@@ -700,52 +700,54 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                     }
                 }
             }
+            // Two passes.  First every operand of the epilogue (residual, mask) is fetched and applied in place in the accumulators; then all
+            // results leave back to back, for one pixel-tile pair the channel tiles in order.  A store covers 32 bytes of a pixel; with a
+            // residual fetch (a full memory round trip) between the stores of neighbouring channel tiles the pieces of one 128-byte line
+            // reached the L2 microseconds apart and many lines went out to HBM half written, twice: WRITE_SIZE of the 100-channel launches
+            // at 512^2 was 1.71 GB for 0.84 GB of results, 0.97 GB without residual (scripts/conv_write_probe.py).
+            // the pixel this lane moves for pixel-tile pair j of half h: tile 2 j + (kq & 1)
+            int pidx2[2][MH / 2];
+            bool pval2[2][MH / 2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < MH / 2; ++j) {
+                    const int pix = (wm * M16 + ((h * MH + 2 * j + (kq & 1)) ^ (r * MH))) * 16 + l15;
+                    const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
+                    pval2[h][j] = oy < a.OH && ox < a.OW;
+                    pidx2[h][j] = pval2[h][j] ? (oy * a.OW + ox) : 0;
+                }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-            // the pixel this lane moves for pixel-tile pair j: tile 2 j + (kq & 1)
-            int pidx2[MH / 2];
-            bool pval2[MH / 2];
-#pragma unroll
-            for (int j = 0; j < MH / 2; ++j) {
-                const int pix = (wm * M16 + ((h * MH + 2 * j + (kq & 1)) ^ (r * MH))) * 16 + l15;
-                const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
-                pval2[j] = oy < a.OH && ox < a.OW;
-                pidx2[j] = pval2[j] ? (oy * a.OW + ox) : 0;
-            }
-            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co, 0,
-                                                                                  __builtin_amdgcn_readfirstlane(a.OH * a.OW * a.y_cs * 2), 0x00020000);
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
-                const int c4 = n0c + TILE_COL(n) + 4 * kq;
                 const int c8 = n0c + TILE_COL(n) + 8 * (kq >> 1);          // the 8 channels this lane moves
-                const bool cvalid8 = c8 < a.n_end;
-                const int cc8 = cvalid8 ? c8 : 0;
-                f32x4 v[MH];
+                const int cc8 = c8 < a.n_end ? c8 : 0;
 #pragma unroll
-                for (int m = 0; m < MH; ++m) v[m] = acc[h * MH + m][n] + bvn[n];
+                for (int m = 0; m < MH; ++m) acc[h * MH + m][n] += bvn[n];
                 if (resb != nullptr) {
                     uint4 rr[MH / 2];
 #pragma unroll
-                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(resb + (size_t)pidx2[j] * a.res_cs + cc8);
+                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(resb + (size_t)pidx2[h][j] * a.res_cs + cc8);
 #pragma unroll
                     for (int j = 0; j < MH / 2; ++j) {
                         const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j].x, rr[j].z, false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(rr[j].y, rr[j].w, false, false);
-                        v[2 * j] += unpack(s0[0], s1[0]);
-                        v[2 * j + 1] += unpack(s0[1], s1[1]);
+                        acc[h * MH + 2 * j][n] += unpack(s0[0], s1[0]);
+                        acc[h * MH + 2 * j + 1][n] += unpack(s0[1], s1[1]);
                     }
                 }
                 if (relu) {
 #pragma unroll
                     for (int m = 0; m < MH; ++m)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[m][q] = fmaxf(v[m][q], 0.f);
+                        for (int q = 0; q < 4; ++q) acc[h * MH + m][n][q] = fmaxf(acc[h * MH + m][n][q], 0.f);
                 }
                 if (maskb != nullptr) {
                     uint4 rr[MH / 2];
 #pragma unroll
-                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(maskb + (size_t)pidx2[j] * a.mask_cs + cc8);
+                    for (int j = 0; j < MH / 2; ++j) rr[j] = *reinterpret_cast<const uint4*>(maskb + (size_t)pidx2[h][j] * a.mask_cs + cc8);
 #pragma unroll
                     for (int j = 0; j < MH / 2; ++j) {
                         const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j].x, rr[j].z, false, false);
@@ -753,20 +755,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                         const f32x4 m0 = unpack(s0[0], s1[0]), m1 = unpack(s0[1], s1[1]);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            v[2 * j][q] = m0[q] > 0.f ? v[2 * j][q] : 0.f;
-                            v[2 * j + 1][q] = m1[q] > 0.f ? v[2 * j + 1][q] : 0.f;
+                            acc[h * MH + 2 * j][n][q] = m0[q] > 0.f ? acc[h * MH + 2 * j][n][q] : 0.f;
+                            acc[h * MH + 2 * j + 1][n][q] = m1[q] > 0.f ? acc[h * MH + 2 * j + 1][n][q] : 0.f;
                         }
                     }
                 }
+            }
+            }
+            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(a.y) + img_pix * a.y_cs + a.y_co, 0,
+                                                                                  __builtin_amdgcn_readfirstlane(a.OH * a.OW * a.y_cs * 2), 0x00020000);
 #pragma unroll
-                for (int j = 0; j < MH / 2; ++j) {
-                    const bf16x4 x_ = {(__bf16)v[2 * j][0], (__bf16)v[2 * j][1], (__bf16)v[2 * j][2], (__bf16)v[2 * j][3]};
-                    const bf16x4 y_ = {(__bf16)v[2 * j + 1][0], (__bf16)v[2 * j + 1][1], (__bf16)v[2 * j + 1][2], (__bf16)v[2 * j + 1][3]};
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < MH / 2; ++j) {
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    if (n == NF && h != 0) continue;
+                    const int c8 = n0c + TILE_COL(n) + 8 * (kq >> 1);
+                    const bool cvalid8 = c8 < a.n_end;
+                    const f32x4 va = acc[h * MH + 2 * j][n], vb = acc[h * MH + 2 * j + 1][n];
+                    const bf16x4 x_ = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
+                    const bf16x4 y_ = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
                     const uint2 xu = __builtin_bit_cast(uint2, x_), yu = __builtin_bit_cast(uint2, y_);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(xu.x, yu.x, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(xu.y, yu.y, false, false);
                     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                    const unsigned vo = (cvalid8 && pval2[j]) ? (unsigned)(pidx2[j] * a.y_cs + c8) * 2u : OOB;
+                    const unsigned vo = (cvalid8 && pval2[h][j]) ? (unsigned)(pidx2[h][j] * a.y_cs + c8) * 2u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128((v4u){s0[0], s1[0], s0[1], s1[1]}, rsy, (int)vo, 0, 0);
                 }
             }
