@@ -634,7 +634,70 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
         auto unpack = [](unsigned lo, unsigned hi) -> f32x4 {
             return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
         };
-        if (y_f32) {
+        if constexpr (EB == 4) {
+            // (two passes like the bf16 form below: operands applied in place, then the stores of a pixel tile over its channel tiles in order;
+            // the pixel indices are computed again for the second pass -- eight more live registers made <8, 32, float> spill)
+            auto pix_of = [&](int mm, int& pidx_, bool& pval_) {
+                const int pix = (wm * M16 + (mm ^ (r * MH))) * 16 + l15;
+                const int oy = oy0c + pix / TW, ox = ox0c + pix % TW;
+                pval_ = oy < a.OH && ox < a.OW;
+                pidx_ = pval_ ? (oy * a.OW + ox) : 0;
+            };
+            if (resb != nullptr || maskb != nullptr || a.bias != nullptr || relu) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int pidx[MH];
+                bool pval[MH];
+#pragma unroll
+                for (int m = 0; m < MH; ++m) pix_of(h * MH + m, pidx[m], pval[m]);
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
+                    const int c4 = n0c + TILE_COL(n) + 4 * kq;
+                    const bool cvalid = c4 < a.n_end;
+                    const int cc = cvalid ? c4 : 0;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias != nullptr && cvalid) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+                    }
+#pragma unroll
+                    for (int m = 0; m < MH; ++m) acc[h * MH + m][n] += bv;
+                    if (resb != nullptr) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m) acc[h * MH + m][n] += ld4(resb + (size_t)pidx[m] * a.res_cs + cc);
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[h * MH + m][n][q] = fmaxf(acc[h * MH + m][n][q], 0.f);
+                    }
+                    if (maskb != nullptr) {
+#pragma unroll
+                        for (int m = 0; m < MH; ++m) {
+                            const f32x4 mv = ld4(maskb + (size_t)pidx[m] * a.mask_cs + cc);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[h * MH + m][n][q] = mv[q] > 0.f ? acc[h * MH + m][n][q] : 0.f;
+                        }
+                    }
+                }
+            }
+            }
+            float* yb = a.y + (a.cps ? (size_t)blockIdx.y * a.slab : (size_t)0) + img_pix * a.y_cs + a.y_co;
+#pragma unroll
+            for (int m = 0; m < M16; ++m) {
+                int pidx;
+                bool pval;
+                pix_of(m, pidx, pval);
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    if (n == NF && m >= MH) continue;
+                    const int c4 = n0c + TILE_COL(n) + 4 * kq;
+                    if (c4 < a.n_end && pval) *reinterpret_cast<f32x4*>(yb + (size_t)pidx * a.y_cs + c4) = acc[m][n];
+                }
+            }
+        } else if (y_f32) {          // bf16 operands, fp32 results (a cold path): one pass
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int pidx[MH];
@@ -684,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                         if (cvalid && pval[m]) *reinterpret_cast<f32x4*>(yb + (size_t)pidx[m] * a.y_cs + c4) = v[m];
                 }
             }
-        } else if constexpr (EB == 2) {
+        } else {
             // the bias of this wave's channel tiles, fetched once and first: a load between two result stores would make the compiler wait for
             // the older store as well (one in-order counter) -- that wait, per channel tile, was most of the epilogue
             f32x4 bvn[NL];
