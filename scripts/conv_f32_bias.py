@@ -10,7 +10,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 import unet_amd._lib as L
 SW = int(sys.argv[1]) if len(sys.argv) > 1 else -2          # -2: the fp32 256-pixel tile on (default), -1: off
 L.lib.unet_set_mfma_shape(SW)
-for H, Cin, Cout in [(512, 96, 96), (256, 192, 96), (256, 96, 96), (256, 96, 128), (128, 256, 256), (128, 64, 64), (64, 384, 384), (64, 128, 128), (32, 512, 512), (32, 256, 256), (16, 512, 512)]:
+for H, Cin, Cout in [(512, 96, 96), (256, 192, 96), (256, 96, 96), (256, 96, 128), (128, 256, 256), (128, 64, 64), (64, 384, 384), (64, 128, 128), (32, 512, 512), (32, 256, 256), (32, 128, 128), (16, 512, 512), (16, 1024, 512), (16, 512, 1024), (16, 256, 256)]:
     x = TS(torch.randn((N, H, H, ops.rup4(Cin)), device="cuda", generator=g), 0, Cin)
     y = TS(torch.empty((N, H, H, ops.rup4(Cout)), device="cuda"), 0, Cout)
     w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) / (Cin * 9) ** 0.5

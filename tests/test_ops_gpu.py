@@ -296,7 +296,8 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
     (40, 112, 128, 128, 4),     # tail of 8 channels (two steps)
     (13, 96, 128, 128, 4),      # the tail is the only chunk
     (256, 256, 32, 32, 16),     # 64 pixel tiles: the planner narrows the channel block to 64 so that 256 workgroups run
-    (64, 128, 32, 32, 16),      # 64 pixel tiles, a reduction too short for a split: narrowed to 32 channels
+    (64, 128, 32, 32, 16),      # 64 pixel tiles: narrowed to 32 channels
+    (512, 512, 16, 16, 16),     # 16 x 16 images (16-pixel patches), 16 pixel tiles x 16 blocks of 32 channels instead of a split reduction
 ])
 def test_conv_f32_t256_kernel(ops, case):
     """forward with bias + residual + ReLU into a channel slice and the input gradient with residual + mask on the fp32 form of the 256-pixel

@@ -362,7 +362,15 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // `splits` chains of K / splits products (the fp32 MFMA sums one k-ordered chain: its rounding error grows like sqrt(K)).
     p->splits = 1; p->cp = 0; p->ws_floats = 0;
     bool split = false;
-    if (g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8 && blocks(128, p->bn) < (g_splitk > 1 ? g_splitk : (kc == 32 ? 400 : 256))) {      // (bf16: measured +1.2 % on the step at 400; fp32 indifferent)
+    // fp32 on a small grid: narrower channel blocks (64, then 32) of the 256-pixel kernel put a workgroup on every CU.  Preferred to a split
+    // reduction of the generic kernel (isolated launches, scripts/conv_f32_bias.py: 16 x 16 512 -> 512 0.207 -> 0.153 ms, 1024 -> 512 0.393 -> 0.299,
+    // 32 x 32 128 -> 128 0.070 -> 0.045) and to the 64-pixel tile (32 x 32 256 -> 256 0.171 -> 0.147)
+    int nb_first = 0;
+    if (kc == 16 && big_tile && big_tile != 2 && d->ks == 3 && k.S == 1 && p->nparity == 1 && mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr &&
+        (p->tw == 32 || p->tw == 16) && p->bn == 128 && blocks(256, 128) < 256)
+        nb_first = blocks(256, 64) >= 256 ? 64 : (blocks(256, 32) >= 256 ? 32 : 0);
+    if (nb_first) p->bn = nb_first;
+    if (!nb_first && g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8 && blocks(128, p->bn) < (g_splitk > 1 ? g_splitk : (kc == 32 ? 400 : 256))) {      // (bf16: measured +1.2 % on the step at 400; fp32 indifferent)
         // at least two chunks per split; when even the deepest split of full-size tiles leaves most CUs idle (a handful of pixel tiles:
         // 8 x 8 stages at batch 2), the tile shrinks as well
         const int smax = k.nchunks / 2 < 32 ? k.nchunks / 2 : 32;
@@ -388,13 +396,6 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // bf16: the 256-pixel x 128-channel tile (conv_bf16_t256_kernel) for 3x3 / stride-1 launches from 64 blocks up -- on the deep 32 x 32
     // stages (a quarter of the chip's workgroup slots) it still beats the generic 128- / 64-pixel tiles by 1.2-1.7x, 512 -> 512: 109 -> 65 us,
     // with or without a split reduction on top (scripts/conv_mid_ab.py).  big_tile == 2: the order of round 3's first half (shrink first).
-    // fp32, a grid of fewer than 256 blocks of 256 pixels x 128 channels: narrower channel blocks (64, then 32) put a workgroup on every CU
-    // -- still the 256-pixel kernel, 1.2x the generic 64-pixel tile on the 32 x 32 stages (scripts/conv_f32_bias.py)
-    if (kc == 16 && big_tile && big_tile != 2 && !split && d->ks == 3 && k.S == 1 && p->nparity == 1 && mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr &&
-        (p->tw == 32 || p->tw == 16) && p->bn == 128 && blocks(256, 128) < 256) {
-        if (blocks(256, 64) >= 256) p->bn = 64;
-        else if (blocks(256, 32) >= 256) p->bn = 32;
-    }
     // fp32 (kc == 16): the same kernel in its float form (a reduction tail runs transposed with its spare MFMA steps skipped; an output width of
     // 16 n + 1..4 takes a whole channel tile there instead of the 4-channel sliver of conv_igemm16_kernel); not for launches that emit column sums
     const bool f32_fit = kc != 16 || (mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr);
