@@ -1260,6 +1260,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same sum for many splits: Q threads per element, thread q takes splits q, q + Q, .. (four independent chains), the Q partial sums meet
+// in LDS in a fixed order.  One thread per element walked up to 512 splits as 128 dependent steps on a grid of 144 workgroups (64 x 64 x 9
+// elements): 18.5 us a launch at 1.5 TB/s, 56 launches a step.
+template <int Q>
+__global__ __launch_bounds__(256) void wgrad_reduce_q_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, size_t KC_,
+                                                             int accumulate) {
+    constexpr int E = 256 / Q;
+    __shared__ float ps[Q][E];
+    const int el = threadIdx.x % E, q = threadIdx.x / E;
+    const size_t total = (size_t)T * KC_;
+    const size_t e = (size_t)blockIdx.x * E + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < total) {
+        const float* p = part + e;
+        int sp = q;
+        for (; sp + 3 * Q < splits; sp += 4 * Q) {
+            s0 += p[(size_t)sp * total];
+            s1 += p[(size_t)(sp + Q) * total];
+            s2 += p[(size_t)(sp + 2 * Q) * total];
+            s3 += p[(size_t)(sp + 3 * Q) * total];
+        }
+        for (; sp < splits; sp += Q) s0 += p[(size_t)sp * total];
+    }
+    ps[q][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && e < total) {
+        float s = ps[0][el];
+#pragma unroll
+        for (int j = 1; j < Q; ++j) s += ps[j][el];
+        const size_t t = e / KC_, i = e - t * KC_;
+        float* o = dw + i * T + t;
+        *o = accumulate ? (*o + s) : s;
+    }
+}
+
 // dbias[c] = sum over the pixel splits of bpart[split][c], in double.  64 channels per workgroup, four threads per channel take every
 // fourth split and meet in LDS in a fixed order (one thread per channel walking up to 256 splits was a 22 us dependent chain, 18 times a step).
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ dbias, int splits, int Cout) {
@@ -1554,6 +1589,12 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     const size_t KC_ = (size_t)d->Cout * d->Cin;
     if (p.small1x1)
         hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(unet::cdiv((int)(KC_ * p.T), 64)), dim3(256), 0, st, d->workspace, d->dw,
+                           p.splits, p.T, KC_, d->accumulate);
+    else if (p.splits >= 32 && KC_ * p.T < ((size_t)1 << 31) / 8)
+        hipLaunchKernelGGL(wgrad_reduce_q_kernel<8>, dim3((unsigned)unet::cdiv((long long)(KC_ * p.T), 32LL)), dim3(256), 0, st, d->workspace, d->dw,
+                           p.splits, p.T, KC_, d->accumulate);
+    else if (p.splits >= 8 && KC_ * p.T < ((size_t)1 << 31) / 8)
+        hipLaunchKernelGGL(wgrad_reduce_q_kernel<4>, dim3((unsigned)unet::cdiv((long long)(KC_ * p.T), 64LL)), dim3(256), 0, st, d->workspace, d->dw,
                            p.splits, p.T, KC_, d->accumulate);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_ * p.T, 256)), dim3(256), 0, st, d->workspace, d->dw,
