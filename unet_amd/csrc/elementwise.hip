@@ -167,7 +167,9 @@ static int pick_tc(int C4) {
 }
 
 static int stats_rows(long long P) {
-    long long r = (P + 127) / 128;
+    // (one row per 32 pixels: the 32 x 32 and 16 x 16 stages get 512 / 128 workgroups instead of 128 / 32 -- their reduce kernels were 8-16
+    // dependent trips of a quarter-filled chip, now 2-4; the finalize kernels walk four times the rows)
+    long long r = (P + 31) / 32;
     if (r < 1) r = 1;
     if (r > 512) r = 512;
     return (int)r;
