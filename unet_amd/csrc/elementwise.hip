@@ -167,10 +167,7 @@ static int pick_tc(int C4) {
 }
 
 static int stats_rows(long long P) {
-    // from 4096 pixels up one row per 32 pixels (the 32 x 32 and 16 x 16 stages of a batch of 16 get 512 / 128 workgroups instead of 128 / 32:
-    // their reduce kernels were 8-16 dependent trips on a quarter-filled chip, now 2-4; the finalize kernels walk four times the rows); below,
-    // one per 128 as before -- there the kernels are launch-bound either way
-    long long r = P >= 4096 ? (P + 31) / 32 : (P + 127) / 128;
+    long long r = (P + 127) / 128;
     if (r < 1) r = 1;
     if (r > 512) r = 512;
     return (int)r;
