@@ -117,7 +117,7 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
-def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world, dev, log, probe=True, use_graph=False):
+def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world, dev, log, probe=True, use_graph=False, self_attention=False):
     """K timed fwd + weighted-CE + bwd + fastai-Adam steps on `batch` synthetic tiles per GPU.  Returns the measurements of this rank
     (wall time of the K steps bracketed by barrier + synchronize, dominant-kernel probe, time the compute stream waited for the gradient
     all-reduce)."""
@@ -128,7 +128,7 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
     from unet_amd.trainer import TrainStep
     import torch.distributed as dist
     torch.manual_seed(0)
-    model = HipDynamicUnet(arch, n_in, n_cls, (size, size), device=dev, act_dtype=dtype)
+    model = HipDynamicUnet(arch, n_in, n_cls, (size, size), device=dev, act_dtype=dtype, self_attention=self_attention)
     broadcast_parameters(model.flat_param, list(model.buffers()))
     model.mark_weights_dirty()
     model.train()
@@ -139,7 +139,7 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
     g = torch.Generator().manual_seed(1234 + rank)
     x = (torch.randint(0, 256, (batch, n_in, size, size), generator=g).float() / 255).to(dev)
     y = torch.randint(0, n_cls, (batch, size, size), generator=g).to(dev)
-    log(f"{arch} {n_in}x{size}x{size} -> {n_cls} classes, {dtype}: {sum(p.numel() for p in model.parameters())} params, batch {batch}/gpu, world {world}")
+    log(f"{arch} {n_in}x{size}x{size} -> {n_cls} classes, {dtype}{', self-attention' if self_attention else ''}: {sum(p.numel() for p in model.parameters())} params, batch {batch}/gpu, world {world}")
     for i in range(warmup):
         step(x, y)
         torch.cuda.synchronize()
@@ -182,10 +182,19 @@ def roofline_of(ps, dtype, dt, steps, pmc):
         t = pmc.get(name)
         if not t or not t.get("hbm_bytes_per_launch"):
             return None
+        # where the figure comes from: it is read from a committed counter summary, not measured in this run; `traffic_code` is the
+        # kernel-source hash that profile was taken on, `traffic_code_current` says whether the code running now is that code
+        src["traffic_source"], src["traffic_code"] = t.get("source"), t.get("code")
+        try:
+            from unet_amd.build import source_hash
+            src["traffic_code_current"] = (t.get("code") == source_hash()) if t.get("code") else None
+        except Exception:      # noqa: BLE001
+            src["traffic_code_current"] = None
         per_step = t.get("launches_sampled", 0) / max(1, t.get("steps_sampled", 0)) if t.get("steps_sampled") else None
         mine = ps["launches"] / max(1, steps)
         return int(t["hbm_bytes_per_launch"] * (per_step / mine if per_step and mine else 1.0))
 
+    src = {"traffic_source": None, "traffic_code": None, "traffic_code_current": None}
     common = {"launches_per_step": ps["launches"] // max(1, steps), "avg_launch_ms": round(ps["avg_ms"], 4),
               "avg_launch_gflop": round(ps["flops"] / max(1, ps["launches"]) / 1e9, 2),
               "avg_launch_alg_bytes": int(ps["bytes"] / max(1, ps["launches"])),
@@ -196,14 +205,14 @@ def roofline_of(ps, dtype, dt, steps, pmc):
                                            "v_mfma_f32_16x16x4_f32: every wide 3x3 conv of the step, forward and input-gradient, incl. the 100-channel "
                                            "layers -- 7 channel tiles, transposed reduction tail; rocprofv3 lists its instantiations <6..8, 32, float>)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
-                "traffic": traffic_of("conv_bf16_t256_kernel<float>"), **common}
+                "traffic": traffic_of("conv_bf16_t256_kernel<float>"), **src, **common}
     achieved = ps["bytes"] / (ps["total_ms"] * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "conv_bf16_t256_kernel (bf16 storage, v_mfma_f32_16x16x32_bf16 implicit GEMM, 256-pixel x 128-channel tile: "
                                       "every wide 3x3 conv, forward and input-gradient; rocprofv3 lists its instantiations <6>, <7>, <8> = "
                                       "16-wide channel tiles per block); algorithmic bytes = every operand tensor once in, the result once "
                                       "out, the packed filter once",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-            "traffic": traffic_of("conv_bf16_t256_kernel"),
+            "traffic": traffic_of("conv_bf16_t256_kernel"), **src,
             "mfma_tflops": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12, 1),
             "mfma_frac_of_bf16_peak": round(ps["flops"] / (ps["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), **common}
 
@@ -366,28 +375,67 @@ def main():
             "devices": devices,
         }
         if world == 1 and not args.no_secondary and args.dtype == "f32":
-            # measured in this same process, after the headline: the other BASELINE configurations and the bf16-storage variant of configs[1]
+            # measured in this same process, after the headline: the other BASELINE configurations and the bf16-storage variant of configs[1].
+            # Every entry runs in its own try: a failure there is recorded in the entry and the headline line is still printed.
             sec = {}
-            log("secondary: bf16-storage step")
-            rb = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", args.steps, args.warmup, 0, 1, dev, log)
-            vb = args.batch * args.steps / rb["dt"]
-            sec["bf16"] = {"value": round(vb, 3), "unit": "tiles/s", "ms_per_step": round(rb["dt"] / args.steps * 1e3, 3), "steps": args.steps,
-                           "dtype": "bf16", "workload": "cfg2 (BASELINE configs[1] wording): same step, bf16 storage of activations / gradients / "
-                           "packed filters, fp32 accumulate, fp32 master weights + Adam", "loss": round(rb["loss"], 5),
-                           "step_tflops": round(vb * GFLOP_PER_TILE_FWD_BWD / 1e3, 2),
-                           "step_frac_of_bf16_peak": round(vb * GFLOP_PER_TILE_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS, 4),
-                           "roofline": roofline_of(rb["probe"], "bf16", rb["dt"], args.steps, pmc), "hbm_bytes_allocated": rb["mem"]}
-            log("secondary: predict (eval forward + softmax + argmax)")
-            sec["predict_b16"] = {"f32": predict_bench("f32", 16, dev), "bf16": predict_bench("bf16", 16, dev)}
-            sec["predict_b1"] = {"f32": predict_bench("f32", 1, dev, iters=20), "bf16": predict_bench("bf16", 1, dev, iters=20)}
-            log("secondary: cfg1 (BASELINE configs[0]: xresnet18 3->2, 256x256, batch 2)")
-            r1 = step_bench("xresnet18", 3, 2, 256, 2, "f32", 30, 5, 0, 1, dev, log, probe=False)
-            sec["cfg1"] = {"value": round(2 * 30 / r1["dt"], 2), "unit": "256x256 tiles/s", "ms_per_step": round(r1["dt"] / 30 * 1e3, 3), "dtype": "f32",
-                           "step_tflops": round(2 * 30 / r1["dt"] * 175.805 / 1e3, 2)}
-            log("secondary: cfg5 (BASELINE configs[4]: 20000x20000 sliding-window predict) fp32")
-            sec["cfg5"] = {"f32": cfg5_bench("f32", dev)}
-            log("secondary: cfg5 bf16")
-            sec["cfg5"]["bf16"] = cfg5_bench("bf16", dev)
+
+            def guarded(name, what, fn):
+                log(f"secondary: {what}")
+                try:
+                    sec[name] = fn()
+                except Exception as e:      # noqa: BLE001  (the headline must survive)
+                    sec[name] = {"error": f"{type(e).__name__}: {e}"}
+                    log(f"secondary {name} FAILED: {type(e).__name__}: {e}")
+                    torch.cuda.empty_cache()
+
+            def step_line(r, batch, steps, gflop, peak, workload, dtype, with_roofline=False):
+                v = batch * steps / r["dt"]
+                o = {"value": round(v, 3), "unit": "tiles/s", "ms_per_step": round(r["dt"] / steps * 1e3, 3), "steps": steps, "dtype": dtype,
+                     "batch": batch, "workload": workload, "loss": round(r["loss"], 5), "step_tflops": round(v * gflop / 1e3, 2),
+                     "step_frac_of_peak": round(v * gflop / 1e3 / peak, 4), "peak_tflops": peak, "hbm_bytes_allocated": r["mem"]}
+                if with_roofline:
+                    o["roofline"] = roofline_of(r["probe"], dtype, r["dt"], steps, pmc)
+                return o
+
+            def bf16_line():
+                rb = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", args.steps, args.warmup, 0, 1, dev, log)
+                o = step_line(rb, args.batch, args.steps, GFLOP_PER_TILE_FWD_BWD, PEAK_BF16_TFLOPS,
+                              "cfg2 (BASELINE configs[1] wording): same step, bf16 storage of activations / gradients / packed filters, "
+                              "fp32 accumulate, fp32 master weights + Adam", "bf16", with_roofline=True)
+                o["step_frac_of_bf16_peak"] = o["step_frac_of_peak"]
+                return o
+
+            def sa_line(dtype):
+                # the reference's SHIPPED default is self_attention=True (params_and_main.py:81-83); SURVEY 8(d): report it separately
+                r = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, dtype, 5, 2, 0, 1, dev, log, probe=False, self_attention=True)
+                return step_line(r, args.batch, 5, GFLOP_PER_TILE_FWD_BWD + 3 * 16.0, PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS,
+                                 "cfg2 with DynamicUnet(self_attention=True): SelfAttention(384) at 64x64 positions behind UnetBlock 1 "
+                                 "(+ ~16 GFLOP fwd per tile)", dtype)
+
+            def cfg4_line():
+                # BASELINE configs[3]: 8-ch 1024x1024 tiles, xresnet50 encoder, 10 classes, fp32
+                r = step_bench("xresnet50", 8, 10, 1024, 2, "f32", 3, 2, 0, 1, dev, log, probe=False)
+                o = step_line(r, 2, 3, 30454.37, PEAK_F32_TFLOPS, "cfg4 (BASELINE configs[3]): xresnet50 DynamicUnet 8 -> 10 classes, "
+                              "1024x1024 tiles, batch 2, fp32, same fwd + CE + bwd + fastai-Adam step", "f32")
+                o["unit"] = "1024x1024 tiles/s"
+                return o
+
+            def cfg1_line():
+                r1 = step_bench("xresnet18", 3, 2, 256, 2, "f32", 30, 5, 0, 1, dev, log, probe=False)
+                return {"value": round(2 * 30 / r1["dt"], 2), "unit": "256x256 tiles/s", "ms_per_step": round(r1["dt"] / 30 * 1e3, 3), "dtype": "f32",
+                        "step_tflops": round(2 * 30 / r1["dt"] * 175.805 / 1e3, 2)}
+
+            guarded("bf16", "bf16-storage step", bf16_line)
+            guarded("predict_b16", "predict (eval forward + softmax + argmax), batch 16",
+                    lambda: {"f32": predict_bench("f32", 16, dev), "bf16": predict_bench("bf16", 16, dev)})
+            guarded("predict_b1", "predict, batch 1",
+                    lambda: {"f32": predict_bench("f32", 1, dev, iters=20), "bf16": predict_bench("bf16", 1, dev, iters=20)})
+            guarded("cfg1", "cfg1 (BASELINE configs[0]: xresnet18 3->2, 256x256, batch 2)", cfg1_line)
+            guarded("cfg4", "cfg4 (BASELINE configs[3]: xresnet50 8->10, 1024x1024, batch 2, fp32)", cfg4_line)
+            guarded("sa_on", "cfg2 with self-attention on (the reference's shipped default), fp32 + bf16",
+                    lambda: {"f32": sa_line("f32"), "bf16": sa_line("bf16")})
+            guarded("cfg5", "cfg5 (BASELINE configs[4]: 20000x20000 sliding-window predict) fp32 + bf16",
+                    lambda: {"f32": cfg5_bench("f32", dev), "bf16": cfg5_bench("bf16", dev)})
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -399,12 +447,15 @@ def main():
         done = threading.Event()
 
         def emergency():
+            # the exchange did not come back: print the headline WITH the failure recorded in it, then end this rank with a non-zero
+            # code so that spawn_ranks / the launcher see a failed run (a hang must not read as success)
             if done.is_set():
                 return
             if rank == 0:
-                out["secondary"] = {"cfg5": {"error": "multi-rank cfg5 did not finish within 300 s; headline unaffected"}}
+                out["secondary"] = {"cfg5": {"error": "multi-rank cfg5 did not finish within 300 s (collective or GPU hang); headline measured before it"}}
+                out["failed"] = "secondary.cfg5 watchdog"
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
         timer = threading.Timer(300.0, emergency)
         timer.daemon = True
         timer.start()

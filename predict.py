@@ -265,6 +265,10 @@ def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_
     model    HipDynamicUnet (eval weights) or a Learner
     raster   path of a GeoTIFF, or an integer array [C, H, W] (numpy / torch, host or device)
     dtype    "int8" | "int16": the reference's DATATYPE switch -- int16 rasters are divided by 255 twice (utils.py:248-249 + IntToFloatTensor)
+    batch_size  windows per forward launch.  Results are bit-reproducible for a FIXED batch_size (any rank count, any run); a different
+             batch_size changes the launch grids and with them which deep-stage convs run as split reductions, i.e. the
+             logits at rounding level (<= 2e-5 of the logit scale, tests/test_fullsize_gpu.py): masks can differ in numerical-tie pixels.
+             The reference's own loop is batch 1 (predict.py:191-193)
     large_file  the reference's int8 merge (predict.py:209-214,288-289,324-329): probabilities as around(p * 31) in int8 rasters, int8 hit
              counters, integer floor division -- same numbers as save_predictions(merge=True, large_file=True)
     Returns on rank 0 the merged array (uint8 argmax [H', W'] by default; float32 [C, H', W'] for all_classes; one float32 plane for

@@ -4,6 +4,7 @@
 TAG=${1:-r01_x}
 DT=${2:-f32}
 R=$PWD; OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
+python -m unet_amd.build --hash > $OUT/code_hash.txt
 python bench.py --dtype $DT > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 tail -1 $OUT/bench.json | cut -c1-200
 export TMPDIR=/tmp; cd /tmp

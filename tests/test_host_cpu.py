@@ -160,6 +160,26 @@ def test_degenerate_and_oversized_problems_are_rejected_before_any_launch():
     assert L.lib.unet_adam_hyper_floats() > 0
 
 
+def test_planner_keeps_oversized_fp32_images_off_the_buffer_descriptor_kernel():
+    """conv_bf16_t256_kernel addresses one image through a buffer descriptor: num_records = IH * IW * x_cs * element size must stay below
+    2^31 - 64 Ki so that the out-of-bounds offset 0x80000000 really is out of bounds.  An fp32 image of 2^29..2^30 elements used to pass the
+    (2-byte) bound: the planner must hand it to the generic kernel (variant ...0), the same shape just under the limit stays on t256 (...7)"""
+    import ctypes as C
+    import unet_amd._lib as L
+
+    def variant(side, cs, cout, dtype):
+        d = L.ConvDesc()
+        for k, v in dict(x=0x100000, x_cs=cs, x_co=0, wp=0x200000, y=0x300000, y_cs=cout, y_co=0, N=1, IH=side, IW=side, Cin=cs, OH=side,
+                         OW=side, Cout=cout, ks=3, stride=1, kind=0, flags=0, dtype=dtype).items():
+            setattr(d, k, v)
+        return L.lib.unet_conv2d_variant(C.byref(d))
+
+    assert variant(1600, 196, 96, L.F32) % 10 == 7          # 1600^2 x 196 x 4 B = 2.007e9 < 2^31 - 65536
+    assert variant(1792, 196, 96, L.F32) % 10 == 0          # 2.52e9 bytes: generic kernel
+    assert variant(1792, 200, 96, L.BF16) % 10 == 7         # 1.28e9 bytes in bf16 storage
+    assert variant(2048, 128, 128, L.F32) % 10 == 0         # 2^31 bytes exactly
+
+
 def test_params_and_main_surface(monkeypatch):
     """the configuration module keeps the reference's global names (params_and_main.py:21-118) and its main() dispatches to the
     three stages with the reference's argument lists"""

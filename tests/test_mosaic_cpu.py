@@ -124,7 +124,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _exchange_worker(rank, world, port, q):
+def _exchange_worker(rank, world, port, q, geom=(1500, 700, 512)):
     """what the ranks of predict._Merge do between the forward passes and the finalisation, with the device kernels replaced by numpy:
     slabs travel through predict._exchange (isend / irecv pair), strips through predict._Merge._gather_rows (send / recv to rank 0)"""
     import os
@@ -134,12 +134,13 @@ def _exchange_worker(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import predict as P
-    H, W, size, C = 1500, 700, 512, 3
+    (H, W, size), C = geom, 3
     wins = sliding_windows(H, W, size, 0.2)
     places = np.concatenate([wins, np.full((len(wins), 2), size)], axis=1)
     g = np.random.default_rng(5)
     probs = [g.random((C, size, size), dtype=np.float32) for _ in places]           # the same "predictions" on both ranks
     plan = MergePlan(places, H, W, world)
+    assert plan.active == world, (plan.active, world)          # the geometry is chosen so that every rank owns a strip
     lo, hi = plan.own[rank]
     m, c = np.zeros((C, hi - lo, W), np.float32), np.zeros((hi - lo, W), np.int32)
     a, b = plan.ranges[rank]
@@ -179,15 +180,22 @@ def _exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_slab_exchange_and_strip_gather_two_gloo_ranks():
+@pytest.mark.parametrize("world,geom", [(2, (1500, 700, 512)), (8, (1400, 300, 128))])
+def test_slab_exchange_and_strip_gather_gloo_ranks(world, geom):
+    """world 8 = the rank count of BASELINE configs[4] (8-GPU tile-sharded predict): seven simultaneous isend / irecv boundaries, every
+    rank receiving from the rank below while sending to the rank above, then the strip gather on rank 0"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q, geom)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-    assert res == [(0, True, True), (1, True, True)], res
+    try:
+        res = sorted(q.get(timeout=300) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert res == [(r, True, True) for r in range(world)], res

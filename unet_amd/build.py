@@ -28,6 +28,16 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+def source_hash() -> str:
+    """content hash of the kernel sources + ABI header: names the code a profile / counter file was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [REPO / "include" / "unet_hip.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [REPO / "include" / "unet_hip.h"]
@@ -59,5 +69,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
+    if "--hash" in sys.argv:
+        print(source_hash())
+        sys.exit(0)
     p = build_lib(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(p)

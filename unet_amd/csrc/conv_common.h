@@ -401,7 +401,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     const bool f32_fit = kc != 16 || (mf == 16 && d->colsum == nullptr && d->colsumsq == nullptr);
     const bool big_ok = big_tile && f32_fit && d->ks == 3 && p->bm == 128 && (p->bn == 128 || big_tile != 2) && (p->tw == 32 || (p->tw == 16 && big_tile != 2)) && k.S == 1 && p->nparity == 1 &&
                         blocks(256, p->bn) >= (big_tile >= 3 ? 64 * (big_tile - 2) : (big_tile == 2 ? 512 : (kc == 16 ? 256 : 64))) &&        // (fp32 is MFMA-bound either way: it wants every CU busy)
-                        (long long)d->IH * d->IW * d->x_cs * 2 < (1ll << 31) - 65536 &&
+                        (long long)d->IH * d->IW * d->x_cs * (kc == 16 ? 4 : 2) < (1ll << 31) - 65536 &&        // (bytes of ONE image at the storage width: the buffer descriptor's num_records, and the OOB offset 0x80000000 must stay outside it)
                         (long long)d->OH * d->OW * d->y_cs * 4 < (1ll << 31) - 65536;       // (its halo items and result stores go through buffer descriptors: one image within 2 GiB)
     if (!split && !(big_ok && big_tile != 2) && p->bn >= 64 && blocks(128, p->bn) < 400) {
         p->bm = 64;

@@ -381,9 +381,9 @@ class HipDynamicUnet(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 probs, amax = self.predict_probs(xs)
-            ent = cache[key] = (g, xs, probs, amax, self.ctx.weights_epoch)
+            ent = cache[key] = (g, xs, probs, amax, (self.ctx.weights_epoch, self.ctx.bn_epoch))
         g, xs, probs, amax, epoch = ent
-        if epoch != self.ctx.weights_epoch:                          # weights changed: the captured filter images are stale
+        if epoch != (self.ctx.weights_epoch, self.ctx.bn_epoch):     # weights or running statistics changed: the captured filter images / shifts are stale
             del cache[key]
             return self.predict_probs_graphed(x)
         xs.copy_(x, non_blocking=True)

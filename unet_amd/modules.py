@@ -240,7 +240,11 @@ class _ConvExec:
         w = self.conv.weight
         c = self.ctx
         folded = c is not None and c.fold_bn and self.fold is not None
-        return (w._version, w.data_ptr(), 0 if c is None else c.weights_epoch, c.bn_epoch if folded else -1)
+        if not folded:
+            return (w._version, w.data_ptr(), 0 if c is None else c.weights_epoch, -1)
+        bn = self.fold.bn                # the folded scale follows the BatchNorm's tensors as _BNExec.coeffs does (a direct buffer update counts)
+        return (w._version, w.data_ptr(), c.weights_epoch, c.bn_epoch, bn.weight._version, bn.running_var._version, bn.running_mean._version,
+                bn.bias._version)
 
     def ensure_buffers(self, with_dgrad: bool):
         """the persistent packed-image buffers (HipDynamicUnet packs all of them in one launch: unet_pack_batch_run)"""

@@ -233,6 +233,7 @@ CONV_PROBE: Optional[ConvProbe] = None
 # Scratch for split-K conv launches (unet_conv_desc.splitk_ws): one fp32 buffer per device, grown on demand, reused by every launch
 # (stream ordered).  It reaches its final size during the eager warm-up steps, so a captured step sees a static address.
 _SPLITK_WS = {}
+_SPLITK_RETIRED = []      # outgrown buffers stay alive: a captured hipGraph may hold their address in its split launches
 
 
 def _splitk_ws(d: ConvDesc):
@@ -243,6 +244,10 @@ def _splitk_ws(d: ConvDesc):
     dev = torch.cuda.current_device()
     buf = _SPLITK_WS.get(dev)
     if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.UnetHipError("split-K workspace would have to grow inside a hipGraph capture: run the eager warm-up at this geometry first")
+        if buf is not None:
+            _SPLITK_RETIRED.append(buf)
         buf = _SPLITK_WS[dev] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=f"cuda:{dev}")
     d.splitk_ws, d.splitk_ws_floats = buf.data_ptr(), buf.numel()
 
