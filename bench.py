@@ -261,7 +261,7 @@ def cfg5_bench(dtype, dev, side=20000, size=512, overlap=0.2, batch=16):
     return r
 
 
-def cfg5_multi(dtype, dev, rank, world, side=20000, size=512, overlap=0.2, batch=16):
+def cfg5_multi(dtype, dev, rank, world, side=int(os.environ.get("UNET_CFG5_SIDE", "20000")), size=512, overlap=0.2, batch=16):
     """BASELINE configs[4] as worded: the 20000 x 20000 raster predicted by ALL ranks -- predict.predict_raster partitions the windows into
     contiguous row blocks (one per rank), every rank keeps its strip of the mosaic, overlap rows travel as slabs to the neighbouring rank
     (RCCL send / recv over xGMI), rank 0 gathers the uint8 mask.  Wall time between two barriers, max over ranks."""

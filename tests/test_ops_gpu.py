@@ -292,7 +292,10 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
     (64, 64, 64, 64, 16),       # 64-wide channel block
     (48, 32, 64, 64, 16),       # 32-wide block
     (64, 128, 32, 24, 64),      # 16 x 16 pixel patches (outputs 16..31 pixels wide), ragged second patch column
-    (100, 100, 256, 256, 2),    # reduction tail of 4 channels (transposed chunk, one of four MFMA steps) and 7 channel tiles for 100 outputs
+    (100, 100, 256, 256, 2),    # reduction tail of 4 channels (transposed chunk, one of four MFMA steps); 100 outputs = 6 tiles + the 4-channel SLIVER
+    (96, 100, 250, 270, 2),     # the sliver behind full chunks only, ragged image edges (pixel tiles partly outside the image)
+    (52, 228, 128, 128, 4),     # two launches: a full block + a 7-tile block (100 = 6 x 16 + 4) that ends in the sliver; tail of 4 channels
+    (36, 100, 128, 128, 4),     # the sliver behind one full chunk + a tail of 4 channels
     (40, 112, 128, 128, 4),     # tail of 8 channels (two steps)
     (13, 96, 128, 128, 4),      # the tail is the only chunk
     (256, 256, 32, 32, 16),     # 64 pixel tiles: the planner narrows the channel block to 64 so that 256 workgroups run
@@ -301,7 +304,9 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
 ])
 def test_conv_f32_t256_kernel(ops, case):
     """forward with bias + residual + ReLU into a channel slice and the input gradient with residual + mask on the fp32 form of the 256-pixel
-    kernel (variant ...7 / ...6), against torch on the CPU and against the generic kernel (unet_set_mfma_shape(-1)) on the same operands"""
+    kernel (variant ...7 / ...6), against torch on the CPU and against the generic kernel (unet_set_mfma_shape(-1)) on the same operands.
+    Output widths of 16 n + 1..4 in a 7-tile block run their last channels as a v_mfma_f32_4x4x1 sliver (conv_bf16_t256_kernel<7, 32, float, true>:
+    four partial chains per output element, summed in a fixed order) -- in both directions for the 100 -> 100 case."""
     from unet_amd._lib import lib
     Cin, Cout, H, W, N = case
     g = torch.Generator().manual_seed(Cin * 1000 + Cout)

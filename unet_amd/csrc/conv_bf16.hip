@@ -370,8 +370,15 @@ __device__ unsigned long long* g_stamps = nullptr;
 // tile pair and stage with the operand roles of the bf16 form -- A = filter, B = pixels -- so that a lane again holds four consecutive
 // channels of one pixel and results move as 16-byte vectors; no reduction tail, no 4-channel sliver: the planner keeps those launches on
 // conv_igemm16_kernel).
-template <int NTOT, int TW, typename T>
+// SLV (fp32 storage, odd NTOT): the last channel tile of the block holds only 1..4 real channels (the 100-wide final ResBlock: 6 x 16 + 4).
+// It takes the place of the shared odd tile -- same filter loads (lane column l15 & 3 of that tile), same half of the pixel tiles per wave --
+// but multiplies with v_mfma_f32_4x4x1_16B_f32: A = filter (lane 4 b + i: output channel i, reduction channel of the lane's k-slot), B = the
+// pixel operand the 16x16x4 tiles use (lane = pixel l15, reduction channel 4 kq + kk), D: lane (l15, kq) gets the four output channels of ITS
+// pixel, summed over the reduction channels of k-slot class kq.  Two passes instead of eight per pixel tile and MFMA step; the four kq-class
+// partial sums of a pixel meet in the epilogue ((kq0 + kq1) + (kq2 + kq3): two lane exchanges, the same order in every lane).
+template <int NTOT, int TW, typename T, bool SLV = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, const int y_f32_arg, const int tpw, const int bn) {
+    static_assert(!SLV || ((NTOT & 1) && sizeof(T) == 4), "the 4-channel sliver replaces the shared odd tile of the fp32 form");
     constexpr int TH = 256 / TW, M16 = 8, N16 = 4, MH = 4, HIT = 6, NTH = 256;
     constexpr int EB = (int)sizeof(T), VEC = 16 / EB, KCT = 64 / EB;       // bytes per element, channels per 16-byte item / per chunk
     const int y_f32 = EB == 4 ? 1 : y_f32_arg;
@@ -465,7 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
 #define TILE_COL(n_) (((n_) == NF ? (n_) * 2 : (n_) * 2 + wn) * 16)
     const unsigned voff = (unsigned)((wn * 16 + l15) * 64 + 16 * kq);
     const unsigned voff2 = voff + 4096u;
-    const unsigned voffs = (NF >= 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
+    const unsigned voffs = SLV ? (unsigned)((l15 & 3) * 64 + 16 * kq) + (NF >= 2 ? 4096u : 0u)        // sliver: column l15 & 3 of the last tile
+                               : (NF >= 2 ? voff2 : voff) - (unsigned)(((NTOT & 1) ? wn : 0) * 1024);      // the shared tile: one tile (1 KiB) lower for wn = 1
     v4f b0[N16], b1[N16];
 
     f32x4 acc[M16][N16];
@@ -504,6 +512,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                         const bf16x8 wv_ = __builtin_bit_cast(bf16x8, (bu_)[n]); \
                         _Pragma("unroll") for (int m = 0; m < MH; ++m) \
                             acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv_, __builtin_bit_cast(bf16x8, pv_[m]), acc[h * MH + m][n], 0, 0, 0); \
+                    } else if (SLV && n == NF) { \
+                        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) \
+                            _Pragma("unroll") for (int m = 0; m < MH; ++m) \
+                                acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_4x4x1f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
                     } else { \
                         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) \
                             _Pragma("unroll") for (int m = 0; m < MH; ++m) \
@@ -576,8 +588,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 if (n < NF || h == 0) { \
                     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
                         if (kk < ks) { \
-                            _Pragma("unroll") for (int m = 0; m < MH; ++m) \
-                                acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
+                            _Pragma("unroll") for (int m = 0; m < MH; ++m) { \
+                                if (SLV && n == NF) acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_4x4x1f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
+                                else acc[h * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32((bu_)[n][kk], pv_[m][kk], acc[h * MH + m][n], 0, 0, 0); \
+                            } \
                         } \
                     } \
                 } \
@@ -643,6 +657,40 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 pval_ = oy < a.OH && ox < a.OW;
                 pidx_ = pval_ ? (oy * a.OW + ox) : 0;
             };
+            // the sliver: lane (l15, kq) holds, for each of the four pixel tiles of this wave's half, the partial sums of ITS pixel over the
+            // reduction channels of k-slot class kq.  The four classes meet ((kq0 + kq1) + (kq2 + kq3), the same in every lane), then lane row kq
+            // keeps pixel tile kq: one 16-byte vector of channels 96..99 per lane, with an epilogue of its own (first: 16 accumulator registers die here)
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+            int spidx = 0;
+            bool spval = false;
+            const int sc4 = n0c + TILE_COL(NF);
+            if constexpr (SLV) {
+#pragma unroll
+                for (int m = 0; m < MH; ++m) {
+                    f32x4 v = acc[m][NF];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], 32);
+                    if (kq == m) sv = v;
+                }
+                pix_of(kq, spidx, spval);
+                spval = spval && sc4 < a.n_end;
+                if (a.bias != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] += (sc4 + q < a.Cout) ? a.bias[sc4 + q] : 0.f;
+                }
+                if (resb != nullptr) sv += ld4(resb + (size_t)spidx * a.res_cs + (sc4 < a.n_end ? sc4 : 0));
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] = fmaxf(sv[q], 0.f);
+                }
+                if (maskb != nullptr) {
+                    const f32x4 mv = ld4(maskb + (size_t)spidx * a.mask_cs + (sc4 < a.n_end ? sc4 : 0));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] = mv[q] > 0.f ? sv[q] : 0.f;
+                }
+            }
             if (resb != nullptr || maskb != nullptr || a.bias != nullptr || relu) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -652,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 for (int m = 0; m < MH; ++m) pix_of(h * MH + m, pidx[m], pval[m]);
 #pragma unroll
                 for (int n = 0; n < NL; ++n) {
-                    if (n == NF && h != 0) continue;          // the shared tile: this wave's first half only
+                    if (n == NF && (h != 0 || SLV)) continue;          // the shared tile: this wave's first half only (the sliver: below)
                     const int c4 = n0c + TILE_COL(n) + 4 * kq;
                     const bool cvalid = c4 < a.n_end;
                     const int cc = cvalid ? c4 : 0;
@@ -692,10 +740,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_t256_kernel(const KArgs a, c
                 pix_of(m, pidx, pval);
 #pragma unroll
                 for (int n = 0; n < NL; ++n) {
-                    if (n == NF && m >= MH) continue;
+                    if (n == NF && (m >= MH || SLV)) continue;
                     const int c4 = n0c + TILE_COL(n) + 4 * kq;
                     if (c4 < a.n_end && pval) *reinterpret_cast<f32x4*>(yb + (size_t)pidx * a.y_cs + c4) = acc[m][n];
                 }
+                if (SLV && m == MH - 1 && spval) *reinterpret_cast<f32x4*>(yb + (size_t)spidx * a.y_cs + sc4) = sv;      // (behind its pixels' other pieces)
             }
         } else if (y_f32) {          // bf16 operands, fp32 results (a cold path): one pass
 #pragma unroll
@@ -885,11 +934,12 @@ extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
 }
 #endif
 
+int g_t256_sliver = [] { const char* e = getenv("UNET_T256_SLIVER"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();      // A/B switch
 int g_t256_tpw = 0;        // tiles per workgroup of conv_bf16_t256_kernel (0: chosen per launch; unet_set_bf16_big_tile(100 + n) forces n)
 
-template <int NTOT, int TW, typename T>
+template <int NTOT, int TW, typename T, bool SLV = false>
 int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
-    auto kern = conv_bf16_t256_kernel<NTOT, TW, T>;
+    auto kern = conv_bf16_t256_kernel<NTOT, TW, T, SLV>;
     static unsigned long long configured = 0;
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -911,6 +961,11 @@ int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
     const int cols = p.k.n_end - p.k.n_base, nblk = p.k.ntn, full = p.bn / 16;
     const int last_tiles = (cols - (nblk - 1) * p.bn + 15) / 16;
     auto one = [&](const Plan& q, int tiles) {
+        if constexpr (sizeof(T) == 4) {
+            // fp32: a 7-tile block whose last tile holds 1..4 real channels (100 = 6 x 16 + 4: the final ResBlock pair) multiplies them as a sliver
+            const int last_w = (q.k.n_end - q.k.n_base) - (q.k.ntn - 1) * q.bn - (tiles - 1) * 16;
+            if (g_t256_sliver && tiles == 7 && q.tw == 32 && last_w >= 1 && last_w <= 4) return launch_t256n<7, 32, T, true>(q, y_f32, st);
+        }
         if (q.tw == 32) {
             switch (tiles) {
                 case 8: return launch_t256n<8, 32, T>(q, y_f32, st);

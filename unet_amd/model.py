@@ -297,6 +297,12 @@ class HipDynamicUnet(nn.Module):
         d = L[nb].hip_bwd(ctx, dX.sub(0, self.up_c))            # -> masked grad wrt UnetBlock 3 conv2 pre-activation
         ctx.free(dX)
         hook = self.grad_ready_hook
+        if hook is not None:
+            user_hook = hook
+
+            def hook(offset, _h=user_hook, _c=ctx):             # the weight gradients up to here may still run on the side stream
+                _c.side_join()
+                _h(offset)
         if hook is not None:                                    # head, final ResBlock, final shuffle: the first bucket can leave now
             hook(self._layer_offset[nb])
         dskips: Dict[int, TS] = {}
@@ -352,6 +358,7 @@ class HipDynamicUnet(nn.Module):
                 hook(self._enc_child_offset[i])
         for t in dskips.values():
             ctx.free(t)
+        ctx.side_join()                                         # every .grad view is final behind this point of the launch stream
         assert not ctx._pool_live, "a backward temporary was not returned to the pool"
 
     # ------------------------------------------------------------------ torch-facing surface

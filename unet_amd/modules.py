@@ -18,7 +18,9 @@ Gradient convention of the programs
 """
 from __future__ import annotations
 
+import collections
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -57,6 +59,23 @@ class Ctx:
         # images are older than this epoch
         self.bn_epoch = 0
         self.fold_bn = False                # this forward folds eval-mode BatchNorms into the conv in front of them
+        # Weight gradients on a second stream (see _ConvExec.bwd_w): dL/dw of a layer is needed by nobody before the optimizer (or the
+        # gradient all-reduce), dL/dx by the very next launch -- so wgrad + its split reduction leave the critical path and run next to
+        # the input-gradient / BatchNorm-backward chain.  Large layers fill the chip either way; small grids (deep stages, small batches:
+        # BASELINE configs[0]) and the HBM-bound reduce launches overlap.  UNET_WGRAD_STREAM=0 keeps everything on one stream.
+        # Which launches go there is a matter of size (measured): next to a weight gradient that fills the chip with MFMA work the
+        # fp32 conv kernels of the main stream slow down by more than the overlap returns, so only launches below `wgrad_overlap_gflop`
+        # leave the main stream (UNET_WGRAD_STREAM = 0: none, all: every one, a number: that many GFLOP)
+        mode = os.environ.get("UNET_WGRAD_STREAM", "1")
+        self.wgrad_overlap = mode != "0"
+        default = 30.0 if act_dtype == torch.float32 else 1e9
+        self.wgrad_overlap_gflop = 1e9 if mode == "all" else (float(mode) if mode not in ("0", "1") else default)
+        self._side: Optional[torch.cuda.Stream] = None
+        self._side_ws: Optional[torch.Tensor] = None
+        self._side_dirty = False            # side-stream work launched since the last join
+        self._side_tag: Dict[int, torch.cuda.Event] = {}     # pool buffer -> event behind its last side-stream reader
+        self._side_pending = collections.deque()             # freed buffers withheld from the pool until that reader is done
+        self.side_depth = 3                 # how many such buffers may be withheld (= how far the main stream may run ahead)
 
     # activations are keyed by (owner id, tag, shape): allocated once per input geometry
     def act(self, owner, tag, N, H, W, C, zero=False, dtype=None) -> TS:
@@ -110,7 +129,53 @@ class Ctx:
         if ptr not in self._pool_live:
             raise RuntimeError("backward temporary freed twice")
         self._pool_live.discard(ptr)
+        ev = self._side_tag.pop(ptr, None)
+        if ev is not None:
+            # a weight-gradient launch on the side stream still reads this buffer: it stays out of the pool until the main stream has
+            # been made to wait for that launch -- which happens `side_depth` frees later, when the launch is long done (no stall).
+            # Program order decides which buffer comes back when: addresses stay the same from step to step
+            self._side_pending.append((ptr, key, ev))
+            while len(self._side_pending) > self.side_depth:
+                self._side_release_oldest()
+            return
         self._pool[key].append(self._pool_flat[ptr])
+
+    # ---- the side stream of the weight gradients
+    def side(self) -> Optional["torch.cuda.Stream"]:
+        if not self.wgrad_overlap or self.device.type != "cuda":
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def side_workspace(self, nfloats: int) -> torch.Tensor:
+        """scratch of the side stream's launches (they are ordered among themselves; the main stream's ctx.workspace is not theirs)"""
+        if self._side_ws is None or self._side_ws.numel() < nfloats:
+            if self._side_ws is not None:
+                self._side_ws.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                self._side_ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=self.device)
+        return self._side_ws
+
+    def side_reads(self, t: Optional[TS], ev) -> None:
+        """`ev` (recorded on the side stream) lies behind the last side-stream reader of t's buffer"""
+        if t is not None and t.buf.data_ptr() in self._pool_key:
+            self._side_tag[t.buf.data_ptr()] = ev
+
+    def _side_release_oldest(self):
+        ptr, key, ev = self._side_pending.popleft()
+        torch.cuda.current_stream().wait_event(ev)
+        self._pool[key].append(self._pool_flat[ptr])
+
+    def side_join(self):
+        """the current stream waits for every weight gradient launched so far (before the optimizer / a gradient bucket leaves)"""
+        if self._side is not None and self._side_dirty:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_dirty = False
+        while self._side_pending:
+            ptr, key, _ = self._side_pending.popleft()
+            self._pool[key].append(self._pool_flat[ptr])
+        self._side_tag.clear()
 
     def vec(self, owner, tag, n, dtype=torch.float32) -> torch.Tensor:
         key = (id(owner), tag, n, dtype)
@@ -277,12 +342,29 @@ class _ConvExec:
         return cs, cq, rows
 
     def bwd_w(self, ctx: Ctx, x: TS, dy: TS):
-        """weight (+bias) gradient into the .grad views of the flat gradient buffer"""
+        """weight (+bias) gradient into the .grad views of the flat gradient buffer -- on the side stream when ctx.wgrad_overlap (the
+        caller goes on with the input gradient; ctx.side_join() before anything reads the .grad views)"""
+        side = ctx.side()
+        if side is None or 2e-9 * dy.P * x.C * dy.C * self.ks * self.ks > ctx.wgrad_overlap_gflop:
+            self._bwd_w(ctx, x, dy, ctx.workspace)
+            return
+        ready = torch.cuda.Event()
+        ready.record()                          # dy is complete on the main stream (x is a forward activation: long complete)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            self._bwd_w(ctx, x, dy, ctx.side_workspace)
+            done = torch.cuda.Event()
+            done.record()
+        ctx._side_dirty = True
+        ctx.side_reads(dy, done)
+        ctx.side_reads(x, done)
+
+    def _bwd_w(self, ctx: Ctx, x: TS, dy: TS, workspace):
         w, b = self.conv.weight, self.conv.bias
         n = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)
         if self.gapped:          # gradient of the gapped filter, then its live rows / columns into the parameter's .grad
             self.wsrc()
-            ops.conv2d_wgrad(x, dy, self._gwpad, self.ks, self.stride, ctx.workspace(n), dbias=None if b is None else self._gbpad)
+            ops.conv2d_wgrad(x, dy, self._gwpad, self.ks, self.stride, workspace(n), dbias=None if b is None else self._gbpad)
             si, _ = self._segs(w.shape[1], self.in_gap)
             so, _ = self._segs(w.shape[0], self.out_gap)
             for lo, po in so:
@@ -291,7 +373,7 @@ class _ConvExec:
                 if b is not None:
                     b.grad[lo].copy_(self._gbpad[po])
             return
-        ops.conv2d_wgrad(x, dy, w.grad, self.ks, self.stride, ctx.workspace(n), dbias=None if b is None else b.grad)
+        ops.conv2d_wgrad(x, dy, w.grad, self.ks, self.stride, workspace(n), dbias=None if b is None else b.grad)
 
     def bwd_x(self, dy: TS, dx: TS, res: Optional[TS] = None, mask: Optional[TS] = None):
         ops.conv2d_dgrad(dy, self.packed(1), dx, self.ks, self.stride, res=res, mask=mask)
