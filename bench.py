@@ -152,6 +152,7 @@ def step_bench(arch, n_in, n_cls, size, batch, dtype, steps, warmup, rank, world
     pr = None
     if probe:
         _ops.CONV_PROBE = pr = _ops.ConvProbe(32 * 10000 + 128 * 10 + 7)
+        pr.exclusive_of = model.ctx._side          # (weight gradients may run on a second stream: the probed launches are timed alone)
     step.comm_events = [] if world > 1 else None
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 5
+#define UNET_ABI_VERSION 6
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -49,10 +49,33 @@ const char* unet_last_error(void);
 #define UNET_BF16 1
 typedef uint16_t unet_bf16;
 
+/* ---------------------------------------------------------------- tuning --
+ * Kernel-selection switches of ONE launch (A/B measurements, cross-checks between independently written kernel families in the tests).
+ * A descriptor's `tuning` pointer may be NULL: the defaults.  The library keeps NO mutable process state: the switches
+ * travel with the descriptor, two callers -- threads, models -- with different tunings do not see each other, every entry point is
+ * re-entrant.  Always start from unet_tuning_default(): a zeroed struct is NOT the default.  Every alternative computes the same result up
+ * to summation order.  Environment overrides of the DEFAULTS, read once at load: UNET_CONV_SPLITK, UNET_T256_SLIVER, UNET_CONV1X1_GEMM. */
+typedef struct {
+    int conv_splitk;        /* 1: the planner may split the reduction of small-grid launches (default); 0: never; n > 1: split launches of
+                               fewer than n full-size tiles */
+    int mfma_shape;         /* fp32 conv: 16 = v_mfma_f32_16x16x4_f32 (default), 32 = v_mfma_f32_32x32x2_f32 with an LDS filter slab */
+    int f32_big_tile;       /* 1: eligible fp32 3x3 launches run on conv_bf16_t256_kernel<.., float> (default); 0: conv_igemm16_kernel */
+    int bf16_big_tile;      /* bf16 conv: 1 = the 256-pixel tile for 3x3 / stride-1 launches from 64 blocks up (default), 0 = off,
+                               2 = the planner order of round 3's first half, 3.. = from 64 (n - 2) blocks up */
+    int t256_tiles_per_wg;  /* consecutive tiles per workgroup of conv_bf16_t256_kernel; 0 = the launcher's choice (default) */
+    int t256_sliver;        /* 1: a 7-tile fp32 block whose last tile holds 1..4 channels multiplies them as a 4x4x1 sliver (default) */
+    int conv1x1_gemm;       /* 1: 1x1 / stride-1 convs of whole chunks on conv1x1_gemm_kernel (default); 0: the implicit-GEMM kernels */
+    int wgrad_mfma_shape;   /* fp32 weight gradient: 32 (default) | 16 (opt-in: loses to wave imbalance) */
+    int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
+    int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */
+    int wgrad_narrow;       /* 1: the narrow-output (80 < Cout <= 112) flattened-tap fp32 weight-gradient kernel (default) */
+} unet_tuning;
+void unet_tuning_default(unet_tuning* t);
+
 /* ------------------------------------------------------------------ conv --
  * Implicit-GEMM convolution on fp32 MFMA, NHWC, no im2col.  Default instruction v_mfma_f32_16x16x4_f32: LDS-staged input halo
  * tile, packed filter tiles global -> VGPR (MFMA operand order); v_mfma_f32_32x32x2_f32 with an LDS filter slab is kept
- * behind unet_set_mfma_shape(32).
+ * behind unet_tuning.mfma_shape = 32.
  * Replaces: every nn.Conv2d of fastai ConvLayer (layers.py) in XResNet
  * (vision/models/xresnet.py), DynamicUnet.middle_conv / UnetBlock.conv1,conv2 /
  * PixelShuffle_ICNR 1x1 / final ResBlock / head (vision/models/unet.py), as
@@ -91,6 +114,7 @@ typedef struct {
     int y_f32;                           /* dtype UNET_BF16 only: y is an fp32 buffer (the logits head feeds the fp32 loss kernels) */
     float* splitk_ws;                    /* optional scratch for split-K launches (small grid, long reduction): fp32, 16-byte aligned, */
     size_t splitk_ws_floats;             /*   >= unet_conv2d_splitk_workspace(desc) floats; NULL / too small = never split this launch */
+    const unet_tuning* tuning;           /* NULL = defaults */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */
@@ -99,22 +123,13 @@ int unet_conv2d(const unet_conv_desc* d, void* stream);
 /* floats of split-K scratch the planner would use for this desc (0: it does not split).  A launch whose output grid cannot fill the chip
  * although its reduction is long (deep low-resolution stages, small batches) is cut into `splits` contiguous ranges of reduction chunks;
  * partial sums are added in split order by a second kernel that applies bias / residual / ReLU / mask: deterministic, and shorter
- * accumulation chains.  unet_set_conv_splitk(0) switches it off process-wide (A/B knob). */
+ * accumulation chains.  unet_tuning.conv_splitk = 0 switches it off for a launch (A/B). */
 size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d);
-int unet_set_conv_splitk(int on);
 /* which kernel instantiation serves this desc: TW*10000 + BN*10 + (stride-2 halo variant) + 1000000 * splits -- for profilers / bench.py;
  * ...7 / ...6: the 256-pixel tile of the bf16 path (3x3 stride 1: conv_bf16_t256_kernel; 7 = 128-wide blocks, 32-pixel patches, >= 512 blocks,
- * 6 = its narrow-block / 16-pixel-patch / small-grid launches); 9: conv1x1_smallk_kernel (1x1, reduction of <= 8 channels) */
+ * 6 = its narrow-block / 16-pixel-patch / small-grid launches); 9: conv1x1_smallk_kernel (1x1, reduction of <= 8 channels);
+ * 8: conv1x1_gemm_kernel (1x1 stride 1, whole reduction chunks, >= 256 blocks: the flat-pixel GEMM without LDS staging) */
 int unet_conv2d_variant(const unet_conv_desc* d);
-/* MFMA instruction shape used by the conv / wgrad kernels: 16 (v_mfma_f32_16x16x4_f32, 16-channel granularity, default)
- * or 32 (v_mfma_f32_32x32x2_f32).  Process-wide tuning knob; results are identical up to summation order. */
-int unet_set_mfma_shape(int shape);
-/* the same for the weight-gradient kernels; also the A/B switch of the bf16 weight gradient: -1 = wgrad_bf16_kernel (2 x 2 tiles per wave) for every
- * shape, -2 = wgrad_bf16_k4_kernel for 3x3 / 1x1 stride-1 launches with 32-pixel-wide tiles (default); identical results */
-int unet_set_wgrad_mfma_shape(int shape);
-int unet_set_wgrad_1x1(int on);      /* 128x128-tiled GEMM kernel for 1x1 weight gradients on/off (default on) */
-int unet_set_wgrad_narrow(int on);   /* narrow-output (Cout <= 112) weight-gradient kernel on/off (default on) */
-
 /* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].
  * mode 0 (FWD):   wp[tap][chunk][coutPad][16]  reduction over Cin
  * mode 1 (DGRAD): wp[tap][chunk][cinPad][16]   reduction over Cout
@@ -144,10 +159,6 @@ typedef struct {
 size_t unet_pack_batch_table_bytes(int njobs);
 int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int dtype, void* table_host, unsigned* total_blocks);
 int unet_pack_batch_run(const void* table_dev, int njobs, unsigned total_blocks, int dtype, void* stream);
-/* bf16 conv: 256-pixel x 128-channel workgroup tile for large 3x3 layers on/off (default on; A/B knob: the input gradient sums its taps in the
- * opposite order on the large tile, everything else is identical); 100 + n: on, with n consecutive tiles per workgroup instead of the launcher's choice */
-int unet_set_bf16_big_tile(int on);
-
 /* weight gradient dW[Cout,Cin,ks,ks] (torch layout) = sum_pixels dy (x) x.
  * Replaces the autograd weight-gradient of the same nn.Conv2d modules.
  * workspace holds split-K partials; query its size (floats) first. */
@@ -160,6 +171,7 @@ typedef struct {
     float* workspace; size_t workspace_floats;
     int accumulate;                      /* 0: dw = result, 1: dw += result */
     int dtype;                           /* UNET_F32 (default 0) | UNET_BF16: storage type of x and dy; dw, dbias and the workspace are fp32 */
+    const unet_tuning* tuning;           /* NULL = defaults */
 } unet_wgrad_desc;
 size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d);
 int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream);

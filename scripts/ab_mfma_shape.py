@@ -1,6 +1,7 @@
 """A/B of the two MFMA shapes on the whole training step (one process, interleaved rounds)."""
 import sys, time, torch
 sys.path.insert(0, '.')
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 from unet_amd._lib import lib
 from unet_amd.model import HipDynamicUnet
 from unet_amd.optimizer import FlatAdam
@@ -15,7 +16,7 @@ torch.cuda.synchronize()
 res = {0: [], 1: []}
 for rnd in range(4):
     for shape in (0, 1):
-        lib.unet_set_wgrad_narrow(shape)
+        _knobs.set_knob("wgrad_narrow", shape)
         step(x, y); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3): step(x, y)

@@ -1,7 +1,8 @@
-"""Isolated bf16 3x3 launches at 16 x 512^2 under several settings of unet_set_bf16_big_tile on one box, interleaved (1 = the 256-pixel tile with its
+"""Isolated bf16 3x3 launches at 16 x 512^2 under several settings of unet_tuning.bf16_big_tile on one box, interleaved (1 = the 256-pixel tile with its
 own choice of tiles per workgroup, 100 + n = n tiles per workgroup, 0 = the 128-pixel tile): python scripts/conv_ab.py 1 101 108 [reps]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import torch
 from unet_amd import ops
 from unet_amd.ops import TS
@@ -38,9 +39,9 @@ res = {}
 for r in range(reps):
     for k in shapes:
         for v in settings:
-            L.lib.unet_set_bf16_big_tile(v)
+            _knobs.set_knob("bf16_big_tile", v)
             res.setdefault((k, v), []).append(run(k))
 for k in shapes:
     fl = 2.0 * N * H * H * k[0] * k[1] * 9
     print(f"{k[0]:4d}->{k[1]:4d} " + "   ".join(f"[{v}] {min(res[(k, v)]):6.3f} ms {fl / min(res[(k, v)]) / 1e9:6.0f} TF" for v in settings), flush=True)
-L.lib.unet_set_bf16_big_tile(1)
+_knobs.set_knob("bf16_big_tile", 1)

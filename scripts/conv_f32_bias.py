@@ -1,6 +1,7 @@
 """fp32 3x3 convolutions of the cfg2 decoder with bias + ReLU (isolated launches): python scripts/conv_f32_bias.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import torch
 from unet_amd import ops
 from unet_amd.ops import TS
@@ -9,7 +10,7 @@ N = 16
 g = torch.Generator(device="cuda").manual_seed(0)
 import unet_amd._lib as L
 SW = int(sys.argv[1]) if len(sys.argv) > 1 else -2          # -2: the fp32 256-pixel tile on (default), -1: off
-L.lib.unet_set_mfma_shape(SW)
+_knobs.set_knob("mfma_shape", SW)
 for H, Cin, Cout in [(512, 96, 96), (256, 192, 96), (256, 96, 96), (256, 96, 128), (128, 256, 256), (128, 64, 64), (64, 384, 384), (64, 128, 128), (32, 512, 512), (32, 256, 256), (32, 128, 128), (16, 512, 512), (16, 1024, 512), (16, 512, 1024), (16, 256, 256)]:
     x = TS(torch.randn((N, H, H, ops.rup4(Cin)), device="cuda", generator=g), 0, Cin)
     y = TS(torch.empty((N, H, H, ops.rup4(Cout)), device="cuda"), 0, Cout)

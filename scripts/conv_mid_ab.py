@@ -1,6 +1,7 @@
 """bf16 3x3 convolutions of the deep stages (small grids) under several thresholds for the 256-pixel tile: python scripts/conv_mid_ab.py 1 4 6"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import torch
 from unet_amd import ops
 from unet_amd.ops import TS
@@ -36,11 +37,11 @@ res = {}
 for r in range(3):
     for k in shapes:
         for v in settings:
-            L.lib.unet_set_bf16_big_tile(v)
+            _knobs.set_knob("bf16_big_tile", v)
             res.setdefault((k, v), []).append(run(k))
             res[(k, v, "var")] = ops.conv2d_variant(data[k][0], data[k][2], data[k][1], 3, 1)
 for k in shapes:
     H, Cin, Cout = k
     fl = 2.0 * N * H * H * Cin * Cout * 9
     print(f"{H:3d}^2 {Cin:4d}->{Cout:4d}  " + "   ".join(f"[{v}] {min(res[(k, v)]) * 1e3:6.1f} us {fl / min(res[(k, v)]) / 1e9:5.0f} TF (var {res[(k, v, 'var')]})" for v in settings), flush=True)
-L.lib.unet_set_bf16_big_tile(1)
+_knobs.set_knob("bf16_big_tile", 1)

@@ -1,6 +1,7 @@
 """Per-layer micro-benchmark of conv fwd / dgrad / wgrad on the cfg2 layer shapes (B=16), both MFMA shapes."""
 import sys, torch
 sys.path.insert(0, '.')
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 from unet_amd import ops
 from unet_amd._lib import lib
 from unet_amd.ops import TS
@@ -33,7 +34,7 @@ for name, H, Cin, Cout, ks in LAYERS:
     gf = 2.0 * B * H * H * Cin * Cout * ks * ks / 1e9
     row = f"{name:8s} {gf:8.1f} GF |"
     for shape in (32, 16):
-        lib.unet_set_mfma_shape(shape); lib.unet_set_wgrad_mfma_shape(32); lib.unet_set_wgrad_narrow(1 if shape == 16 else 0)
+        _knobs.set_knob("mfma_shape", shape); _knobs.set_knob("wgrad_mfma_shape", 32); _knobs.set_knob("wgrad_narrow", 1 if shape == 16 else 0)
         tf = timeit(lambda: ops.conv2d(x, wf, y, ks, 1))
         td = timeit(lambda: ops.conv2d_dgrad(y, wd, x, ks, 1))
         tw = timeit(lambda: ops.conv2d_wgrad(x, y, dw, ks, 1, ws))

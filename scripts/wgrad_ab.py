@@ -1,6 +1,7 @@
 """bf16 3x3 weight gradients at 16 x 512^2 / 256^2 / 128^2: wgrad_bf16_k4_kernel (on) against wgrad_bf16_kernel<32,1,3> (off), interleaved on one box"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import torch
 from unet_amd import ops
 from unet_amd.ops import TS
@@ -37,7 +38,7 @@ ref = {}
 for r in range(3):
     for k in shapes:
         for v in (-2, -1):
-            L.lib.unet_set_wgrad_mfma_shape(v)
+            _knobs.set_knob("wgrad_mfma_shape", v)
             res.setdefault((k, v), []).append(run(k))
             if r == 0:
                 ref[(k, v)] = data[k][2].clone()
@@ -46,4 +47,4 @@ for k in shapes:
     fl = 2.0 * N * H * H * Cin * Cout * ks * ks
     d = (ref[(k, -2)] - ref[(k, -1)]).abs().max().item() / ref[(k, -1)].abs().max().item()
     print(f"{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks}  k4 {min(res[(k, -2)]):6.3f} ms {fl / min(res[(k, -2)]) / 1e9:6.0f} TF   2x2 {min(res[(k, -1)]):6.3f} ms {fl / min(res[(k, -1)]) / 1e9:6.0f} TF   (incl. bias gradient and reduce)  rel diff {d:.1e}", flush=True)
-L.lib.unet_set_wgrad_mfma_shape(-2)
+_knobs.set_knob("wgrad_mfma_shape", -2)

@@ -9,6 +9,7 @@ Network level, against the fp32 CPU oracle (xresnet34 4->5, the headline geometr
     training loss    within 5e-3 relative
     gradients        cosine similarity >= 0.99 for the whole flat gradient and >= 0.97 for every decoder tensor
 """
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import pytest
 import torch
 import torch.nn.functional as F
@@ -112,6 +113,45 @@ def test_conv_forward_dgrad_wgrad_bf16(case):
     assert (db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max().item() <= 5e-5 * dy.double().sum((0, 2, 3)).abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("case", [(96, 384, 64, 64, 8), (64, 256, 61, 67, 5), (256, 96, 128, 128, 2), (32, 200, 128, 128, 2)])
+def test_conv1x1_gemm_kernel_bf16(case):
+    """conv1x1_gemm_kernel<bf16> (variant 8): 1x1 / stride 1 over whole 32-channel chunks as a flat-pixel GEMM; bf16 output within one rounding
+    of the fp64 result on bf16-representable operands, fp32 output (y_f32) to 5e-5; gradient form with residual + mask"""
+    from unet_amd import ops
+    Cin, Cout, H, W, N = case
+    g = torch.Generator().manual_seed(Cin + 7 * Cout)
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    r = _bf(torch.randn(N, Cout, H, W, generator=g))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double())
+    xt, rt = _ts(x, cs=Cin + 16, co=8), _ts(r)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    yt = _empty(N, H, W, Cout, cs=ops.rupv(Cout, torch.bfloat16) + 16, co=8)
+    yf = _empty(N, H, W, Cout, dtype=torch.float32)
+    assert ops.conv2d_variant(xt, wp, yt, 1) == 8
+    ops.conv2d(xt, wp, yt, 1, bias=b.cuda(), res=rt, relu=True)
+    ops.conv2d(xt, wp, yf, 1, bias=b.cuda())
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (_back(yt).double() - ref).abs().max().item() <= 2.0 ** -8 * scale
+    pre = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    assert (_back(yf).double() - pre).abs().max().item() <= 5e-5 * pre.abs().max().item()
+    assert bool((yt.buf[..., :8] == 7.25).all()) and bool((yt.buf[..., 8 + ops.rupv(Cout, torch.bfloat16):] == 7.25).all())
+    if Cout % 32 == 0 and Cin >= 128:
+        dy = _bf(torch.randn(N, Cout, H, W, generator=g))
+        act = _bf(torch.relu(torch.randn(N, Cin, H, W, generator=g)))
+        extra = _bf(torch.randn(N, Cin, H, W, generator=g))
+        dref = (torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy.double()) + extra.double()) * (act > 0)
+        dxt = _empty(N, H, W, Cin)
+        wpd = ops.pack_weights(w.cuda(), 1, dtype=torch.bfloat16)
+        dyt = _ts(dy)
+        assert ops.conv2d_variant(dyt, wpd, dxt, 1, 1, kind=1) == 8
+        ops.conv2d_dgrad(dyt, wpd, dxt, 1, 1, res=_ts(extra), mask=_ts(act))
+        torch.cuda.synchronize()
+        assert (_back(dxt).double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 512, 512, 3), (1, 16, 16, 1024, 200, 3), (1, 16, 16, 2048, 96, 1), (2, 8, 8, 264, 100, 3)])
 def test_conv_splitk_bf16(case):
     """split-K with bf16 storage: fp32 partial slabs, one rounding to bf16 in the reduce kernel -- the same numbers as the unsplit launch up to
@@ -129,7 +169,7 @@ def test_conv_splitk_bf16(case):
     wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
     res = {}
     for on in (1, 0):
-        lib.unet_set_conv_splitk(on)
+        _knobs.set_knob("conv_splitk", on)
         try:
             yt = _empty(N, H, W, Cout)
             yf = _empty(N, H, W, Cout, dtype=torch.float32)
@@ -138,7 +178,7 @@ def test_conv_splitk_bf16(case):
             ops.conv2d(xt, wp, yf, ks, bias=b.cuda())
             torch.cuda.synchronize()
         finally:
-            lib.unet_set_conv_splitk(1)
+            _knobs.set_knob("conv_splitk", 1)
         assert (var >= 2000000) == bool(on) or Cout > 128, (case, on, var)
         res[on] = (_back(yt), _back(yf))
     scale = ref.abs().max().item()

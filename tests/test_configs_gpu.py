@@ -14,6 +14,7 @@ to fp64 as the fp32 CPU oracle is (or within the stated absolute bar), tensor by
   SelfAttention at cfg2 size (4096 positions).
 Reference call sites: train.py:247-250 (fit_one_cycle step), predict.py:193-203,232 (probabilities -> argmax).
 """
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import copy
 
 import pytest
@@ -358,10 +359,10 @@ def test_cfg4_training_step_properties_at_full_size(cfg4):
     l0b, g0b = step()
     assert l0 == l0b and torch.equal(g0, g0b)
     try:
-        lib.unet_set_mfma_shape(32)
+        _knobs.set_knob("mfma_shape", 32)
         l1, g1 = step()
     finally:
-        lib.unet_set_mfma_shape(16)
+        _knobs.set_knob("mfma_shape", 16)
     n0 = g0.double().norm().item()
     assert torch.isfinite(g0).all() and n0 > 0
     # a different conv kernel changes the summation order of every activation: ReLU sign flips of ~0 pre-activations move single

@@ -11,6 +11,7 @@ The oracle is too slow for a batch of 16 full tiles inside the test budget, so t
          dimension vs 64x64-tiled) agree on the whole flat gradient of a full training step, and so do the two conv kernels;
        * linearity of the input-gradient program: dgrad(a * dy) == a * dgrad(dy) through the fused backward of a conv.
 """
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import pytest
 import torch
 
@@ -88,12 +89,12 @@ def test_two_conv_kernels_agree_on_full_batch_logits(pair, batch):
     x = batch[0].cuda()
     try:
         with torch.no_grad():
-            lib.unet_set_mfma_shape(16)
+            _knobs.set_knob("mfma_shape", 16)
             z16 = model(x).clone()
-            lib.unet_set_mfma_shape(32)
+            _knobs.set_knob("mfma_shape", 32)
             z32 = model(x).clone()
     finally:
-        lib.unet_set_mfma_shape(16)
+        _knobs.set_knob("mfma_shape", 16)
     scale = z16.abs().max().item()
     err = (z16 - z32).abs().max().item()
     assert err < 2e-5 * max(1.0, scale)
@@ -121,15 +122,15 @@ def test_full_training_step_gradient_under_both_kernel_families(pair, batch):
     l0b, g0b = _flat_grad_of_step(model, x, y, w)
     assert l0 == l0b and torch.equal(g0, g0b), "the step is not deterministic run to run"
     try:
-        lib.unet_set_wgrad_narrow(0)
+        _knobs.set_knob("wgrad_narrow", 0)
         l1, g1 = _flat_grad_of_step(model, x, y, w)
     finally:
-        lib.unet_set_wgrad_narrow(1)
+        _knobs.set_knob("wgrad_narrow", 1)
     try:
-        lib.unet_set_mfma_shape(32)
+        _knobs.set_knob("mfma_shape", 32)
         l2, g2 = _flat_grad_of_step(model, x, y, w)
     finally:
-        lib.unet_set_mfma_shape(16)
+        _knobs.set_knob("mfma_shape", 16)
     n0 = g0.double().norm().item()
     assert abs(l1 - l0) <= 1e-6 * abs(l0) and ((g1 - g0).double().norm().item() / n0) < 1e-5
     # a different conv kernel changes the summation order of every activation: ReLU sign flips of ~0 pre-activations can move

@@ -23,7 +23,11 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(L.lib, s), s
-    assert L.lib.unet_abi_version() == 5
+    assert L.lib.unet_abi_version() == 6
+    # version 6: no process-wide setters any more -- the kernel-selection switches travel with the descriptors (unet_tuning)
+    assert not [s for s in syms if s.startswith("unet_set_")]
+    t = L.Tuning.default()
+    assert (t.conv_splitk, t.mfma_shape, t.f32_big_tile, t.bf16_big_tile, t.wgrad_mfma_shape) == (1, 16, 1, 1, 32)
     # pure host-side queries work without a GPU
     assert L.lib.unet_pack_weights_size(96, 100, 3, 0) == 9 * 7 * 128 * 16
     # 100 output channels = 6 tiles of 16 + a 4-channel sliver image [tap][chunk][4][16] behind the main one
@@ -178,6 +182,37 @@ def test_planner_keeps_oversized_fp32_images_off_the_buffer_descriptor_kernel():
     assert variant(1792, 196, 96, L.F32) % 10 == 0          # 2.52e9 bytes: generic kernel
     assert variant(1792, 200, 96, L.BF16) % 10 == 7         # 1.28e9 bytes in bf16 storage
     assert variant(2048, 128, 128, L.F32) % 10 == 0         # 2^31 bytes exactly
+
+
+def test_tuning_travels_with_the_descriptor_and_the_library_keeps_no_state():
+    """two descriptors of the same problem with different unet_tuning structs plan differently IN THE SAME PROCESS, interleaved, and a NULL
+    pointer means the defaults before and after (no global state; up to ABI version 5 these were process-wide setters)"""
+    import ctypes as C
+    import unet_amd._lib as L
+    from unet_amd import ops
+
+    def desc(tuning=None):
+        d = L.ConvDesc()
+        for k, v in dict(x=0x100000, x_cs=128, x_co=0, wp=0x200000, y=0x300000, y_cs=128, y_co=0, N=2, IH=256, IW=256, Cin=128, OH=256,
+                         OW=256, Cout=128, ks=3, stride=1, kind=0, flags=0, dtype=L.F32).items():
+            setattr(d, k, v)
+        if tuning is not None:
+            d.tuning = C.pointer(tuning)
+        return d
+
+    plain, off = desc(), desc(L.Tuning.default(f32_big_tile=0))
+    for _ in range(2):
+        assert L.lib.unet_conv2d_variant(C.byref(plain)) % 10 == 7
+        assert L.lib.unet_conv2d_variant(C.byref(off)) % 10 == 0
+    bad = desc(L.Tuning())          # a zeroed struct is not the default: refused with a message, not silently planned
+    assert L.lib.unet_conv2d_variant(C.byref(bad)) == -1 and b"unet_tuning_default" in L.lib.unet_last_error()
+    # the Python-side context manager: thread-local, nests, leaves nothing behind
+    assert ops._tuning_ptr() is None
+    with ops.tuning(conv_splitk=0) as t0:
+        with ops.tuning(mfma_shape=32) as t1:
+            assert (t1.conv_splitk, t1.mfma_shape) == (0, 32)
+        assert (t0.conv_splitk, t0.mfma_shape) == (0, 16) and ops._tuning_ptr().contents.conv_splitk == 0
+    assert ops._tuning_ptr() is None
 
 
 def test_params_and_main_surface(monkeypatch):

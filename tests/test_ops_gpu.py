@@ -4,6 +4,7 @@ Tolerances: fp32 everywhere.  Convolutions reduce over up to 9*1024 products in 
 different order than oneDNN, so they are compared at rtol 2e-4 of the tensor's max
 magnitude; data movement / pooling / masks are bit exact.
 """
+from unet_amd import ops as _knobs  # noqa: E402  (unet_tuning switches of this thread's launches)
 import pytest
 import torch
 import torch.nn.functional as F
@@ -102,11 +103,11 @@ def test_conv_sliver_last_channels_on_mfma4x4(ops, Cin, Cout):
     tiles; then the input-gradient form (residual + ReLU mask) of a conv whose INPUT width is such a count."""
     N, H, W = 2, 150, 170                      # 400+ blocks of 128 pixels: the planner keeps the 128 x 128 tile
     from unet_amd._lib import lib
-    lib.unet_set_mfma_shape(-1)                # (large grids now run the fp32 form of the 256-pixel kernel, 7 channel tiles for 100 outputs: this
+    _knobs.set_knob("mfma_shape", -1)                # (large grids now run the fp32 form of the 256-pixel kernel, 7 channel tiles for 100 outputs: this
     try:                                       # test is about the sliver instantiation that smaller grids keep using)
         _sliver_case(ops, Cin, Cout, N, H, W)
     finally:
-        lib.unet_set_mfma_shape(-2)
+        _knobs.set_knob("mfma_shape", -2)
 
 
 def _sliver_case(ops, Cin, Cout, N, H, W):
@@ -195,14 +196,14 @@ def test_conv_splitk(ops, case):
     wp = ops.pack_weights(w.cuda(), 0)
     outs, errs = [], []
     for on in (1, 0, 1):
-        lib.unet_set_conv_splitk(on)
+        _knobs.set_knob("conv_splitk", on)
         try:
             yt = empty_ts(N, H, W, Cout, cs=Cout + 8 + (-Cout) % 4, co=8)
             var = ops.conv2d_variant(xt, wp, yt, ks)
             ops.conv2d(xt, wp, yt, ks, bias=b.cuda(), res=rt, mask=mt, relu=True)
             torch.cuda.synchronize()
         finally:
-            lib.unet_set_conv_splitk(1)
+            _knobs.set_knob("conv_splitk", 1)
         assert outside_untouched(yt)
         got = from_ts(yt)
         outs.append(got)
@@ -304,7 +305,7 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
 ])
 def test_conv_f32_t256_kernel(ops, case):
     """forward with bias + residual + ReLU into a channel slice and the input gradient with residual + mask on the fp32 form of the 256-pixel
-    kernel (variant ...7 / ...6), against torch on the CPU and against the generic kernel (unet_set_mfma_shape(-1)) on the same operands.
+    kernel (variant ...7 / ...6), against torch on the CPU and against the generic kernel (unet_tuning.f32_big_tile = 0) on the same operands.
     Output widths of 16 n + 1..4 in a 7-tile block run their last channels as a v_mfma_f32_4x4x1 sliver (conv_bf16_t256_kernel<7, 32, float, true>:
     four partial chains per output element, summed in a fixed order) -- in both directions for the 100 -> 100 case."""
     from unet_amd._lib import lib
@@ -319,7 +320,7 @@ def test_conv_f32_t256_kernel(ops, case):
     wp = ops.pack_weights(w.cuda(), 0)
     outs = []
     for sw in (-2, -1):
-        lib.unet_set_mfma_shape(sw)
+        _knobs.set_knob("mfma_shape", sw)
         try:
             yt = empty_ts(N, H, W, Cout, cs=ops.rup4(Cout) + 12, co=8)
             if sw == -2:
@@ -329,7 +330,7 @@ def test_conv_f32_t256_kernel(ops, case):
             assert outside_untouched(yt)
             outs.append(from_ts(yt))
         finally:
-            lib.unet_set_mfma_shape(-2)
+            _knobs.set_knob("mfma_shape", -2)
     assert_close(outs[0], ref, rtol=2e-4, what="t256 f32 fwd")
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * ref.abs().max().item()          # same k-ordered chains, possibly another MFMA-internal order
     dy = torch.randn(N, Cout, H, W, generator=g)
@@ -342,6 +343,48 @@ def test_conv_f32_t256_kernel(ops, case):
         ops.conv2d_dgrad(to_ts(dy), wpd, dxt, 3, 1, res=to_ts(extra), mask=to_ts(act))
         torch.cuda.synchronize()
         assert_close(from_ts(dxt), dref, rtol=2e-4, what="t256 f32 dgrad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (Cin, Cout, H, W, N): conv1x1_gemm_kernel<float> (variant 8) -- 1x1 / stride 1, whole 16-channel chunks, >= 256 blocks of 128 pixels x 128 channels
+    (96, 384, 64, 64, 8),       # the final PixelShuffle conv's shape family: 3 channel blocks
+    (64, 256, 61, 67, 5),       # ragged pixel count (20435 = 159 x 128 + 83: the last pixel tile is partly outside)
+    (256, 96, 128, 128, 2),     # a narrow block of 6 tiles dealt 3 + 3 to the two waves (the 384 -> 96 input gradient's shape family)
+    (16, 200, 128, 128, 2),     # one reduction chunk; 128 + 72 channels = two launches of ops.conv2d (channel ranges)
+    (48, 132, 128, 128, 3),     # three chunks (odd count: the second register set ends on a repeated load), last block 4 channels wide
+])
+def test_conv1x1_gemm_kernel(ops, case):
+    """forward form with bias + residual + ReLU into a channel slice and gradient form with residual + mask on the flat-pixel GEMM kernel,
+    against torch on the CPU and against the implicit-GEMM kernel (UNET_CONV1X1_GEMM=0 is the process-wide switch; here: a grid below
+    the kernel's 256-block threshold cannot be forced, so the cross-check is torch alone)"""
+    Cin, Cout, H, W, N = case
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x, w, b) + r)
+    xt, rt = to_ts(x, cs=ops.rup4(Cin) + 8, co=4), to_ts(r, cs=ops.rup4(Cout) + 4, co=4)
+    wp = ops.pack_weights(w.cuda(), 0)
+    yt = empty_ts(N, H, W, Cout, cs=ops.rup4(Cout) + 12, co=8)
+    assert ops.conv2d_variant(xt, wp, yt, 1, 1) == 8
+    ops.conv2d(xt, wp, yt, 1, 1, bias=b.cuda(), res=rt, relu=True)
+    torch.cuda.synchronize()
+    assert outside_untouched(yt)
+    assert_close(from_ts(yt), ref, rtol=2e-4, what="1x1 gemm fwd")
+    if Cout % 16 == 0:          # the gradient form reduces over Cout: whole chunks only
+        dy = torch.randn(N, Cout, H, W, generator=g)
+        act = F.relu(torch.randn(N, Cin, H, W, generator=g))
+        extra = torch.randn(N, Cin, H, W, generator=g)
+        dref = (torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy) + extra) * (act > 0)
+        dxt = empty_ts(N, H, W, Cin)
+        wpd = ops.pack_weights(w.cuda(), 1)
+        dyt = to_ts(dy)
+        assert ops.conv2d_variant(dyt, wpd, dxt, 1, 1, kind=1) == 8 or Cin < 128
+        ops.conv2d_dgrad(dyt, wpd, dxt, 1, 1, res=to_ts(extra), mask=to_ts(act))
+        torch.cuda.synchronize()
+        assert_close(from_ts(dxt), dref, rtol=2e-4, what="1x1 gemm dgrad")
 
 
 WGRAD_CASES = [
@@ -653,7 +696,7 @@ def test_bad_arguments_fail_loudly(ops):
 def test_conv_mfma_shapes_agree(ops, shape):
     """both MFMA instruction shapes (16x16x4 with tile skipping, 32x32x2) give the reference result on the awkward widths"""
     from unet_amd._lib import lib
-    assert lib.unet_set_mfma_shape(shape) == 0
+    assert _knobs.set_knob("mfma_shape", shape) == 0
     try:
         for case in [(2, 40, 48, 100, 100, 3, 1), (1, 16, 16, 192, 96, 3, 1), (1, 32, 32, 99, 2, 1, 1), (2, 26, 26, 64, 128, 3, 2),
                      (1, 24, 24, 36, 100, 3, 1), (1, 16, 16, 20, 52, 3, 1)]:
@@ -676,13 +719,13 @@ def test_conv_mfma_shapes_agree(ops, shape):
             assert_close(from_ts(dxt), torch.nn.grad.conv2d_input(x.shape, w, dy, stride=stride, padding=(ks - 1) // 2), rtol=2e-4,
                          what=f"mf{shape} dgrad {case}")
     finally:
-        lib.unet_set_mfma_shape(16)
+        _knobs.set_knob("mfma_shape", 16)
 
 
 def test_wgrad_mfma_shapes_agree(ops):
     from unet_amd._lib import lib
     for shape in (32, 16):
-        assert lib.unet_set_wgrad_mfma_shape(shape) == 0
+        assert _knobs.set_knob("wgrad_mfma_shape", shape) == 0
         try:
             for case in [(2, 40, 48, 100, 100, 3, 1), (1, 16, 16, 192, 96, 3, 1), (2, 26, 26, 64, 128, 3, 2), (2, 16, 16, 100, 5, 1, 1),
                          (1, 24, 24, 36, 52, 3, 1)]:
@@ -700,7 +743,7 @@ def test_wgrad_mfma_shapes_agree(ops):
                 torch.cuda.synchronize()
                 assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"wgrad mf{shape} {case}")
         finally:
-            lib.unet_set_wgrad_mfma_shape(32)
+            _knobs.set_knob("wgrad_mfma_shape", 32)
 
 
 def test_row_softmax_and_strided_pack(ops):
@@ -754,11 +797,11 @@ def test_wgrad_narrow_kernel(ops, narrow):
     """narrow-output weight gradient (80 < Cout <= 112, 3x3 s1, W >= 32; default on) and its 64x64-tiled fallback on the same
     cases against torch, incl. bias gradient, ragged tiles and input-channel chunking"""
     from unet_amd._lib import lib
-    lib.unet_set_wgrad_narrow(narrow)
+    _knobs.set_knob("wgrad_narrow", narrow)
     try:
         _narrow_cases(ops)
     finally:
-        lib.unet_set_wgrad_narrow(1)
+        _knobs.set_knob("wgrad_narrow", 1)
 
 
 def _narrow_cases(ops):

@@ -26,6 +26,22 @@ c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
 
 
+class Tuning(C.Structure):
+    """unet_tuning: the kernel-selection switches of one launch (include/unet_hip.h).  Start from Tuning.default()."""
+    _fields_ = [(n, C.c_int) for n in ("conv_splitk", "mfma_shape", "f32_big_tile", "bf16_big_tile", "t256_tiles_per_wg", "t256_sliver",
+                                       "conv1x1_gemm", "wgrad_mfma_shape", "wgrad_bf16_k4", "wgrad_1x1", "wgrad_narrow")]
+
+    @classmethod
+    def default(cls, **over) -> "Tuning":
+        t = cls()
+        lib.unet_tuning_default(C.byref(t))
+        for k, v in over.items():
+            if k not in dict(cls._fields_):
+                raise KeyError(f"unet_tuning has no field {k!r}")
+            setattr(t, k, int(v))
+        return t
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", vp), ("x_cs", C.c_int), ("x_co", C.c_int),
@@ -44,6 +60,7 @@ class ConvDesc(C.Structure):
         ("wp_img_stride", C.c_longlong),
         ("dtype", C.c_int), ("y_f32", C.c_int),
         ("splitk_ws", vp), ("splitk_ws_floats", C.c_size_t),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -58,6 +75,7 @@ class WgradDesc(C.Structure):
         ("workspace", vp), ("workspace_floats", C.c_size_t),
         ("accumulate", C.c_int),
         ("dtype", C.c_int),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -94,12 +112,7 @@ _sig = {
     "unet_conv2d": (i, [C.POINTER(ConvDesc), vp]),
     "unet_conv2d_variant": (i, [C.POINTER(ConvDesc)]),
     "unet_conv2d_splitk_workspace": (sz, [C.POINTER(ConvDesc)]),
-    "unet_set_conv_splitk": (i, [i]),
-    "unet_set_mfma_shape": (i, [i]),
-    "unet_set_wgrad_mfma_shape": (i, [i]),
-    "unet_set_wgrad_narrow": (i, [i]),
-    "unet_set_wgrad_1x1": (i, [i]),
-    "unet_set_bf16_big_tile": (i, [i]),
+    "unet_tuning_default": (None, [C.POINTER(Tuning)]),
     "unet_pack_batch_table_bytes": (sz, [i]),
     "unet_pack_batch_build": (i, [C.POINTER(PackJob), i, i, vp, C.POINTER(C.c_uint)]),
     "unet_pack_batch_run": (i, [vp, i, C.c_uint, i, vp]),
@@ -171,7 +184,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 5:
+if lib.unet_abi_version() != 6:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 
@@ -184,7 +197,3 @@ def check(rc: int, what: str = "") -> None:
         msg = lib.unet_last_error().decode(errors="replace")
         raise UnetHipError(f"{what}: rc={rc}: {msg}")
 
-
-# A/B knobs from the environment (measurements inside one gpurun call): UNET_CONV_SPLITK=0 switches the split-K planner off
-if os.environ.get("UNET_CONV_SPLITK") is not None:
-    lib.unet_set_conv_splitk(int(os.environ["UNET_CONV_SPLITK"]))

@@ -63,3 +63,9 @@ static inline int ew_grid(long long work_items, int block) {
 }
 
 }  // namespace unet
+
+namespace unetconv {
+// the switches of a launch: the descriptor's struct or the defaults (read-only after load; env overrides: conv_igemm.hip)
+const unet_tuning& tuning_defaults();
+static inline unet_tuning tuning_of(const unet_tuning* t) { return t != nullptr ? *t : tuning_defaults(); }
+}  // namespace unetconv

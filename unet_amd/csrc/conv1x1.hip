@@ -1,0 +1,191 @@
+// conv1x1_gemm_kernel: 1x1 / stride-1 convolutions whose reduction is whole 64-byte chunks -- the PixelShuffle_ICNR convs of the decoder
+// (reference train.py:141, blur=True: ConvLayer(ni, 4 nf, ks=1) in front of every PixelShuffle), forward and input gradient, and the
+// identity-path convs of the encoder ResBlocks -- as what they are: a GEMM over FLAT pixels, Y[p][co] = sum_ci X[p][ci] W[co][ci].
+//
+// The implicit-GEMM conv kernels treat them as a one-tap filter: a halo tile of the pixel patch goes global -> registers -> LDS -> registers
+// behind one barrier per 64-byte chunk, with nine-tap bookkeeping around a single stage (fp32: 4.2 ms per cfg2 step on
+// conv_igemm16_kernel, bf16: 1.5 ms on conv_bf16_kernel at 1.4-2.4 TB/s).  Without a halo there is nothing to share through LDS: the MFMA
+// B operand of lane (l15, kq) -- pixel l15 of a 16-pixel tile, channels VEC kq .. of the chunk -- IS a 16-byte piece of the NHWC row of that
+// pixel, so every wave fetches its operands global -> VGPR directly, one chunk ahead (two register sets, compiler-scheduled plain loads: all
+// of them unconditional, the counts per stage fixed), no LDS, no barrier.
+//   workgroup = 4 waves = 2 (pixel halves) x 2 (channel halves): 128 pixels x 128 channels; wave = 4 x 4 tiles of 16 x 16
+//   filter image = the packed 1x1 image of unet_pack_weights[_bf16]: wp[chunk][outPad][64 B], tile n of a chunk = 1 KiB in operand order
+//   channel tiles dealt round-robin to the two waves of a pixel half (a 96-wide block: 3 + 3 tiles, not 4 + 2)
+//   XCD-aware order: the channel blocks of one pixel tile are consecutive workgroups of one XCD (their pixel rows hit that XCD's L2)
+// Roofline: bf16 storage is HBM-bound (96 -> 384 at 16 x 256^2: 1.0 GB for 77 GFLOP), fp32 MFMA-bound (the same layer: 2.0 GB, 0.49 ms
+// of fp32 MFMA time).  Algorithmic bytes per pixel: EB (Cin + Cout [+ residual / mask]); FLOP per pixel: 2 Cin Cout.
+#include "conv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct G1Args {
+    const char* x; const char* wp; const float* bias; const char* res; const char* mask; char* y;
+    int x_cs, x_co, res_cs, res_co, mask_cs, mask_co, y_cs, y_co;
+    long long P;
+    int nchunks, coutPad, n_base, n_end, Cout, relu, y_f32, ntn;
+    long long ntiles;          // pixel tiles x channel blocks
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
+    constexpr int EB = (int)sizeof(T), KCB = 64;                  // bytes per element / per reduction chunk of one pixel
+    constexpr int MT = 4, NT = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, kq = lane >> 4;
+    const long long per_xcd = (long long)(gridDim.x >> 3);
+    const long long wg = (long long)(blockIdx.x & 7) * per_xcd + (long long)(blockIdx.x >> 3);
+    if (wg >= a.ntiles) return;
+    const int nb = (int)(wg % a.ntn);
+    const long long pt = wg / a.ntn;
+    const long long p0 = pt * 128 + wm * 64;
+    const int c0 = a.n_base + nb * 128;                             // first produced channel of the block
+
+    // operand addresses: pixel m * 16 + l15 of this wave's 64 (clamped to the last pixel: rows beyond P are computed and not stored)
+    const char* xp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        long long p = p0 + m * 16 + l15;
+        p = p < a.P ? p : a.P - 1;
+        xp[m] = a.x + ((size_t)p * a.x_cs + a.x_co) * EB + 16 * kq;
+    }
+    // filter tile n of this wave = channels c0 + (2 n + wn) * 16 ..: lane (l15, kq) reads 16 bytes at [column][16 kq]
+    const char* wl = a.wp + ((size_t)(c0 + wn * 16 + l15) * KCB + 16 * kq);
+    const size_t slab = (size_t)a.coutPad * KCB;
+    int nv = 0;                                                      // tiles of this wave that hold produced channels
+#pragma unroll
+    for (int n = 0; n < NT; ++n) nv += (c0 + (2 * n + wn) * 16 < a.n_end) ? 1 : 0;
+    nv = __builtin_amdgcn_readfirstlane(nv);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xa[MT], wa[NT], xb[MT], wb[NT];
+    auto load = [&](f32x4 (&xs)[MT], f32x4 (&ws)[NT], int c) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xs[m] = *reinterpret_cast<const f32x4*>(xp[m] + (size_t)c * KCB);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ws[n] = *reinterpret_cast<const f32x4*>(wl + (size_t)c * slab + (size_t)n * 2048);
+    };
+    auto mma = [&](const f32x4 (&xs)[MT], const f32x4 (&ws)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (n < nv) {
+                if constexpr (EB == 2) {
+                    const bf16x8 wv = __builtin_bit_cast(bf16x8, ws[n]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, __builtin_bit_cast(bf16x8, xs[m]), acc[m][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[n][kk], xs[m][kk], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // two chunks per trip, the next chunk's operands in flight behind the current chunk's MFMAs; beyond the last chunk the loads repeat it
+    // (unconditional: the compiler's wait counts stay exact), the MFMAs are skipped
+    const int last = a.nchunks - 1;
+    load(xa, wa, 0);
+    for (int c = 0; c < a.nchunks; c += 2) {
+        load(xb, wb, c + 1 < last ? c + 1 : last);
+        mma(xa, wa);
+        load(xa, wa, c + 2 < last ? c + 2 : last);
+        if (c + 1 < a.nchunks) mma(xb, wb);
+    }
+
+    // ---- epilogue: lane (l15, kq) holds channels 4 kq .. 4 kq + 3 of tile n for pixel l15 of pixel tile m
+    const T* resb = reinterpret_cast<const T*>(a.res);
+    const T* maskb = reinterpret_cast<const T*>(a.mask);
+    auto ld4 = [](const T* p_) -> f32x4 {
+        if constexpr (EB == 2) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p_);
+            return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        } else return *reinterpret_cast<const f32x4*>(p_);
+    };
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        if (n >= nv) continue;
+        const int c4 = c0 + (2 * n + wn) * 16 + 4 * kq;
+        const bool cvalid = c4 < a.n_end;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && cvalid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const long long p = p0 + m * 16 + l15;
+            if (!(cvalid && p < a.P)) continue;
+            f32x4 v = acc[m][n] + bv;
+            if (resb != nullptr) v += ld4(resb + (size_t)p * a.res_cs + a.res_co + c4);
+            if (a.relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (maskb != nullptr) {
+                const f32x4 mv = ld4(maskb + (size_t)p * a.mask_cs + a.mask_co + c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
+            }
+            if (EB == 4 || a.y_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + (size_t)p * a.y_cs + a.y_co + c4) = v;
+            else {
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.y) + (size_t)p * a.y_cs + a.y_co + c4) = __builtin_bit_cast(uint2, o);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace unetconv {
+
+// the launches this kernel takes (the descriptor was validated by the planner): one filter image for the batch, whole 64-byte reduction
+// chunks, a grid that fills the chip (smaller problems keep the generic kernels and their split reduction)
+bool conv_gemm1x1_applies(const unet_conv_desc* d) {
+    if (!tuning_of(d->tuning).conv1x1_gemm || d->ks != 1 || d->stride != 1 || d->wp_img_stride != 0 || d->colsum != nullptr || d->colsumsq != nullptr) return false;
+    const int kct = d->dtype == UNET_BF16 ? 32 : 16;
+    if (d->Cin < kct || d->Cin % kct != 0) return false;
+    if (d->cout_begin % 128 != 0) return false;
+    const int cols = d->cout_count ? d->cout_count : d->Cout;
+    const long long P = (long long)d->N * d->OH * d->OW;
+    return ((P + 127) / 128) * ((cols + 127) / 128) >= 256;
+}
+
+int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
+    G1Args a;
+    const bool bf = d->dtype == UNET_BF16;
+    const int kct = bf ? 32 : 16;
+    a.x = (const char*)d->x; a.wp = (const char*)d->wp; a.bias = d->bias; a.res = (const char*)d->res;
+    a.mask = (d->flags & UNET_CONV_MASK) ? (const char*)d->mask : nullptr; a.y = (char*)d->y;
+    a.x_cs = d->x_cs; a.x_co = d->x_co; a.res_cs = d->res_cs; a.res_co = d->res_co; a.mask_cs = d->mask_cs; a.mask_co = d->mask_co;
+    a.y_cs = d->y_cs; a.y_co = d->y_co;
+    a.P = (long long)d->N * d->OH * d->OW;
+    a.nchunks = d->Cin / kct;
+    a.coutPad = unet::roundup(d->Cout, 128);
+    a.n_base = d->cout_begin;
+    a.n_end = d->cout_begin + (d->cout_count ? d->cout_count : d->Cout);
+    a.Cout = d->Cout;
+    a.relu = (d->flags & UNET_CONV_RELU) ? 1 : 0;
+    a.y_f32 = bf ? d->y_f32 : 1;
+    a.ntn = unet::cdiv(a.n_end - a.n_base, 128);
+    a.ntiles = ((a.P + 127) / 128) * a.ntn;
+    UNET_CHECK_ARG(a.ntiles < (1ll << 31) - 8, "conv 1x1: grid too large");
+    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv1x1_gemm_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+}  // namespace unetconv

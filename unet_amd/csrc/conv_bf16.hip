@@ -934,8 +934,6 @@ extern "C" int unet_debug_set_stamps(unsigned long long* buf) {
 }
 #endif
 
-int g_t256_sliver = [] { const char* e = getenv("UNET_T256_SLIVER"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();      // A/B switch
-int g_t256_tpw = 0;        // tiles per workgroup of conv_bf16_t256_kernel (0: chosen per launch; unet_set_bf16_big_tile(100 + n) forces n)
 
 template <int NTOT, int TW, typename T, bool SLV = false>
 int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
@@ -945,7 +943,7 @@ int launch_t256n(const Plan& p, int y_f32, hipStream_t st) {
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // consecutive tiles per workgroup: as many as leave >= 4 workgroups for each of the 512 slots of the chip (2 per CU)
     const int ntiles = p.k.mtiles * p.k.ntn;
-    int tpw = g_t256_tpw > 0 ? g_t256_tpw : ntiles / 2048;
+    int tpw = p.tune.t256_tiles_per_wg > 0 ? p.tune.t256_tiles_per_wg : ntiles / 2048;      // (unet_tuning.t256_tiles_per_wg forces a count)
     tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
     dim3 grid = p.grid;
     grid.x = (unsigned)unet::roundup(unet::cdiv(ntiles, tpw), 8);
@@ -964,7 +962,7 @@ int launch_t256(const Plan& p, int y_f32, hipStream_t st) {
         if constexpr (sizeof(T) == 4) {
             // fp32: a 7-tile block whose last tile holds 1..4 real channels (100 = 6 x 16 + 4: the final ResBlock pair) multiplies them as a sliver
             const int last_w = (q.k.n_end - q.k.n_base) - (q.k.ntn - 1) * q.bn - (tiles - 1) * 16;
-            if (g_t256_sliver && tiles == 7 && q.tw == 32 && last_w >= 1 && last_w <= 4) return launch_t256n<7, 32, T, true>(q, y_f32, st);
+            if (q.tune.t256_sliver && tiles == 7 && q.tw == 32 && last_w >= 1 && last_w <= 4) return launch_t256n<7, 32, T, true>(q, y_f32, st);
         }
         if (q.tw == 32) {
             switch (tiles) {
@@ -1063,10 +1061,12 @@ int launch_tw(const Plan& p, int y_f32, hipStream_t st) {
     }
 }
 
-int g_big_tile = 1;       // 256-pixel workgroup tile for the large bf16 layers (unet_set_bf16_big_tile)
-
-int plan_bf16(const unet_conv_desc* d, Plan* p) {
-    int rc = unetconv::make_plan(d, p, KCB, 8, 16, g_big_tile);
+// splitk < 0: the tuning's own value; 0: a plan that must not split
+int plan_bf16(const unet_conv_desc* d, Plan* p, int splitk = -1) {
+    UNET_CHECK_ARG(d != nullptr, "conv: null desc");
+    const unet_tuning t = unetconv::tuning_of(d->tuning);
+    int rc = unetconv::make_plan(d, p, KCB, 8, 16, t.bf16_big_tile, splitk < 0 ? t.conv_splitk : splitk);
+    p->tune = t;
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");
     p->lds_bytes = (size_t)(32 + 2 * p->max_hpix * LDKB) * sizeof(float);
@@ -1086,12 +1086,7 @@ namespace unetconv {
 static int plan_bf16_ws(const unet_conv_desc* d, Plan* p) {
     int rc = plan_bf16(d, p);
     if (rc != UNET_OK) return rc;
-    if (!splitk_redirect(d, p)) {
-        const int keep = g_splitk;
-        g_splitk = 0;
-        rc = plan_bf16(d, p);
-        g_splitk = keep;
-    }
+    if (!splitk_redirect(d, p)) rc = plan_bf16(d, p, 0);
     return rc;
 }
 
@@ -1102,6 +1097,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return conv_smallk_bf16(d, st);
+    if (conv_gemm1x1_applies(d)) return conv_gemm1x1(d, st);
     const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
     if (p.hit == 6) rc = launch_t256<unsigned short>(p, y_f32, st);
     else rc = (p.hit == 10) ? launch_tw<10>(p, y_f32, st) : launch_tw<4>(p, y_f32, st);
@@ -1122,6 +1118,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
     int rc = plan_bf16_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
+    if (conv_gemm1x1_applies(d)) return 8;         // conv1x1_gemm_kernel
     // 256-pixel tile: ...7 = the large layers (128-wide blocks, 32-pixel patches, >= 512 blocks: the launches bench.py's roofline follows), ...6 = its
     // narrow-block / 16-pixel-patch / small-grid launches
     const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
@@ -1129,12 +1126,6 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
 }
 
 }  // namespace unetconv
-
-extern "C" int unet_set_bf16_big_tile(int on) {
-    g_t256_tpw = on >= 100 ? on - 100 : 0;
-    g_big_tile = (on >= 2 && on < 100) ? on : (on ? 1 : 0);          // 2: the planner order of round 3's first half; 3..: the 256-pixel tile from 64 (on - 2) blocks up
-    return UNET_OK;
-}
 
 extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;

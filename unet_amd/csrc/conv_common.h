@@ -232,9 +232,9 @@ struct Plan {
     // slab [split][pixel][cp] of the caller's workspace; splitk_reduce_kernel adds the slabs in split order and applies the epilogue
     int splits, cp;
     size_t ws_floats;
+    unet_tuning tune;        // the switches of this launch (a copy: the descriptor's or the defaults)
 };
 
-extern int g_splitk;      // unet_set_conv_splitk: 1 = the planner may split the reduction (default), 0 = never, n > 1 = split when fewer than n full-size tiles
 
 // one element of an activation tensor of either storage type (fp32 | bf16 bit pattern)
 __device__ __forceinline__ float ld_act(const float* p) { return *p; }
@@ -245,7 +245,8 @@ __device__ __forceinline__ void st_act(unsigned short* p, float v) { *p = __buil
 // kc: reduction channels per chunk (16 fp32 / 32 bf16 = 64 bytes); vec: channels per 16-byte access (4 fp32 / 8 bf16): channel
 // strides, offsets and the zero-padded channel count of a slice are multiples of vec; mf: MFMA shape of the fp32 kernels (16 | 32)
 // big_tile: allow the 256-pixel workgroup tile (bf16 kernel: the math is 16x cheaper, so halving the filter-operand loads per MFMA pays)
-static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf, int big_tile = 0) {
+// splitk: unet_tuning.conv_splitk of this plan (0: never split; callers that must not split pass 0)
+static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf, int big_tile, int splitk) {
     UNET_CHECK_ARG(d != nullptr, "conv: null desc");
     UNET_CHECK_ARG(d->x && d->wp && d->y, "conv: null tensor pointer");
     UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv: ks must be 1 or 3 (got %d)", d->ks);
@@ -370,7 +371,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
         (p->tw == 32 || p->tw == 16) && p->bn == 128 && blocks(256, 128) < 256)
         nb_first = blocks(256, 64) >= 256 ? 64 : (blocks(256, 32) >= 256 ? 32 : 0);
     if (nb_first) p->bn = nb_first;
-    if (!nb_first && g_splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8 && blocks(128, p->bn) < (g_splitk > 1 ? g_splitk : (kc == 32 ? 400 : 256))) {      // (bf16: measured +1.2 % on the step at 400; fp32 indifferent)
+    if (!nb_first && splitk && mf == 16 && p->nparity == 1 && d->colsum == nullptr && d->colsumsq == nullptr && k.nchunks >= 8 && blocks(128, p->bn) < (splitk > 1 ? splitk : (kc == 32 ? 400 : 256))) {      // (bf16: measured +1.2 % on the step at 400; fp32 indifferent)
         // at least two chunks per split; when even the deepest split of full-size tiles leaves most CUs idle (a handful of pixel tiles:
         // 8 x 8 stages at batch 2), the tile shrinks as well
         const int smax = k.nchunks / 2 < 32 ? k.nchunks / 2 : 32;
@@ -470,6 +471,8 @@ int conv2d_bf16_variant(const unet_conv_desc* d);
 int plan_bf16_public(const unet_conv_desc* d, Plan* p);
 // 1x1 convolutions with a reduction of at most 8 channels (conv_igemm.hip: conv1x1_smallk_kernel), both storage types
 int conv2d_t256_f32(const Plan& p, hipStream_t st);       // conv_bf16.hip: conv_bf16_t256_kernel<.., float>
+bool conv_gemm1x1_applies(const unet_conv_desc* d);      // conv1x1.hip: 1x1 / stride-1 convs of whole reduction chunks on the flat-pixel GEMM kernel
+int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st);
 bool conv_smallk_applies(const unet_conv_desc* d);
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
 

@@ -711,14 +711,50 @@ __global__ void pack_weights_strided_kernel(const float* __restrict__ w, long lo
 
 // ------------------------------------------------------------------ host side
 
-// MFMA shape of the conv kernels: 16 = v_mfma_f32_16x16x4_f32 with per-tile skipping (default), 32 = v_mfma_f32_32x32x2_f32
-static int g_mfma_shape = 16;
 }  // namespace
-namespace unetconv { int g_splitk = 1; }
+
+// The defaults of unet_tuning: constants, with environment overrides read ONCE when the library is loaded (A/B runs of whole programs).
+// Nothing writes them afterwards: the library has no mutable process state.
+namespace unetconv {
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e != nullptr && e[0] != 0) ? atoi(e) : dflt;
+}
+const unet_tuning& tuning_defaults() {
+    static const unet_tuning t = [] {
+        unet_tuning v;
+        v.conv_splitk = env_int("UNET_CONV_SPLITK", 1);
+        v.mfma_shape = 16;
+        v.f32_big_tile = 1;
+        v.bf16_big_tile = 1;
+        v.t256_tiles_per_wg = 0;
+        v.t256_sliver = env_int("UNET_T256_SLIVER", 1);
+        v.conv1x1_gemm = env_int("UNET_CONV1X1_GEMM", 1);
+        v.wgrad_mfma_shape = 32;
+        v.wgrad_bf16_k4 = 1;
+        v.wgrad_1x1 = 1;
+        v.wgrad_narrow = 1;
+        return v;
+    }();
+    return t;
+}
+}  // namespace unetconv
+
+extern "C" void unet_tuning_default(unet_tuning* t) {
+    if (t != nullptr) *t = unetconv::tuning_defaults();
+}
+
 namespace {
 
-int g_big_f32 = 1;         // the 256-pixel tile (conv_bf16_t256_kernel<.., float>) for eligible fp32 launches; unet_set_mfma_shape(-1 / -2) = off / on
-static int make_plan(const unet_conv_desc* d, Plan* p) { return unetconv::make_plan(d, p, KC, 4, g_mfma_shape, g_big_f32); }
+// splitk < 0: the tuning's own value; 0: a plan that must not split (column-sum launches, a caller without a workspace)
+static int make_plan(const unet_conv_desc* d, Plan* p, int splitk = -1) {
+    UNET_CHECK_ARG(d != nullptr, "conv: null desc");
+    const unet_tuning t = unetconv::tuning_of(d->tuning);
+    UNET_CHECK_ARG(t.mfma_shape == 16 || t.mfma_shape == 32, "conv: unet_tuning.mfma_shape must be 16 or 32 (start from unet_tuning_default())");
+    const int rc = unetconv::make_plan(d, p, KC, 4, t.mfma_shape, t.f32_big_tile ? 1 : 0, splitk < 0 ? t.conv_splitk : splitk);
+    p->tune = t;
+    return rc;
+}
 
 
 template <int TW, int MT, int NT, int WM, int WN, int HIT>
@@ -779,20 +815,10 @@ int launch_tw(const Plan& p, hipStream_t st) {
 extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
     Plan p;
     // the plan of the launch that WILL carry the column-sum pointers (they may still be null in this query): never split
-    const int keep = unetconv::g_splitk;
-    unetconv::g_splitk = 0;
-    int rc = make_plan(d, &p);
-    unetconv::g_splitk = keep;
+    int rc = make_plan(d, &p, 0);
     if (rc != UNET_OK) return rc;
     const int wm = (p.bn == 32 && p.bm == 128) ? 4 : 2;
     return p.nparity * p.k.mtiles * wm;
-}
-
-extern "C" int unet_set_mfma_shape(int shape) {
-    if (shape < 0) { g_big_f32 = shape == -2 ? 1 : 0; return UNET_OK; }       // A/B switch of the fp32 256-pixel tile
-    UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
-    g_mfma_shape = shape;
-    return UNET_OK;
 }
 
 static int make_plan_ws(const unet_conv_desc* d, Plan* p);
@@ -803,6 +829,7 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (unetconv::conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
+    if (unetconv::conv_gemm1x1_applies(d)) return 8;         // conv1x1_gemm_kernel
     const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
     return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? (large ? 7 : 6) : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
 }
@@ -1004,12 +1031,7 @@ int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st) { return launch_sm
 static int make_plan_ws(const unet_conv_desc* d, Plan* p) {
     int rc = make_plan(d, p);
     if (rc != UNET_OK) return rc;
-    if (!unetconv::splitk_redirect(d, p)) {
-        const int keep = unetconv::g_splitk;
-        unetconv::g_splitk = 0;
-        rc = make_plan(d, p);
-        unetconv::g_splitk = keep;
-    }
+    if (!unetconv::splitk_redirect(d, p)) rc = make_plan(d, p, 0);
     return rc;
 }
 
@@ -1021,6 +1043,7 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     if (rc != UNET_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (smallk_applies(d)) return launch_smallk<float>(d, st);
+    if (unetconv::conv_gemm1x1_applies(d)) return unetconv::conv_gemm1x1(d, st);
     if (p.hit == 6) rc = unetconv::conv2d_t256_f32(p, st);          // the 256-pixel tile (conv_bf16.hip: conv_bf16_t256_kernel<.., float>)
     else rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
     if (rc != UNET_OK || p.splits <= 1) return rc;
@@ -1032,11 +1055,6 @@ extern "C" size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d) {
     if (d == nullptr) return 0;
     const int rc = d->dtype == UNET_BF16 ? unetconv::plan_bf16_public(d, &p) : make_plan(d, &p);
     return rc == UNET_OK ? p.ws_floats : 0;
-}
-
-extern "C" int unet_set_conv_splitk(int on) {
-    unetconv::g_splitk = on < 0 ? 0 : on;       // 0 off, 1 default threshold, n > 1: split launches of fewer than n full-size tiles (tuning knob)
-    return UNET_OK;
 }
 
 extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {

@@ -1309,11 +1309,10 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
     if (q == 0 && c < Cout) dbias[c] = (float)(((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]);
 }
 
-// narrow-output kernel (wgrad_flat_kernel) for 80 < Cout <= 112; unet_set_wgrad_narrow(0) falls back to the 64x64-tiled kernel
-static int g_wgrad_narrow = 1;
-static int g_wgrad_1x1 = 1;           // 128x128-tiled GEMM kernel for 1x1 weight gradients
-
+// unet_tuning.wgrad_narrow: the narrow-output kernel (wgrad_flat_kernel) for 80 < Cout <= 112 (0 falls back to the 64x64-tiled kernel);
+// .wgrad_1x1: the 128x128-tiled GEMM kernel for 1x1 weight gradients
 struct WPlan {
+    unet_tuning tune;
     WArgs k;
     int ptw, splits, T, narrow, gemm1x1, small1x1, ps, bf16;
     long long pix_per_block;
@@ -1322,6 +1321,8 @@ struct WPlan {
 
 int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     UNET_CHECK_ARG(d != nullptr, "wgrad: null desc");
+    p->tune = unetconv::tuning_of(d->tuning);
+    UNET_CHECK_ARG(p->tune.wgrad_mfma_shape == 16 || p->tune.wgrad_mfma_shape == 32, "wgrad: unet_tuning.wgrad_mfma_shape must be 16 or 32 (start from unet_tuning_default())");
     UNET_CHECK_ARG(d->x && d->dy && d->dw, "wgrad: null tensor pointer");
     UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "wgrad: ks must be 1 or 3");
     UNET_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride must be 1 or 2");
@@ -1353,7 +1354,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.kt = unet::cdiv(d->Cout, BK);
     k.ct = unet::cdiv(d->Cin, BC);
     // narrow-output specialisation (taps flattened into the column dimension): only where the 64x64-tiled kernel pads
-    p->narrow = (!p->bf16 && g_wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 80 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
+    p->narrow = (!p->bf16 && p->tune.wgrad_narrow && d->ks == 3 && d->stride == 1 && d->Cout > 80 && d->Cout <= 112 && d->OW >= 32) ? 1 : 0;
     int cols = k.kt * k.ct;
     if (p->narrow) {
         p->ptw = 32;
@@ -1367,7 +1368,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         cols = nch * k.nnb;
     }
     // heads: 1x1 with <= 16 output channels and <= 1024 input channels -> FMA kernel, one partial row per (workgroup, pixel lane)
-    p->small1x1 = (!p->bf16 && d->ks == 1 && d->Cout <= 16 && k.Cin4 <= 512 && g_wgrad_1x1) ? 1 : 0;
+    p->small1x1 = (!p->bf16 && d->ks == 1 && d->Cout <= 16 && k.Cin4 <= 512 && p->tune.wgrad_1x1) ? 1 : 0;
     p->ps = 1; p->pix_per_block = 0;
     if (p->small1x1) {
         const long long P = (long long)d->N * d->OH * d->OW;
@@ -1387,7 +1388,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         p->lds_bytes = p->lds_bytes16 = 0;
         return UNET_OK;
     }
-    p->gemm1x1 = (!p->bf16 && d->ks == 1 && g_wgrad_1x1) ? 1 : 0;
+    p->gemm1x1 = (!p->bf16 && d->ks == 1 && p->tune.wgrad_1x1) ? 1 : 0;
     if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
         k.kt = unet::cdiv(d->Cout, 128);
         k.ct = unet::cdiv(d->Cin, 128);
@@ -1411,7 +1412,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     return UNET_OK;
 }
 
-static int g_wgrad_mfma_shape = 32;   // the 16x16x4 wgrad form measured slower (register pressure): opt-in only
+// unet_tuning.wgrad_mfma_shape = 16: the 16x16x4 wgrad form measured slower (register pressure): opt-in only
 
 template <int PTW, int S, int KS>
 int launch_w16(const WPlan& p, hipStream_t st) {
@@ -1427,7 +1428,7 @@ int launch_w16(const WPlan& p, hipStream_t st) {
 
 template <int PTW, int S, int KS>
 int launch_w(const WPlan& p, hipStream_t st) {
-    if (g_wgrad_mfma_shape == 16) return launch_w16<PTW, S, KS>(p, st);
+    if (p.tune.wgrad_mfma_shape == 16) return launch_w16<PTW, S, KS>(p, st);
     auto kern = wgrad_kernel<PTW, S, KS>;
     static unsigned long long configured = 0;   // one bit per device
     if (unet::first_use_on_device(&configured)) {
@@ -1438,7 +1439,7 @@ int launch_w(const WPlan& p, hipStream_t st) {
     return UNET_OK;
 }
 
-static int g_wgrad_k4 = 1;           // 3x3 / stride 1 / 32-wide tiles on wgrad_bf16_k4_kernel (unet_set_wgrad_mfma_shape(-1) turns it off, -2 on)
+// unet_tuning.wgrad_bf16_k4: 3x3 / stride 1 / 32-wide tiles on wgrad_bf16_k4_kernel (0: wgrad_bf16_kernel)
 
 template <int KV, int KS>
 int launch_wb_k4n(const WPlan& p, hipStream_t st) {
@@ -1473,7 +1474,7 @@ template <int PTW, int S, int KS>
 int launch_wb(const WPlan& p, hipStream_t st) {
     if constexpr (PTW == 32 && S == 1) {
         // (its in-image byte offsets are 32-bit with bit 31 = out of range: one image of either tensor within 2 GiB)
-        if (g_wgrad_k4 && (long long)p.k.IH * p.k.IW * p.k.x_cs * 2 < (1ll << 31) - 65536 && (long long)p.k.OH * p.k.OW * p.k.dy_cs * 2 < (1ll << 31) - 65536)
+        if (p.tune.wgrad_bf16_k4 && (long long)p.k.IH * p.k.IW * p.k.x_cs * 2 < (1ll << 31) - 65536 && (long long)p.k.OH * p.k.OW * p.k.dy_cs * 2 < (1ll << 31) - 65536)
             return launch_wb_k4<KS>(p, st);
     }
     auto kern = wgrad_bf16_kernel<PTW, S, KS>;
@@ -1504,28 +1505,11 @@ int launch_w_ptw(const WPlan& p, int ks, int stride, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int unet_set_wgrad_mfma_shape(int shape) {
-    if (shape < 0) { g_wgrad_k4 = shape == -2 ? 1 : 0; return UNET_OK; }        // bf16: wgrad_bf16_k4_kernel off (-1) / on (-2)
-    UNET_CHECK_ARG(shape == 16 || shape == 32, "mfma shape must be 16 or 32");
-    g_wgrad_mfma_shape = shape;
-    return UNET_OK;
-}
-
 extern "C" size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d) {
     WPlan p;
     if (make_wplan(d, &p) != UNET_OK) return 0;
     // split-K partials of dW followed by the [splits][Cout] partial column sums of dy (bias gradient)
     return (size_t)p.splits * p.T * d->Cout * d->Cin + (size_t)p.splits * d->Cout;
-}
-
-extern "C" int unet_set_wgrad_1x1(int on) {
-    g_wgrad_1x1 = on ? 1 : 0;
-    return UNET_OK;
-}
-
-extern "C" int unet_set_wgrad_narrow(int on) {
-    g_wgrad_narrow = on ? 1 : 0;
-    return UNET_OK;
 }
 
 extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {

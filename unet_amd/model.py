@@ -231,6 +231,7 @@ class HipDynamicUnet(nn.Module):
             put = lambda buf, at, _x=x: ops.nchw_to_nhwc(_x, ops.TS(buf, 0, buf.shape[3]), at=at)
         ctx = self.ctx
         ctx.training = training
+        ctx.step_pixels = N * H * W
         ctx.fold_bn = bool(self.fold_eval_bn) and not training     # eval: Conv + BN + ReLU = ONE launch (BatchNorm folded into filter + bias)
         self._pack_all(training and ctx.need_grad)
         L = self.layers

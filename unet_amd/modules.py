@@ -63,13 +63,15 @@ class Ctx:
         # gradient all-reduce), dL/dx by the very next launch -- so wgrad + its split reduction leave the critical path and run next to
         # the input-gradient / BatchNorm-backward chain.  Large layers fill the chip either way; small grids (deep stages, small batches:
         # BASELINE configs[0]) and the HBM-bound reduce launches overlap.  UNET_WGRAD_STREAM=0 keeps everything on one stream.
-        # Which launches go there is a matter of size (measured): next to a weight gradient that fills the chip with MFMA work the
-        # fp32 conv kernels of the main stream slow down by more than the overlap returns, so only launches below `wgrad_overlap_gflop`
-        # leave the main stream (UNET_WGRAD_STREAM = 0: none, all: every one, a number: that many GFLOP)
+        # Measured (scripts/ab_side.py, ab_side2.py): bf16 storage +3 % on the cfg2 step, cfg1 (fp32, batch 2) +8 %; the fp32 cfg2 step is
+        # MFMA-bound in both chains and gains nothing (144.0 vs 144.0 tiles/s), and moving only SOME launches is worse than either extreme
+        # (the small side-stream kernels starve behind chip-filling main-stream ones and the main stream then waits for them: 136-138).
+        # So the switch is per forward geometry: every weight gradient of the step, or none -- bf16 storage always, fp32 up to
+        # `wgrad_overlap_pixels` input pixels per step.  UNET_WGRAD_STREAM = 0: never, all: always, a number: that pixel limit.
         mode = os.environ.get("UNET_WGRAD_STREAM", "1")
         self.wgrad_overlap = mode != "0"
-        default = 30.0 if act_dtype == torch.float32 else 1e9
-        self.wgrad_overlap_gflop = 1e9 if mode == "all" else (float(mode) if mode not in ("0", "1") else default)
+        self.wgrad_overlap_pixels = (1 << 62) if (mode == "all" or act_dtype != torch.float32) else (int(float(mode)) if mode not in ("0", "1") else 1 << 20)
+        self.step_pixels = 0                # N * H * W of the current forward (set by HipDynamicUnet._hip_forward)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_ws: Optional[torch.Tensor] = None
         self._side_dirty = False            # side-stream work launched since the last join
@@ -345,7 +347,7 @@ class _ConvExec:
         """weight (+bias) gradient into the .grad views of the flat gradient buffer -- on the side stream when ctx.wgrad_overlap (the
         caller goes on with the input gradient; ctx.side_join() before anything reads the .grad views)"""
         side = ctx.side()
-        if side is None or 2e-9 * dy.P * x.C * dy.C * self.ks * self.ks > ctx.wgrad_overlap_gflop:
+        if side is None or ctx.step_pixels > ctx.wgrad_overlap_pixels:
             self._bwd_w(ctx, x, dy, ctx.workspace)
             return
         ready = torch.cuda.Event()

@@ -16,6 +16,67 @@ from . import _lib as L
 from ._lib import ConvDesc, WgradDesc, check, lib
 
 
+# ---- kernel-selection switches (unet_tuning).  The LIBRARY keeps no state: every descriptor carries a pointer to the struct that is current
+# on this side when it is built -- None (the defaults) unless a `with ops.tuning(...)` block is active in this thread.
+import contextlib
+import threading
+
+_TUNE = threading.local()
+
+
+@contextlib.contextmanager
+def tuning(**fields):
+    """`with ops.tuning(mfma_shape=32, conv_splitk=0): ...` -- launches issued by this thread inside the block carry these switches
+    (A/B measurements; the tests cross-check independently written kernel families this way).  Blocks nest: inner fields override outer."""
+    prev = getattr(_TUNE, "cur", None)
+    cur = L.Tuning.default() if prev is None else L.Tuning.from_buffer_copy(prev)
+    for k, v in fields.items():
+        if k not in dict(L.Tuning._fields_):
+            raise KeyError(f"unet_tuning has no field {k!r}")
+        setattr(cur, k, int(v))
+    _TUNE.cur = cur
+    try:
+        yield cur
+    finally:
+        _TUNE.cur = prev
+
+
+def set_tuning(**fields) -> None:
+    """the switches of THIS thread's launches from now on (outside `with tuning(...)` blocks); no arguments: back to the defaults.
+    Python-side convenience for scripts and try / finally style tests -- the library itself stays stateless."""
+    if not fields:
+        _TUNE.cur = None
+        return
+    cur = getattr(_TUNE, "cur", None)
+    cur = L.Tuning.default() if cur is None else L.Tuning.from_buffer_copy(cur)
+    for k, v in fields.items():
+        if k not in dict(L.Tuning._fields_):
+            raise KeyError(f"unet_tuning has no field {k!r}")
+        setattr(cur, k, int(v))
+    _TUNE.cur = cur
+
+
+def set_knob(name: str, v: int) -> int:
+    """the value conventions of the setters the ABI had up to version 5 (unet_set_<name>), mapped onto unet_tuning fields"""
+    v = int(v)
+    if name == "mfma_shape":
+        set_tuning(**({"f32_big_tile": int(v == -2)} if v < 0 else {"mfma_shape": v}))
+    elif name == "wgrad_mfma_shape":
+        set_tuning(**({"wgrad_bf16_k4": int(v == -2)} if v < 0 else {"wgrad_mfma_shape": v}))
+    elif name == "bf16_big_tile":
+        set_tuning(t256_tiles_per_wg=v - 100 if v >= 100 else 0, bf16_big_tile=(v if 2 <= v < 100 else int(bool(v))))
+    elif name in ("conv_splitk", "wgrad_narrow", "wgrad_1x1", "t256_sliver", "conv1x1_gemm"):
+        set_tuning(**{name: max(v, 0)})
+    else:
+        raise KeyError(name)
+    return 0
+
+
+def _tuning_ptr():
+    cur = getattr(_TUNE, "cur", None)
+    return None if cur is None else C.pointer(cur)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -203,6 +264,7 @@ def _conv_desc(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int, kind: int, 
     d.OH, d.OW, d.Cout = y.H, y.W, y.C
     d.ks, d.stride, d.kind, d.flags = ks, stride, kind, flags
     d.colsum, d.colsumsq = _p(colsum), _p(colsumsq)
+    d.tuning = _tuning_ptr()
     if x.bf16:
         assert wp.dtype == torch.bfloat16 and (res is None or res.bf16) and (mask is None or mask.bf16)
         d.dtype, d.y_f32 = L.BF16, int(not y.bf16)
@@ -221,6 +283,9 @@ class ConvProbe:
         self.flops = 0.0
         self.bytes = 0.0          # ALGORITHMIC bytes of the probed launches: every operand tensor once in, the result once out
         self.detail = []          # (what, N, H, W, Cin, Cout, ks, stride, flops) per probed launch
+        # a stream whose work must not run next to a probed launch (the side stream of the weight gradients): the launch stream waits for
+        # it in front of the first event, so that the events time THIS kernel alone, not this kernel sharing the chip with another one
+        self.exclusive_of = None
 
     def summary(self):
         ms = [a.elapsed_time(b) for a, b in self.events]
@@ -257,6 +322,8 @@ def _launch_conv_part(d: ConvDesc, what: str, alg_flops: float):
     pr = CONV_PROBE
     if pr is not None and lib.unet_conv2d_variant(C.byref(d)) % 1000000 == pr.variant:      # (split-K launches of the instantiation included)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if pr.exclusive_of is not None:
+            torch.cuda.current_stream().wait_stream(pr.exclusive_of)
         e0.record()
         check(lib.unet_conv2d(C.byref(d), _stream()), what)
         e1.record()
@@ -328,6 +395,7 @@ def _wgrad_desc(x: TS, dy: TS, dw, dbias, ks, stride, ws, accumulate) -> WgradDe
     d.workspace = _p(ws)
     d.workspace_floats = 0 if ws is None else ws.numel()
     d.accumulate = int(accumulate)
+    d.tuning = _tuning_ptr()
     assert x.bf16 == dy.bf16
     d.dtype = L.BF16 if x.bf16 else L.F32
     return d
