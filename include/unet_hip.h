@@ -381,6 +381,13 @@ int unet_relu_mask_bf16(const unet_bf16* g, int g_cs, int g_co, const unet_bf16*
 int unet_dot_bf16(const unet_bf16* x, int x_cs, int x_co, const unet_bf16* y, int y_cs, int y_co, long long P, int C, float* out, float* workspace, void* stream);
 int unet_cast_slice_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
 
+/* ------------------------------------------------------ GeoTIFF codecs --
+ * Host-side (no device code) strip / tile decoders of unet_amd/tiffio.py.  Replaces what GDAL / rasterio do when the reference opens a
+ * compressed raster (create_tiles_unet.py:252-434: gdal.Open / ReadAsArray; data.py:18-28: rasterio.open().read()).  Deflate is zlib.
+ * Return the number of bytes written to dst (capacity cap), -1 on a malformed stream or overflow. */
+long long unet_tiff_lzw_decode(const unsigned char* src, long long n, unsigned char* dst, long long cap);      /* TIFF 6.0 LZW (compression 5) */
+long long unet_tiff_packbits_decode(const unsigned char* src, long long n, unsigned char* dst, long long cap); /* PackBits (compression 32773) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,3 +45,45 @@ def test_flip_augment_slicing_rule():
     assert torch.equal(a, x) and torch.equal(b, y)                  # quirk Q7: default touches nothing
     a, b = FlipAugment(1.0, 0.0, n_transform_imgs=0.5)(x.clone(), y.clone())
     assert torch.equal(a[:2], x[:2].flip(-1)) and torch.equal(a[2:], x[2:]) and torch.equal(b[:2], y[:2].flip(-1))
+
+
+def test_compressed_and_bigtiff_golden_files_written_by_libtiff():
+    """LZW / Deflate / PackBits strips, Predictor 2, BigTIFF: the files under tests/golden/tiff were written by Pillow's libtiff binding
+    (tests/golden/make_tiff_golden.py) -- an independent implementation -- from seeded arrays; the reader must return those arrays bit for
+    bit.  This is what lets predict_raster("scene.tif") open the rasters GDAL writes (reference create_tiles_unet.py:252-434 reads through
+    gdal.Open, data.py:18-28 through rasterio: both decode these transparently)."""
+    import glob
+    import importlib.util
+    import os
+    from unet_amd.tiffio import tiff_info
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_tiff_golden", os.path.join(here, "make_tiff_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    A = mod.arrays()
+    files = sorted(glob.glob(os.path.join(here, "tiff", "*.tif")))
+    assert len(files) >= 10
+    seen = set()
+    for f in files:
+        name = os.path.basename(f).split("_")[0]
+        ref = A[name] if A[name].ndim == 2 else np.moveaxis(A[name], -1, 0)
+        got, meta = read_tiff(f)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), f
+        info = tiff_info(f)
+        assert (info["height"], info["width"]) == ref.shape[-2:], f
+        seen.add(open(f, "rb").read(4)[2])
+    assert seen == {42, 43}          # classic and BigTIFF headers
+
+
+def test_lzw_decoder_rejects_garbage_and_overflow():
+    import ctypes as C
+    from unet_amd._lib import lib
+    dst = C.create_string_buffer(16)
+    assert lib.unet_tiff_lzw_decode(bytes([0xff] * 8), 8, dst, 16) == -1            # a code beyond the table
+    # ClearCode, 'A', 'B', EOI as 9-bit MSB-first codes: 100000000 001000001 001000010 100000001
+    bits = "100000000" + "001000001" + "001000010" + "100000001"
+    bits += "0" * (-len(bits) % 8)
+    src = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    assert lib.unet_tiff_lzw_decode(src, len(src), dst, 16) == 2 and dst.raw[:2] == b"AB"
+    assert lib.unet_tiff_lzw_decode(src, len(src), dst, 1) == -1                     # capacity exceeded
+    assert lib.unet_tiff_packbits_decode(bytes([0x02, 1, 2, 3, 0xfe, 9]), 6, dst, 16) == 6 and dst.raw[:6] == bytes([1, 2, 3, 9, 9, 9])

@@ -163,6 +163,8 @@ _sig = {
     "unet_window_nonzero": (i, [vp, i, i, ll, i, vp, i, i, i, vp, vp]),
     "unet_window_gather": (i, [vp, i, i, ll, ll, i, vp, i, i, i, i, vp, i, i, i, vp]),
     "unet_mosaic_accumulate_windows": (i, [vp, i, i, i, i, i, vp, i, i, i, i, vp, vp, i, i, i, i, vp]),
+    "unet_tiff_lzw_decode": (ll, [vp, ll, vp, ll]),
+    "unet_tiff_packbits_decode": (ll, [vp, ll, vp, ll]),
     "unet_mosaic_finalize_rows": (i, [vp, vp, i, i, i, i, i, vp, c_float_p, vp]),
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)

@@ -1,10 +1,12 @@
 """Minimal GeoTIFF reader / writer (no GDAL, no rasterio, no tifffile: none of them is installed here).
 
 Covers what the tile workflow of the reference needs (``data.py:18-28`` reads tiles with rasterio, ``predict.py:19-52``
-writes them with GDAL): baseline TIFF, little/big endian, uncompressed, strips or tiles, chunky or planar, 8/16/32-bit
-unsigned / signed / float samples, plus the GeoTIFF georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922,
-GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams 34737, GDAL_NODATA 42113) which are passed through verbatim.
-Compressed files raise loudly.
+writes them with GDAL; ``create_tiles_unet.py:252-434`` opens whole scenes with GDAL): classic TIFF and BigTIFF, little/big endian,
+strips or tiles, chunky or planar, 8/16/32/64-bit unsigned / signed / float samples, the compressions GDAL writes by default or
+on request -- none, LZW (5), Deflate (8 / 32946), PackBits (32773) -- with horizontal differencing (Predictor 2), plus the GeoTIFF
+georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922, GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams
+34737, GDAL_NODATA 42113) which are passed through verbatim.  Anything else (JPEG, floating-point predictor 3, ...) raises loudly.
+The byte-oriented decoders are C functions of libunet_hip.so (csrc/tiff_codecs.hip); files are written uncompressed.
 """
 from __future__ import annotations
 
@@ -15,7 +17,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 _TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 6: ("b", 1), 7: ("B", 1), 8: ("h", 2), 9: ("i", 4),
-          10: ("ii", 8), 11: ("f", 4), 12: ("d", 8), 16: ("Q", 8)}
+          10: ("ii", 8), 11: ("f", 4), 12: ("d", 8), 16: ("Q", 8), 17: ("q", 8), 18: ("Q", 8)}
 GEO_TAGS = (33550, 33922, 34735, 34736, 34737, 42113)
 
 
@@ -25,29 +27,74 @@ def _dtype(bits: int, fmt: int, bo: str) -> np.dtype:
 
 
 def _parse_tags(b, path):
-    """IFD 0 of a classic TIFF held in a bytes-like object (bytes or mmap): {tag: values}, byte-order prefix"""
+    """IFD 0 of a TIFF (classic: magic 42, 32-bit offsets; BigTIFF: magic 43, 64-bit offsets and counts) held in a bytes-like object
+    (bytes or mmap): {tag: values}, byte-order prefix"""
     bo = {b"II": "<", b"MM": ">"}[bytes(b[:2])]
     magic = struct.unpack(bo + "H", b[2:4])[0]
-    if magic != 42:
-        raise NotImplementedError(f"{path}: BigTIFF / unknown magic {magic}")
-    off = struct.unpack(bo + "I", b[4:8])[0]
-    n = struct.unpack(bo + "H", b[off:off + 2])[0]
+    if magic == 42:
+        off = struct.unpack(bo + "I", b[4:8])[0]
+        n = struct.unpack(bo + "H", b[off:off + 2])[0]
+        base, esz, cfmt, inl = off + 2, 12, "I", 4
+    elif magic == 43:
+        osz, zero = struct.unpack(bo + "HH", b[4:8])
+        if osz != 8 or zero != 0:
+            raise NotImplementedError(f"{path}: BigTIFF with offset size {osz}")
+        off = struct.unpack(bo + "Q", b[8:16])[0]
+        n = struct.unpack(bo + "Q", b[off:off + 8])[0]
+        base, esz, cfmt, inl = off + 8, 20, "Q", 8
+    else:
+        raise NotImplementedError(f"{path}: not a TIFF (magic {magic})")
     tags: Dict[int, tuple] = {}
     for i in range(n):
-        e = bytes(b[off + 2 + 12 * i: off + 14 + 12 * i])
-        tag, typ, cnt = struct.unpack(bo + "HHI", e[:8])
+        e = bytes(b[base + esz * i: base + esz * (i + 1)])
+        tag, typ = struct.unpack(bo + "HH", e[:4])
+        cnt = struct.unpack(bo + cfmt, e[4:4 + inl])[0]
+        if typ not in _TYPES:
+            continue
         fmt, sz = _TYPES[typ]
         total = sz * cnt
-        if total <= 4:
-            data = e[8:8 + total]
+        if total <= inl:
+            data = e[4 + inl:4 + inl + total]
         else:
-            o = struct.unpack(bo + "I", e[8:12])[0]
+            o = struct.unpack(bo + cfmt, e[4 + inl:4 + 2 * inl])[0]
             data = bytes(b[o:o + total])
         if typ == 2:
             tags[tag] = (data.rstrip(b"\0").decode("latin1"),)
         else:
             tags[tag] = struct.unpack(bo + fmt[0] * (cnt * len(fmt)), data)
     return tags, bo
+
+
+def _decoder(comp: int, path):
+    """bytes of one strip / tile -> decoded bytes (at most `cap`)"""
+    if comp == 1:
+        return lambda raw, cap: raw
+    if comp in (8, 32946):
+        import zlib
+        return lambda raw, cap: zlib.decompress(bytes(raw))
+    if comp in (5, 32773):
+        import ctypes as C
+        from ._lib import lib          # the C decoders of libunet_hip.so (host code; no GPU involved)
+        fn = lib.unet_tiff_lzw_decode if comp == 5 else lib.unet_tiff_packbits_decode
+
+        def dec(raw, cap):
+            src = bytes(raw)
+            dst = C.create_string_buffer(cap)
+            got = fn(src, len(src), dst, cap)
+            if got < 0:
+                raise ValueError(f"{path}: corrupt {'LZW' if comp == 5 else 'PackBits'} data")
+            return dst.raw[:got]
+        return dec
+    raise NotImplementedError(f"{path}: TIFF compression {comp} is not supported (none, LZW, Deflate and PackBits are)")
+
+
+def _unpredict(block: np.ndarray, predictor: int, path) -> np.ndarray:
+    """undo Predictor 2 (horizontal differencing per sample, TIFF 6.0 section 14) on a [rows, width, samples] block"""
+    if predictor == 1:
+        return block
+    if predictor != 2 or block.dtype.kind == "f":
+        raise NotImplementedError(f"{path}: TIFF predictor {predictor} on {block.dtype} is not supported")
+    return np.cumsum(block, axis=1, dtype=block.dtype)
 
 
 def _geo_meta(tags) -> Dict:
@@ -85,13 +132,23 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     spp = tags.get(277, (1,))[0]
     bits = tags.get(258, (1,))[0]
     fmt = tags.get(339, (1,))[0]
-    if tags.get(259, (1,))[0] != 1:
-        raise NotImplementedError(f"{path}: compressed TIFF (compression={tags[259][0]}) is not supported")
+    comp, predictor = tags.get(259, (1,))[0], tags.get(317, (1,))[0]
+    decode = _decoder(comp, path)
     planar = tags.get(284, (1,))[0]
     dt = _dtype(bits, fmt, bo)
     planes = spp if planar == 2 else 1
     pix = 1 if planar == 2 else spp
     out = np.zeros((planes, H, W, pix), dtype=dt.newbyteorder("="))
+
+    def block(off, nbytes, rows, cols):
+        """one strip / tile as [rows, cols, pix] in native byte order, decompressed and un-differenced"""
+        need = rows * cols * pix * dt.itemsize
+        raw = decode(memoryview(b)[off:off + nbytes], need) if comp != 1 else memoryview(b)[off:off + need]
+        if len(raw) < need:
+            raise ValueError(f"{path}: strip / tile holds {len(raw)} bytes, {need} expected")
+        t = np.frombuffer(raw, dtype=dt, count=rows * cols * pix).reshape(rows, cols, pix)
+        return _unpredict(t.astype(dt.newbyteorder("=")), predictor, path)
+
     if 324 in tags:        # tiled
         tw, th = tags[322][0], tags[323][0]
         offs, cnts = tags[324], tags[325]
@@ -100,19 +157,20 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
         for p in range(planes):
             for j in range(ty):
                 for i in range(tx):
-                    t = np.frombuffer(b, dtype=dt, count=tw * th * pix, offset=offs[k]).reshape(th, tw, pix)
+                    t = block(offs[k], cnts[k], th, tw)
                     h, w = min(th, H - j * th), min(tw, W - i * tw)
                     out[p, j * th:j * th + h, i * tw:i * tw + w] = t[:h, :w]
                     k += 1
     else:
-        rps = tags.get(278, (H,))[0]
+        rps = min(tags.get(278, (H,))[0], H)
         offs = tags[273]
         spi = -(-H // rps)
+        cnts = tags.get(279) or tuple(min(rps, H - (s % spi) * rps) * W * pix * dt.itemsize for s in range(planes * spi))
         for p in range(planes):
-            for s in range(spi):
-                r0 = s * rps
+            for s_ in range(spi):
+                r0 = s_ * rps
                 rows = min(rps, H - r0)
-                out[p, r0:r0 + rows] = np.frombuffer(b, dtype=dt, count=rows * W * pix, offset=offs[p * spi + s]).reshape(rows, W, pix)
+                out[p, r0:r0 + rows] = block(offs[p * spi + s_], cnts[p * spi + s_], rows, W)
     arr = out[:, :, :, 0] if planar == 2 else np.moveaxis(out[0], -1, 0)
     meta = _geo_meta(tags)
     meta["dtype"] = arr.dtype
