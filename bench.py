@@ -399,11 +399,18 @@ def main():
                 return o
 
             def bf16_line():
-                rb = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", args.steps, args.warmup, 0, 1, dev, log)
+                # `value`: K un-probed steps (bf16 storage runs its weight gradients on a second stream; the probe's events would make the
+                # launch stream wait for that stream in front of every probed launch -- measured: 3-5 % of the step).  `roofline`: a second
+                # run of the same step WITH the probe (launches timed alone), its own tiles/s reported as `probed_value`
+                rb = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", args.steps, args.warmup, 0, 1, dev, log, probe=False)
                 o = step_line(rb, args.batch, args.steps, GFLOP_PER_TILE_FWD_BWD, PEAK_BF16_TFLOPS,
                               "cfg2 (BASELINE configs[1] wording): same step, bf16 storage of activations / gradients / packed filters, "
-                              "fp32 accumulate, fp32 master weights + Adam", "bf16", with_roofline=True)
+                              "fp32 accumulate, fp32 master weights + Adam", "bf16")
                 o["step_frac_of_bf16_peak"] = o["step_frac_of_peak"]
+                rp = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, "bf16", 5, 2, 0, 1, dev, log, probe=True)
+                o["roofline"] = roofline_of(rp["probe"], "bf16", rp["dt"], 5, pmc)
+                o["roofline"]["measured_in"] = "a second run of 5 steps with the launch probe on (probed launches wait for the weight-gradient stream: timed alone)"
+                o["roofline"]["probed_value"] = round(args.batch * 5 / rp["dt"], 3)
                 return o
 
             def sa_line(dtype):

@@ -64,7 +64,8 @@ typedef struct {
                                2 = the planner order of round 3's first half, 3.. = from 64 (n - 2) blocks up */
     int t256_tiles_per_wg;  /* consecutive tiles per workgroup of conv_bf16_t256_kernel; 0 = the launcher's choice (default) */
     int t256_sliver;        /* 1: a 7-tile fp32 block whose last tile holds 1..4 channels multiplies them as a 4x4x1 sliver (default) */
-    int conv1x1_gemm;       /* 1: 1x1 / stride-1 convs of whole chunks on conv1x1_gemm_kernel (default); 0: the implicit-GEMM kernels */
+    int conv1x1_gemm;       /* 1: plain 1x1 / stride-1 convs of whole chunks on conv1x1_gemm_kernel; 0: the implicit-GEMM kernels (default: the
+                               flat-pixel GEMM measured slower on them -- csrc/conv1x1.hip; pixel_shuffle descriptors use it regardless) */
     int wgrad_mfma_shape;   /* fp32 weight gradient: 32 (default) | 16 (opt-in: loses to wave imbalance) */
     int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
     int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */
@@ -115,6 +116,12 @@ typedef struct {
     float* splitk_ws;                    /* optional scratch for split-K launches (small grid, long reduction): fp32, 16-byte aligned, */
     size_t splitk_ws_floats;             /*   >= unet_conv2d_splitk_workspace(desc) floats; NULL / too small = never split this launch */
     const unet_tuning* tuning;           /* NULL = defaults */
+    int pixel_shuffle;                   /* 1: a 1x1 FWD conv of Cout = 4 nf channels that stores PixelShuffle(2)(act(conv)) directly: y is a Cout / 4 wide
+                                            slice of a [N, 2 OH, 2 OW] tensor, produced channel q = ij * nf + c of pixel (h, w) lands at channel c of pixel
+                                            (2 h + ij / 2, 2 w + ij % 2); wp must be the mode-2 image (columns in that order), bias stays in the filter's own
+                                            order.  The PixelShuffle_ICNR without blur in front of the dense merge (reference train.py:141: blur_final applies
+                                            to the LAST UnetBlock, the final upsample has none) then needs no un-shuffled copy of the conv output at all.
+                                            Only descriptors unet_conv2d_variant answers 8 for are taken (UNET_E_UNSUPPORTED otherwise) */
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */
@@ -133,6 +140,8 @@ int unet_conv2d_variant(const unet_conv_desc* d);
 /* weight packing.  w is the torch-layout master parameter [Cout,Cin,ks,ks].
  * mode 0 (FWD):   wp[tap][chunk][coutPad][16]  reduction over Cin
  * mode 1 (DGRAD): wp[tap][chunk][cinPad][16]   reduction over Cout
+ * mode 2 (FWD, pixel-shuffle order; ks = 1, Cout % 64 == 0): mode 0 with image column q = ij * (Cout / 4) + c holding filter 4 c + ij
+ *                 (what unet_conv_desc.pixel_shuffle stores from)
  * pads are zero filled; chunk = 16 reduction channels; *Pad = roundup(.,128). */
 size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode); /* floats */
 int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream);
@@ -238,6 +247,10 @@ int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X, int X_cs,
 /* adjoint incl. the ReLU of the 1x1 conv: dyc = (yc > 0) * shuffle^T(blur^T(dX)) */
 int unet_shuffle_blur_bwd(const float* dX, int dX_cs, int dX_co, const float* yc, int yc_cs, int yc_co,
                           float* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+/* the same adjoint without blur when the forward stored the shuffled activation only (unet_conv_desc.pixel_shuffle): the ReLU mask is read
+ * from X, the [N,2h,2w] forward output, at the address of dX: dyc[h,w,4c+2i+j] = X[2h+i,2w+j,c] > 0 ? dX[2h+i,2w+j,c] : 0 */
+int unet_shuffle_bwd_xmask(const float* dX, int dX_cs, int dX_co, const float* X, int X_cs, int X_co,
+                           float* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, void* stream);
 /* F.interpolate(mode='nearest') and its adjoint (UnetBlock / ResizeToOrig when sizes differ) */
 int unet_resize_nearest(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
                         int N, int IH, int IW, int OH, int OW, int C, void* stream);
@@ -366,6 +379,7 @@ int unet_maxpool3x3s2_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, const 
 int unet_avgpool2_ceil_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int C, int OH, int OW, void* stream);
 int unet_avgpool2_ceil_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int C, int OH, int OW, int accumulate, void* stream);
 int unet_shuffle_blur_bf16(const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* X, int X_cs, int X_co, int N, int h, int w, int Cu, int do_blur, void* stream);
+int unet_shuffle_bwd_xmask_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* X, int X_cs, int X_co, unet_bf16* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, void* stream);
 int unet_shuffle_blur_bwd_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cu, int do_blur, void* stream);
 int unet_resize_nearest_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, int N, int IH, int IW, int OH, int OW, int C, void* stream);
 int unet_resize_nearest_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, int N, int IH, int IW, int OH, int OW, int C, void* stream);

@@ -9,7 +9,7 @@ from unet_amd.ops import TS
 dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
 N = 16
 g = torch.Generator(device="cuda").manual_seed(0)
-tag = os.environ.get("UNET_CONV1X1_GEMM", "1")
+tag = os.environ.get("UNET_CONV1X1_GEMM", "0")
 tot = 0.0
 for H, Cin, Cout in [(16, 512, 1024), (32, 512, 1024), (64, 384, 768), (128, 256, 512), (256, 96, 384), (16, 1024, 512), (32, 1024, 512), (64, 768, 384), (128, 512, 256), (256, 384, 96)]:
     x = TS(torch.randn((N, H, H, Cin), device="cuda", generator=g).to(dt), 0, Cin)

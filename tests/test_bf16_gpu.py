@@ -115,6 +115,12 @@ def test_conv_forward_dgrad_wgrad_bf16(case):
 
 @pytest.mark.parametrize("case", [(96, 384, 64, 64, 8), (64, 256, 61, 67, 5), (256, 96, 128, 128, 2), (32, 200, 128, 128, 2)])
 def test_conv1x1_gemm_kernel_bf16(case):
+    from unet_amd import ops
+    with ops.tuning(conv1x1_gemm=1):
+        _conv1x1_gemm_case_bf16(case)
+
+
+def _conv1x1_gemm_case_bf16(case):
     """conv1x1_gemm_kernel<bf16> (variant 8): 1x1 / stride 1 over whole 32-channel chunks as a flat-pixel GEMM; bf16 output within one rounding
     of the fp64 result on bf16-representable operands, fp32 output (y_f32) to 5e-5; gradient form with residual + mask"""
     from unet_amd import ops

@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # version 6: no process-wide setters any more -- the kernel-selection switches travel with the descriptors (unet_tuning)
     assert not [s for s in syms if s.startswith("unet_set_")]
     t = L.Tuning.default()
-    assert (t.conv_splitk, t.mfma_shape, t.f32_big_tile, t.bf16_big_tile, t.wgrad_mfma_shape) == (1, 16, 1, 1, 32)
+    assert (t.conv_splitk, t.mfma_shape, t.f32_big_tile, t.bf16_big_tile, t.wgrad_mfma_shape, t.conv1x1_gemm) == (1, 16, 1, 1, 32, 0)
     # pure host-side queries work without a GPU
     assert L.lib.unet_pack_weights_size(96, 100, 3, 0) == 9 * 7 * 128 * 16
     # 100 output channels = 6 tiles of 16 + a 4-channel sliver image [tap][chunk][4][16] behind the main one

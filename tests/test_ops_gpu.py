@@ -355,6 +355,11 @@ def test_conv_f32_t256_kernel(ops, case):
     (48, 132, 128, 128, 3),     # three chunks (odd count: the second register set ends on a repeated load), last block 4 channels wide
 ])
 def test_conv1x1_gemm_kernel(ops, case):
+    with ops.tuning(conv1x1_gemm=1):          # (off by default: measured slower than the implicit-GEMM kernels on plain 1x1 convs; the
+        _conv1x1_gemm_case(ops, case)         #  pixel-shuffle store uses the same kernel code regardless)
+
+
+def _conv1x1_gemm_case(ops, case):
     """forward form with bias + residual + ReLU into a channel slice and gradient form with residual + mask on the flat-pixel GEMM kernel,
     against torch on the CPU and against the implicit-GEMM kernel (UNET_CONV1X1_GEMM=0 is the process-wide switch; here: a grid below
     the kernel's 256-block threshold cannot be forced, so the cross-check is torch alone)"""
@@ -385,6 +390,52 @@ def test_conv1x1_gemm_kernel(ops, case):
         ops.conv2d_dgrad(dyt, wpd, dxt, 1, 1, res=to_ts(extra), mask=to_ts(act))
         torch.cuda.synchronize()
         assert_close(from_ts(dxt), dref, rtol=2e-4, what="1x1 gemm dgrad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("case", [(96, 96, 64, 64, 8), (64, 32, 61, 67, 8), (32, 16, 128, 128, 2)])
+def test_conv1x1_shuffle_is_conv_relu_pixelshuffle(ops, case, bf16):
+    """unet_conv_desc.pixel_shuffle: ONE launch = PixelShuffle(2)(relu(conv1x1(x) + b)) written into a channel slice of the up-sampled buffer
+    (mode-2 packed image: columns in pixel-shuffle order); its adjoint unet_shuffle_bwd_xmask takes the ReLU mask from that slice.  Against
+    torch: F.pixel_shuffle(F.relu(F.conv2d(..)), 2) and its autograd gradient w.r.t. the conv output."""
+    Cin, nf, H, W, N = case
+    dt = torch.bfloat16 if bf16 else torch.float32
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf16 else (lambda t: t)
+    g = torch.Generator().manual_seed(Cin * 100 + nf)
+    x = rnd(torch.randn(N, Cin, H, W, generator=g))
+    w = rnd(torch.randn(4 * nf, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    b = torch.randn(4 * nf, generator=g)
+    yc = F.conv2d(x.double(), w.double(), b.double()).requires_grad_(True)
+    ref = F.pixel_shuffle(F.relu(yc), 2)
+    v = 8 if bf16 else 4
+    xb = torch.full((N, H, W, Cin + 2 * v), 7.25)
+    xb[..., v:v + Cin] = x.permute(0, 2, 3, 1)
+    xt = ops.TS(xb.to(dt).cuda(), v, Cin)
+    Xt = ops.TS(torch.full((N, 2 * H, 2 * W, nf + 2 * v), 7.25, dtype=dt, device="cuda"), v, nf)
+    assert ops.conv1x1_shuffle_applies(xt, Xt)
+    wp = ops.pack_weights(w.cuda(), 2, dtype=dt)
+    ops.conv1x1_shuffle(xt, wp, Xt, bias=b.cuda(), relu=True)
+    torch.cuda.synchronize()
+    got = Xt.view().float().permute(0, 3, 1, 2).cpu()
+    tol = (2.0 ** -8 if bf16 else 2e-5) * ref.abs().max().item()
+    assert (got.double() - ref.detach()).abs().max().item() <= tol
+    assert bool((Xt.buf[..., :v] == 7.25).all()) and bool((Xt.buf[..., v + nf:] == 7.25).all())          # the neighbouring slices are untouched
+    # adjoint: dL/d(yc) from dL/dX, masked by the ReLU -- the mask read from X itself
+    dX = rnd(torch.randn(N, nf, 2 * H, 2 * W, generator=g))
+    ref.backward(dX.double())
+    dXt = ops.TS(dX.permute(0, 2, 3, 1).contiguous().to(dt).cuda(), 0, nf)
+    dyc = ops.TS(torch.empty((N, H, W, 4 * nf), dtype=dt, device="cuda"), 0, 4 * nf)
+    ops.shuffle_bwd_xmask(dXt, Xt, dyc)
+    torch.cuda.synchronize()
+    gy = dyc.view().float().permute(0, 3, 1, 2).cpu().double()
+    # (a pre-activation that rounds to exactly 0 in bf16 but is positive in fp64 is masked off here: compare where the stored activation decides)
+    decided = (F.pixel_unshuffle(got.double(), 2) > 0) == (yc.detach() > 0)
+    assert decided.float().mean().item() > 0.999
+    assert ((gy - yc.grad).abs() * decided).max().item() == 0.0
+    # a geometry the GEMM kernel does not take is refused, not silently planned elsewhere
+    small = ops.TS(torch.zeros((1, 8, 8, Cin), dtype=dt, device="cuda"), 0, Cin)
+    assert not ops.conv1x1_shuffle_applies(small, ops.TS(torch.zeros((1, 16, 16, nf), dtype=dt, device="cuda"), 0, nf))
 
 
 WGRAD_CASES = [

@@ -61,6 +61,7 @@ class ConvDesc(C.Structure):
         ("dtype", C.c_int), ("y_f32", C.c_int),
         ("splitk_ws", vp), ("splitk_ws_floats", C.c_size_t),
         ("tuning", C.POINTER(Tuning)),
+        ("pixel_shuffle", C.c_int),
     ]
 
 
@@ -137,6 +138,7 @@ _sig = {
     "unet_avgpool2_ceil_bwd": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, i, vp]),
     "unet_shuffle_blur": (i, [vp, i, i, vp, i, i, i, i, i, i, i, vp]),
     "unet_shuffle_blur_bwd": (i, [vp, i, i, vp, i, i, vp, i, i, i, i, i, i, i, vp]),
+    "unet_shuffle_bwd_xmask": (i, [vp, i, i, vp, i, i, vp, i, i, i, i, i, i, vp]),
     "unet_resize_nearest": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, vp]),
     "unet_resize_nearest_bwd": (i, [vp, i, i, vp, i, i, i, i, i, i, i, i, vp]),
     "unet_nchw_to_nhwc": (i, [vp, vp, i, i, i, i, i, i, vp]),
@@ -169,7 +171,7 @@ _sig = {
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
-           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
+           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "shuffle_bwd_xmask", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
 for _n in ("pack_weights_strided", "row_softmax", "row_softmax_bwd", "relu_mask", "dot"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]

@@ -29,6 +29,9 @@ struct G1Args {
     long long P;
     int nchunks, coutPad, n_base, n_end, Cout, relu, y_f32, ntn;
     long long ntiles;          // pixel tiles x channel blocks
+    // pixel-shuffle store (unet_conv_desc.pixel_shuffle): produced channel q = ij * nf + c of input pixel (img, h, w) goes to channel c of
+    // output pixel (img, 2 h + (ij >> 1), 2 w + (ij & 1)) of a [N, 2 H, 2 W] tensor; bias is indexed in the filter's own order 4 c + ij
+    int ps, nf, H, W;
 };
 
 template <typename T>
@@ -112,21 +115,42 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
             return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
         } else return *reinterpret_cast<const f32x4*>(p_);
     };
+    // stores: pixel tile by pixel tile, its channel tiles back to back (the pieces of one pixel's 128-byte lines reach the L2 together)
+    f32x4 bv[NT];
+    int c4s[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        if (n >= nv) continue;
         const int c4 = c0 + (2 * n + wn) * 16 + 4 * kq;
-        const bool cvalid = c4 < a.n_end;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr && cvalid) {
+        c4s[n] = c4;
+        bv[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && n < nv && c4 < a.n_end) {
+            if (a.ps) {
+                const int ij = c4 / a.nf, c = c4 - ij * a.nf;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+                for (int q = 0; q < 4; ++q) bv[n][q] = a.bias[4 * (c + q) + ij];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[n][q] = (c4 + q < a.Cout) ? a.bias[c4 + q] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const long long p = p0 + m * 16 + l15;
+        if (p >= a.P) continue;
+        long long pimg = 0;
+        int ph = 0, pw = 0;
+        if (a.ps) {
+            pimg = p / ((long long)a.H * a.W);
+            const int rem = (int)(p - pimg * a.H * a.W);
+            ph = rem / a.W; pw = rem - ph * a.W;
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const long long p = p0 + m * 16 + l15;
-            if (!(cvalid && p < a.P)) continue;
-            f32x4 v = acc[m][n] + bv;
+        for (int n = 0; n < NT; ++n) {
+            if (n >= nv) continue;
+            const int c4 = c4s[n];
+            if (c4 >= a.n_end) continue;
+            f32x4 v = acc[m][n] + bv[n];
             if (resb != nullptr) v += ld4(resb + (size_t)p * a.res_cs + a.res_co + c4);
             if (a.relu) {
 #pragma unroll
@@ -137,10 +161,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
             }
-            if (EB == 4 || a.y_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + (size_t)p * a.y_cs + a.y_co + c4) = v;
+            size_t yo = (size_t)p * a.y_cs + a.y_co + c4;
+            if (a.ps) {
+                const int ij = c4 / a.nf, c = c4 - ij * a.nf;
+                yo = ((size_t)(pimg * 2 * a.H + 2 * ph + (ij >> 1)) * (2 * a.W) + 2 * pw + (ij & 1)) * a.y_cs + a.y_co + c;
+            }
+            if (EB == 4 || a.y_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + yo) = v;
             else {
                 const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.y) + (size_t)p * a.y_cs + a.y_co + c4) = __builtin_bit_cast(uint2, o);
+                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.y) + yo) = __builtin_bit_cast(uint2, o);
             }
         }
     }
@@ -152,14 +181,42 @@ namespace unetconv {
 
 // the launches this kernel takes (the descriptor was validated by the planner): one filter image for the batch, whole 64-byte reduction
 // chunks, a grid that fills the chip (smaller problems keep the generic kernels and their split reduction)
-bool conv_gemm1x1_applies(const unet_conv_desc* d) {
-    if (!tuning_of(d->tuning).conv1x1_gemm || d->ks != 1 || d->stride != 1 || d->wp_img_stride != 0 || d->colsum != nullptr || d->colsumsq != nullptr) return false;
+// Measured (scripts/ab_conv1x1.py, isolated launches at batch 16, profiles/r04_d_conv1x1.log): as a REPLACEMENT of the implicit-GEMM kernels on
+// plain 1x1 convs this kernel loses -- fp32 5.98 vs 4.12 ms over the ten PixelShuffle-conv launches of a cfg2 step (65-72 vs 100-115 TFLOP/s),
+// bf16 1.77 vs 1.40 ms: two waves fetch every pixel row through the L1 where the LDS-staged kernels fetch it once, and one chunk of prefetch
+// distance does not cover the memory latency at three waves per SIMD.  unet_tuning.conv1x1_gemm therefore defaults to 0; what the kernel is
+// for is the pixel-shuffle store (unet_conv_desc.pixel_shuffle), where it replaces conv + a 1.6 GB shuffle pass and nets 0.6 / 0.4 ms.
+static bool shape_ok(const unet_conv_desc* d) {
+    if (d->ks != 1 || d->stride != 1 || d->wp_img_stride != 0 || d->colsum != nullptr || d->colsumsq != nullptr) return false;
     const int kct = d->dtype == UNET_BF16 ? 32 : 16;
     if (d->Cin < kct || d->Cin % kct != 0) return false;
     if (d->cout_begin % 128 != 0) return false;
     const int cols = d->cout_count ? d->cout_count : d->Cout;
     const long long P = (long long)d->N * d->OH * d->OW;
     return ((P + 127) / 128) * ((cols + 127) / 128) >= 256;
+}
+bool conv_gemm1x1_applies(const unet_conv_desc* d) { return tuning_of(d->tuning).conv1x1_gemm > 0 && shape_ok(d); }
+
+// unet_conv_desc.pixel_shuffle: validated here (the planner of the implicit-GEMM kernels never sees these descriptors); only this kernel
+// stores that way, so a descriptor it does not take is UNSUPPORTED (callers ask unet_conv2d_variant first and keep the two-pass form)
+int conv_gemm1x1_ps_check(const unet_conv_desc* d) {
+    UNET_CHECK_ARG(d->x && d->wp && d->y && unet::aligned16(d->x) && unet::aligned16(d->wp) && unet::aligned16(d->y), "conv pixel_shuffle: null / unaligned tensor pointer");
+    UNET_CHECK_ARG(d->dtype == UNET_F32 || d->dtype == UNET_BF16, "conv: unknown dtype %d", d->dtype);
+    const int vec = d->dtype == UNET_BF16 ? 8 : 4;
+    UNET_CHECK_ARG(d->ks == 1 && d->stride == 1 && d->kind == UNET_CONV_FWD && d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH == d->IH && d->OW == d->IW && d->Cin > 0 && d->Cout > 0,
+                   "conv pixel_shuffle: a 1x1 / stride-1 forward convolution");
+    UNET_CHECK_ARG(d->Cout % 64 == 0, "conv pixel_shuffle: Cout = 4 nf with nf a multiple of 16 (got %d)", d->Cout);
+    UNET_CHECK_ARG(unet::slice_ok_v(d->x_cs, d->x_co, d->Cin, vec), "conv pixel_shuffle: bad x slice");
+    UNET_CHECK_ARG(unet::slice_ok_v(d->y_cs, d->y_co, d->Cout / 4, (d->dtype == UNET_BF16 && !d->y_f32) ? 4 : 4), "conv pixel_shuffle: bad y slice (Cout / 4 channels of a [N, 2 OH, 2 OW] tensor)");
+    UNET_CHECK_ARG(d->res == nullptr && !(d->flags & UNET_CONV_MASK) && d->colsum == nullptr && d->colsumsq == nullptr && d->cout_begin == 0 &&
+                   d->cout_count == 0 && d->wp_img_stride == 0, "conv pixel_shuffle: no residual / mask / column sums / channel range / per-image filters");
+    UNET_CHECK_ARG((long long)d->N * d->OH * d->OW * 4 < (1ll << 31), "conv pixel_shuffle: more than 2^31 output pixels");
+    if (!shape_ok(d)) {
+        unet::set_error("conv pixel_shuffle: only conv1x1_gemm_kernel stores pixel-shuffled (whole reduction chunks, >= 256 blocks of 128 x 128); "
+                        "ask unet_conv2d_variant first and keep conv + unet_shuffle_blur otherwise");
+        return UNET_E_UNSUPPORTED;
+    }
+    return UNET_OK;
 }
 
 int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
@@ -180,6 +237,7 @@ int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
     a.y_f32 = bf ? d->y_f32 : 1;
     a.ntn = unet::cdiv(a.n_end - a.n_base, 128);
     a.ntiles = ((a.P + 127) / 128) * a.ntn;
+    a.ps = d->pixel_shuffle ? 1 : 0; a.nf = d->Cout / 4; a.H = d->OH; a.W = d->OW;
     UNET_CHECK_ARG(a.ntiles < (1ll << 31) - 8, "conv 1x1: grid too large");
     const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
     if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short>), dim3(grid), dim3(256), 0, st, a);

@@ -1129,7 +1129,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
 
 extern "C" size_t unet_pack_weights_size_bf16(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;
-    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int red = mode == 1 ? Cout : Cin, out = mode == 1 ? Cin : Cout;
     return bf16_image_elems(red, unet::roundup(out, 128), T);
 }
 
@@ -1145,9 +1145,9 @@ extern "C" int unet_pack_weights_strided_bf16(const unet_bf16* w, long long so, 
 
 extern "C" int unet_pack_weights_bf16(const float* w, unet_bf16* wp, int Cout, int Cin, int ks, int mode, void* stream) {
     UNET_CHECK_ARG(w && wp, "pack_weights_bf16: null pointer");
-    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1) && Cout > 0 && Cin > 0, "pack_weights_bf16: bad args");
+    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1 || (mode == 2 && ks == 1 && Cout % 64 == 0)) && Cout > 0 && Cin > 0, "pack_weights_bf16: bad args");
     const int T = ks * ks;
-    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int red = mode == 1 ? Cout : Cin, out = mode == 1 ? Cin : Cout;
     const int nchunks = unet::cdiv(red, KCB), outPad = unet::roundup(out, 128);
     const size_t total = bf16_image_elems(red, outPad, T);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout,

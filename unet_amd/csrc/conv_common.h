@@ -72,13 +72,15 @@ __host__ __device__ inline bool bf16_fold_tail(int red, int T) { return T == 9 &
 __host__ __device__ inline size_t bf16_image_elems(int red, int out_pad, int T) {
     return (size_t)(T * ((red + 31) / 32) + (bf16_fold_tail(red, T) ? 3 : 0)) * out_pad * 32;
 }
+// mode 2 = mode 0 with the image columns in pixel-shuffle order: column q = ij * (Cout / 4) + c holds filter 4 c + ij
+__host__ __device__ inline int ps_filter_of(int q, int Cout) { const int nf = Cout >> 2; return 4 * (q % nf) + q / nf; }
 // element i of the image of the fp32 master parameter w[Cout][Cin][T]; mode 0: out = cout, reduction = cin; mode 1: the reverse
 __device__ inline float bf16_image_value(const float* __restrict__ w, int Cout, int Cin, int T, int mode, int nchunks, int outPad, size_t i) {
     const int rr = (int)(i & 31);
     size_t j = i >> 5;
     const int o = (int)(j % outPad);
     const int slab = (int)(j / outPad);
-    const int red = mode == 0 ? Cin : Cout;
+    const int red = mode == 1 ? Cout : Cin;
     int tap, r;
     if (slab < T * nchunks) {
         tap = slab / nchunks;
@@ -89,6 +91,7 @@ __device__ inline float bf16_image_value(const float* __restrict__ w, int Cout, 
         if (tap >= T) return 0.f;
     }
     if (r >= red) return 0.f;
+    if (mode == 2) return o < Cout ? w[((size_t)ps_filter_of(o, Cout) * Cin + r) * T + tap] : 0.f;
     if (mode == 0) return o < Cout ? w[((size_t)o * Cin + r) * T + tap] : 0.f;
     return o < Cin ? w[((size_t)r * Cin + o) * T + tap] : 0.f;
 }
@@ -473,6 +476,7 @@ int plan_bf16_public(const unet_conv_desc* d, Plan* p);
 int conv2d_t256_f32(const Plan& p, hipStream_t st);       // conv_bf16.hip: conv_bf16_t256_kernel<.., float>
 bool conv_gemm1x1_applies(const unet_conv_desc* d);      // conv1x1.hip: 1x1 / stride-1 convs of whole reduction chunks on the flat-pixel GEMM kernel
 int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st);
+int conv_gemm1x1_ps_check(const unet_conv_desc* d);      // validation of a unet_conv_desc.pixel_shuffle descriptor (UNET_OK: conv_gemm1x1 takes it)
 bool conv_smallk_applies(const unet_conv_desc* d);
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
 

@@ -662,11 +662,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int o = (int)(j % outPad); j /= outPad;
         const int chunk = (int)(j % nchunks);
         const int tap = (int)(j / nchunks);
-        const int red = mode == 0 ? Cin : Cout;
+        const int red = mode == 1 ? Cout : Cin;
         const bool tail = (red & 15) != 0 && chunk == nchunks - 1;
         const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         float v = 0.f;
-        if (mode == 0) {
+        if (mode == 2) {
+            if (o < Cout && r < Cin) v = w[((size_t)unetconv::ps_filter_of(o, Cout) * Cin + r) * T + tap];
+        } else if (mode == 0) {
             if (o < Cout && r < Cin) v = w[((size_t)o * Cin + r) * T + tap];
         } else {
             if (o < Cin && r < Cout) v = w[((size_t)r * Cin + o) * T + tap];
@@ -674,7 +676,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         wp[i] = v;
     }
     // the sliver image behind it (conv_common.h, f32_sliver)
-    const int out_ = mode == 0 ? Cout : Cin;
+    const int out_ = mode == 1 ? Cin : Cout;
     if (unetconv::f32_sliver(out_)) {
         const size_t nsl = (size_t)T * nchunks * 64;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nsl; i += (size_t)gridDim.x * blockDim.x)
@@ -729,7 +731,7 @@ const unet_tuning& tuning_defaults() {
         v.bf16_big_tile = 1;
         v.t256_tiles_per_wg = 0;
         v.t256_sliver = env_int("UNET_T256_SLIVER", 1);
-        v.conv1x1_gemm = env_int("UNET_CONV1X1_GEMM", 1);
+        v.conv1x1_gemm = env_int("UNET_CONV1X1_GEMM", 0);
         v.wgrad_mfma_shape = 32;
         v.wgrad_bf16_k4 = 1;
         v.wgrad_1x1 = 1;
@@ -824,6 +826,7 @@ extern "C" int unet_conv2d_colsum_rows(const unet_conv_desc* d) {
 static int make_plan_ws(const unet_conv_desc* d, Plan* p);
 
 extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
+    if (d != nullptr && d->pixel_shuffle) { const int rc = unetconv::conv_gemm1x1_ps_check(d); return rc == UNET_OK ? 8 : rc; }
     if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16_variant(d);
     Plan p;
     int rc = make_plan_ws(d, &p);
@@ -1036,6 +1039,10 @@ static int make_plan_ws(const unet_conv_desc* d, Plan* p) {
 }
 
 extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
+    if (d != nullptr && d->pixel_shuffle) {          // 1x1 conv + activation + PixelShuffle(2) store: conv1x1_gemm_kernel only (both storage types)
+        const int rc = unetconv::conv_gemm1x1_ps_check(d);
+        return rc == UNET_OK ? unetconv::conv_gemm1x1(d, (hipStream_t)stream) : rc;
+    }
     if (d != nullptr && d->dtype == UNET_BF16) return unetconv::conv2d_bf16(d, (hipStream_t)stream);
     UNET_CHECK_ARG(d == nullptr || d->dtype == UNET_F32, "conv: unknown dtype %d", d->dtype);
     Plan p;
@@ -1052,14 +1059,14 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
 
 extern "C" size_t unet_conv2d_splitk_workspace(const unet_conv_desc* d) {
     Plan p;
-    if (d == nullptr) return 0;
+    if (d == nullptr || d->pixel_shuffle) return 0;
     const int rc = d->dtype == UNET_BF16 ? unetconv::plan_bf16_public(d, &p) : make_plan(d, &p);
     return rc == UNET_OK ? p.ws_floats : 0;
 }
 
 extern "C" size_t unet_pack_weights_size(int Cout, int Cin, int ks, int mode) {
     const int T = ks * ks;
-    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int red = mode == 1 ? Cout : Cin, out = mode == 1 ? Cin : Cout;
     return unetconv::f32_image_elems(red, out, T);
 }
 
@@ -1075,9 +1082,9 @@ extern "C" int unet_pack_weights_strided(const float* w, long long so, long long
 
 extern "C" int unet_pack_weights(const float* w, float* wp, int Cout, int Cin, int ks, int mode, void* stream) {
     UNET_CHECK_ARG(w && wp, "pack_weights: null pointer");
-    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1) && Cout > 0 && Cin > 0, "pack_weights: bad args");
+    UNET_CHECK_ARG((ks == 1 || ks == 3) && (mode == 0 || mode == 1 || (mode == 2 && ks == 1 && Cout % 64 == 0)) && Cout > 0 && Cin > 0, "pack_weights: bad args");
     const int T = ks * ks;
-    const int red = mode == 0 ? Cin : Cout, out = mode == 0 ? Cout : Cin;
+    const int red = mode == 1 ? Cout : Cin, out = mode == 1 ? Cin : Cout;
     const int nchunks = unet::cdiv(red, KC), outPad = unet::roundup(out, 128);
     const size_t total = (size_t)T * nchunks * outPad * KC;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(unet::ew_grid((long long)total, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -835,6 +835,37 @@ __global__ __launch_bounds__(256) void shuffle_blur_bwd_vec_kernel(const T* __re
     }
 }
 
+// Adjoint of PixelShuffle(2) behind a ReLU whose un-shuffled output was never stored (unet_conv_desc.pixel_shuffle): the mask comes from
+// the SHUFFLED activation X itself -- yc[h][w][4c+2a+b] = X[2h+a][2w+b][c] --, read at the address dX is read at:
+// dyc[h][w][4c+2a+b] = X[2h+a][2w+b][c] > 0 ? dX[2h+a][2w+b][c] : 0.  V channels per thread (16-byte accesses).
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle_bwd_xmask_kernel(const T* __restrict__ dX, int dX_cs, int dX_co, const T* __restrict__ X, int X_cs,
+                                                                int X_co, T* __restrict__ dyc, int dyc_cs, int dyc_co, int N, int h, int w, int Cg) {
+    constexpr int V = VecOf<T>::V;
+    const long long total = (long long)N * h * w * Cg;
+    const int H = 2 * h, W = 2 * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int c0 = V * (int)(t % Cg); t /= Cg;
+        const int ww = (int)(t % w); t /= w;
+        const int hh = (int)(t % h);
+        const int n = (int)(t / h);
+        float g[4 * V];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const size_t px = (size_t)(n * H + 2 * hh + a) * W + 2 * ww + b;
+                float d[V], m[V];
+                ldn<V>(dX + px * dX_cs + dX_co + c0, d);
+                ldn<V>(X + px * X_cs + X_co + c0, m);
+#pragma unroll
+                for (int k = 0; k < V; ++k) g[4 * k + 2 * a + b] = m[k] > 0.f ? d[k] : 0.f;
+            }
+        stn<4 * V>(dyc + ((size_t)(n * h + hh) * w + ww) * dyc_cs + dyc_co + 4 * c0, g);
+    }
+}
+
 // ------------------------------------------------------- nearest resize
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
     int s = (int)floorf((float)dst * scale);
@@ -1417,6 +1448,23 @@ extern "C" int unet_shuffle_blur(const float* yc, int yc_cs, int yc_co, float* X
                                  int do_blur, void* stream) { return shuffle_blur_impl<float>(yc, yc_cs, yc_co, X, X_cs, X_co, N, h, w, Cu, do_blur, stream); }
 extern "C" int unet_shuffle_blur_bf16(const unet_bf16* yc, int yc_cs, int yc_co, unet_bf16* X, int X_cs, int X_co, int N, int h, int w, int Cu,
                                  int do_blur, void* stream) { return shuffle_blur_impl<unet_bf16>(yc, yc_cs, yc_co, X, X_cs, X_co, N, h, w, Cu, do_blur, stream); }
+
+template <typename T>
+static int shuffle_bwd_xmask_impl(const T* dX, int dX_cs, int dX_co, const T* X, int X_cs, int X_co, T* dyc, int dyc_cs, int dyc_co, int N, int h, int w,
+                                  int Cu, void* stream) {
+    constexpr int V = VecOf<T>::V;
+    UNET_CHECK_ARG(dX && X && dyc && N > 0 && h > 0 && w > 0 && Cu > 0 && Cu % V == 0, "shuffle_bwd_xmask: bad args (Cu must be a multiple of the 16-byte vector)");
+    UNET_CHECK_ARG(dX_cs > 0 && dX_co >= 0 && dX_co + Cu <= dX_cs && dX_cs % V == 0 && dX_co % V == 0 && X_cs > 0 && X_co >= 0 && X_co + Cu <= X_cs &&
+                   X_cs % V == 0 && X_co % V == 0 && dyc_cs % V == 0 && dyc_co % V == 0 && dyc_co + 4 * Cu <= dyc_cs, "shuffle_bwd_xmask: bad slice");
+    hipLaunchKernelGGL((shuffle_bwd_xmask_kernel<T>), dim3(ew_grid((long long)N * h * w * (Cu / V), 256)), dim3(256), 0, ST, dX, dX_cs, dX_co, X, X_cs, X_co,
+                       dyc, dyc_cs, dyc_co, N, h, w, Cu / V);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+extern "C" int unet_shuffle_bwd_xmask(const float* dX, int dX_cs, int dX_co, const float* X, int X_cs, int X_co, float* dyc, int dyc_cs, int dyc_co, int N,
+                                      int h, int w, int Cu, void* stream) { return shuffle_bwd_xmask_impl<float>(dX, dX_cs, dX_co, X, X_cs, X_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, stream); }
+extern "C" int unet_shuffle_bwd_xmask_bf16(const unet_bf16* dX, int dX_cs, int dX_co, const unet_bf16* X, int X_cs, int X_co, unet_bf16* dyc, int dyc_cs,
+                                           int dyc_co, int N, int h, int w, int Cu, void* stream) { return shuffle_bwd_xmask_impl<unet_bf16>(dX, dX_cs, dX_co, X, X_cs, X_co, dyc, dyc_cs, dyc_co, N, h, w, Cu, stream); }
 
 template <typename T>
 static int shuffle_blur_bwd_impl(const T* dX, int dX_cs, int dX_co, const T* yc, int yc_cs, int yc_co, T* dyc, int dyc_cs,

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
     }
     const Job j = jobs[lo];
     const int KC = bf16 ? 32 : 16, sh = bf16 ? 5 : 4;
-    const int red = j.mode == 0 ? j.Cin : j.Cout;
-    const int out = j.mode == 0 ? j.Cout : j.Cin;
+    const int red = j.mode == 1 ? j.Cout : j.Cin;
+    const int out = j.mode == 1 ? j.Cin : j.Cout;
     const size_t main_f32 = (size_t)j.T * j.nchunks * j.outPad * KC;
     const size_t total = bf16 ? unetconv::bf16_image_elems(red, j.outPad, j.T) : unetconv::f32_image_elems(red, out, j.T);
     const size_t base = (size_t)(blockIdx.x - j.block_begin) * ELEMS_PER_BLOCK;
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const Job* __restrict__
         const bool tail = (red & 15) != 0 && chunk == j.nchunks - 1;
         const int r = chunk * 16 + (tail ? (4 * (rr & 3) + (rr >> 2)) : rr);
         float v = 0.f;
-        if (j.mode == 0) {
+        if (j.mode == 2) {          // forward image, columns in pixel-shuffle order (ks = 1)
+            if (o < j.Cout && r < j.Cin) v = j.w[((size_t)unetconv::ps_filter_of(o, j.Cout) * j.Cin + r) * j.T + tap];
+        } else if (j.mode == 0) {
             if (o < j.Cout && r < j.Cin) v = j.w[((size_t)o * j.Cin + r) * j.T + tap] * (scaled ? j.scale[o] : 1.f);
         } else {
             if (o < j.Cin && r < j.Cout) v = j.w[((size_t)r * j.Cin + o) * j.T + tap];
@@ -85,9 +87,10 @@ extern "C" int unet_pack_batch_build(const unet_pack_job* jobs, int njobs, int d
     unsigned long long blocks = 0;
     for (int i = 0; i < njobs; ++i) {
         const unet_pack_job& s = jobs[i];
-        UNET_CHECK_ARG(s.w && s.wp && (s.ks == 1 || s.ks == 3) && (s.mode == 0 || s.mode == 1) && s.Cout > 0 && s.Cin > 0,
+        UNET_CHECK_ARG(s.w && s.wp && (s.ks == 1 || s.ks == 3) && (s.mode == 0 || s.mode == 1 || s.mode == 2) && s.Cout > 0 && s.Cin > 0,
                        "pack_batch_build: bad job %d", i);
-        const int red = s.mode == 0 ? s.Cin : s.Cout, out = s.mode == 0 ? s.Cout : s.Cin;
+        UNET_CHECK_ARG(s.mode != 2 || (s.ks == 1 && s.Cout % 64 == 0 && s.out_scale == nullptr), "pack_batch_build: job %d: mode 2 is a 1x1 filter with Cout %% 64 == 0", i);
+        const int red = s.mode == 1 ? s.Cout : s.Cin, out = s.mode == 1 ? s.Cin : s.Cout;
         Job& j = t[i];
         j.w = s.w; j.wp = s.wp; j.scale = s.out_scale; j.Cout = s.Cout; j.Cin = s.Cin; j.T = s.ks * s.ks; j.mode = s.mode;
         j.nchunks = unet::cdiv(red, KC); j.outPad = unet::roundup(out, 128);

@@ -210,6 +210,8 @@ def _no_forward(self, *a, **k):
 # BatchNorm batch statistics from the producing conv's epilogue instead of a separate pass over y.  Parity-tested, but OFF: the
 # per-wave partial rows (4096 for a 128x128 stage) make the finalize kernel slower than the pass it saves (step 122.5 -> 127.0 ms).
 FUSE_BN_STATS = False
+# conv1x1 + bias + ReLU + PixelShuffle(2) as one launch where there is no blur behind it (UNET_FUSE_SHUFFLE=0: the two-pass form, A/B)
+FUSE_SHUFFLE = os.environ.get("UNET_FUSE_SHUFFLE", "1") != "0"
 
 
 class _ConvExec:
@@ -221,8 +223,10 @@ class _ConvExec:
         self.stride = conv.stride[0]
         self.wp_f: Optional[torch.Tensor] = None
         self.wp_d: Optional[torch.Tensor] = None
+        self.wp_s: Optional[torch.Tensor] = None      # forward image with its columns in pixel-shuffle order (ops.conv1x1_shuffle), built on demand
         self._ver_f = None
         self._ver_d = None
+        self._ver_s = None
         self.ctx: Optional["Ctx"] = None   # set by HipDynamicUnet once the tree is built
         self.fold: Optional["_BNExec"] = None       # the BatchNorm that follows this conv (ConvLayer with norm), folded in eval mode
         # Channel gaps (bf16 storage of a concat whose first part is not a multiple of 8 channels wide: xresnet34_deep).  The tensors carry
@@ -297,6 +301,12 @@ class _ConvExec:
                 ops.pack_jobs([(self.wsrc(), self.wp_f, 0, self.fold_scale())], self.wp_f.dtype == torch.bfloat16, self.wp_f.device)
                 self._ver_f = ver
             return self.wp_f
+        if mode == 2:
+            dt = torch.float32 if self.ctx is None else self.ctx.act_dtype
+            if self.wp_s is None or self.wp_s.dtype != dt or self._ver_s != ver:
+                self.wp_s = ops.pack_weights(self.conv.weight.data, 2, self.wp_s, dtype=dt)
+                self._ver_s = ver
+            return self.wp_s
         if self.wp_d is None or self._ver_d != ver:
             self.ensure_buffers(True)
             ops.pack_jobs([(self.wsrc(), self.wp_d, 1, None)], self.wp_d.dtype == torch.bfloat16, self.wp_d.device)
@@ -666,9 +676,18 @@ class PixelShuffle_ICNR(nn.Sequential):
         """writes [blur](shuffle(relu(conv1x1(up_in)))) into `dst` (a channel slice of the concat buffer),
         nearest-resized to out_hw when the skip / input size differs (non-/32 tiles)."""
         cl: ConvLayer = self[0]
+        ctx.saved[(id(cl), "x")] = up_in
+        # no blur (the final upsample in front of the dense merge) and no resize: conv + bias + ReLU + PixelShuffle is ONE launch that stores
+        # the shuffled activation straight into the concat slice -- the un-shuffled conv output (at 16 x 512^2: 1.6 GB fp32) is never
+        # written, read back or kept; the backward takes its ReLU mask from the slice itself (ops.shuffle_bwd_xmask)
+        fused = (not self.blur and (2 * up_in.H, 2 * up_in.W) == tuple(out_hw) and not cl.cx.gapped and self.nf % 16 == 0
+                 and FUSE_SHUFFLE and ops.conv1x1_shuffle_applies(up_in, dst))
+        ctx.saved[(id(self), "fused")] = dst if fused else None
+        if fused:
+            ops.conv1x1_shuffle(up_in, cl.cx.packed(2), dst, bias=cl.cx.bsrc(), relu=True)
+            return
         yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
         cl.cx.fwd(up_in, yc, relu=True)
-        ctx.saved[(id(cl), "x")] = up_in
         if (2 * up_in.H, 2 * up_in.W) == tuple(out_hw):
             ops.shuffle_blur(yc, dst, self.blur)
         else:
@@ -681,8 +700,14 @@ class PixelShuffle_ICNR(nn.Sequential):
         a ReLU output, i.e. mask_input)."""
         cl: ConvLayer = self[0]
         up_in: TS = ctx.saved[(id(cl), "x")]
-        yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
         dyc = ctx.tmp(up_in.N, up_in.H, up_in.W, 4 * self.nf)
+        fused_dst: Optional[TS] = ctx.saved.get((id(self), "fused"))
+        if fused_dst is not None:
+            ops.shuffle_bwd_xmask(d_dst, fused_dst, dyc)
+            dx = cl.bwd_from_dy(ctx, dyc, mask=up_in if mask_input else None)
+            ctx.free(dyc)
+            return dx
+        yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
         if (2 * up_in.H, 2 * up_in.W) == (d_dst.H, d_dst.W):
             ops.shuffle_blur_bwd(d_dst, yc, dyc, self.blur)
         else:

@@ -363,6 +363,42 @@ def conv2d(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, bias=None, 
     _launch_conv(d, "conv2d", 2.0 * y.P * x.C * y.C * ks * ks)
 
 
+def _ps_desc(x: TS, wp: torch.Tensor, X: TS, bias, relu: bool) -> ConvDesc:
+    """1x1 conv of 4 * X.C channels whose epilogue stores PixelShuffle(2)(act(conv(x))) into the slice X of a [N, 2H, 2W] buffer"""
+    assert X.H == 2 * x.H and X.W == 2 * x.W and X.N == x.N and x.bf16 == X.bf16
+    d = ConvDesc()
+    d.x, d.x_cs, d.x_co = x.ptr, x.cs, x.co
+    d.wp, d.bias = wp.data_ptr(), _p(bias)
+    d.y, d.y_cs, d.y_co = X.ptr, X.cs, X.co
+    d.N, d.IH, d.IW, d.Cin = x.N, x.H, x.W, x.C
+    d.OH, d.OW, d.Cout = x.H, x.W, 4 * X.C
+    d.ks, d.stride, d.kind, d.flags = 1, 1, L.CONV_FWD, (L.CONV_RELU if relu else 0)
+    d.dtype = L.BF16 if x.bf16 else L.F32
+    d.tuning = _tuning_ptr()
+    d.pixel_shuffle = 1
+    return d
+
+
+def conv1x1_shuffle_applies(x: TS, X: TS) -> bool:
+    """does the library take conv1x1 -> act -> PixelShuffle(2) as ONE launch for this geometry (unet_conv2d_variant == 8)?"""
+    d = _ps_desc(x, torch.empty(0), X, None, True)
+    d.wp = 16          # (any aligned non-null address: the query only plans)
+    return int(lib.unet_conv2d_variant(C.byref(d))) == 8
+
+
+def conv1x1_shuffle(x: TS, wp_ps: torch.Tensor, X: TS, bias=None, relu=True):
+    """X = PixelShuffle(2)(act(conv1x1(x) + bias)); wp_ps is the mode-2 packed image (columns in pixel-shuffle order)"""
+    d = _ps_desc(x, wp_ps, X, bias, relu)
+    check(lib.unet_conv2d(C.byref(d), _stream()), "conv1x1_shuffle")
+
+
+def shuffle_bwd_xmask(dX: TS, X: TS, dyc: TS):
+    """dyc[h,w,4c+2i+j] = X[2h+i,2w+j,c] > 0 ? dX[2h+i,2w+j,c] : 0 (the adjoint of conv1x1_shuffle's store incl. its ReLU)"""
+    assert dyc.C == 4 * dX.C and dX.H == 2 * dyc.H and dX.W == 2 * dyc.W and X.C == dX.C
+    check(_fn("shuffle_bwd_xmask", dX)(dX.ptr, dX.cs, dX.co, X.ptr, X.cs, X.co, dyc.ptr, dyc.cs, dyc.co, dyc.N, dyc.H, dyc.W, dX.C, _stream()),
+          "shuffle_bwd_xmask")
+
+
 def conv2d_variant(x: TS, wp: torch.Tensor, y: TS, ks: int, stride: int = 1, kind: int = 0) -> int:
     """id of the kernel instantiation the planner picks for this launch (unet_conv2d_variant; scripts/layer_table.py, tests)"""
     d = _conv_desc(x, wp, y, ks, stride, kind)
