@@ -1,6 +1,6 @@
 """cfg1 training step / predict at batch 1 for rocprofv3 --kernel-trace --stats (what the small configurations spend their time on)"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from unet_amd.model import HipDynamicUnet
 from unet_amd.optimizer import FlatAdam
 from unet_amd.trainer import TrainStep

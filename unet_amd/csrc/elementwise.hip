@@ -167,7 +167,11 @@ static int pick_tc(int C4) {
 }
 
 static int stats_rows(long long P) {
-    long long r = (P + 127) / 128;
+    // one partial row (= one workgroup) per 32 pixels, at most 512: the 32 x 32 and 16 x 16 stages of a batch of 16 -- and every stage of a
+    // batch of 2 (BASELINE configs[0]) -- get 4 x the workgroups of the 128-pixel rule round 3 ended on, 2-4 dependent trips per thread instead
+    // of 8-16 on a partly filled chip.  (Round 3 measured +0.9 % on the bf16 step and took it back because single-draw flip-noise bars tripped
+    // at 2.001e-3 against 2e-3; those bars are medians over three draws now)
+    long long r = (P + 31) / 32;
     if (r < 1) r = 1;
     if (r > 512) r = 512;
     return (int)r;

@@ -188,7 +188,26 @@ class HipDynamicUnet(nn.Module):
                 marks.append((cx, 1, ver))
         if not jobs:
             return
-        ops.pack_jobs(jobs, self.ctx.act_dtype == torch.bfloat16, self._device, self._pack_tables)
+        bf = self.ctx.act_dtype == torch.bfloat16
+        side = self.ctx.side() if (training and self.ctx.step_pixels <= self.ctx.wgrad_overlap_pixels) else None
+        if side is None:
+            ops.pack_jobs(jobs, bf, self._device, self._pack_tables)
+        else:
+            # the input-gradient images are first read when the backward starts: they are built on the weight-gradient stream next to the
+            # forward pass (half of an HBM-bound launch over every parameter leaves the critical path); _hip_backward waits for the event
+            fwd = [j for j in jobs if j[2] != 1]
+            bwd = [j for j in jobs if j[2] == 1]
+            if fwd:
+                ops.pack_jobs(fwd, bf, self._device, self._pack_tables)
+            if bwd:
+                ready = torch.cuda.Event()
+                ready.record()                      # the parameters are final on the launch stream (behind the optimizer step)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    ops.pack_jobs(bwd, bf, self._device, self._pack_tables)
+                    self.ctx.pack_d_event = torch.cuda.Event()
+                    self.ctx.pack_d_event.record()
+                self.ctx._side_dirty = True
         for cx, mode, ver in marks:
             if mode == 0:
                 cx._ver_f = ver
@@ -288,6 +307,9 @@ class HipDynamicUnet(nn.Module):
         enc: Encoder = L[0]
         last = self._last
         assert last.get("training", False), "backward needs a preceding training-mode forward"
+        if getattr(ctx, "pack_d_event", None) is not None:      # input-gradient filter images built on the second stream during the forward
+            torch.cuda.current_stream().wait_event(ctx.pack_d_event)
+            ctx.pack_d_event = None
         skips: Dict[int, TS] = last["skips"]
         nb = 4 + len(self.sz_chg_idxs)
         head: ConvLayer = L[nb + 4]
