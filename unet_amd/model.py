@@ -175,7 +175,9 @@ class HipDynamicUnet(nn.Module):
         """Rebuild every stale packed filter image in ONE launch (unet_pack_batch_run).  The parameters are rewritten by every
         optimizer step, so in training this runs once per step for all 52 convs x (forward, input-gradient) images.  In eval mode
         (ctx.fold_bn) the forward image of a conv that is followed by a BatchNorm is w * scale[cout] (eval coefficients, cached)."""
-        cxs = [m.cx for m in self.modules() if isinstance(getattr(m, "cx", None), _ConvExec)]
+        cxs = self.__dict__.get("_cxs")          # (the module tree does not change after construction; walking it costs 0.5 ms of host time per step)
+        if cxs is None:
+            cxs = self.__dict__["_cxs"] = [m.cx for m in self.modules() if isinstance(getattr(m, "cx", None), _ConvExec)]
         jobs, marks = [], []
         for cx in cxs:
             cx.ensure_buffers(training)
@@ -250,6 +252,7 @@ class HipDynamicUnet(nn.Module):
             put = lambda buf, at, _x=x: ops.nchw_to_nhwc(_x, ops.TS(buf, 0, buf.shape[3]), at=at)
         ctx = self.ctx
         ctx.training = training
+        ctx.main_stream = None
         ctx.step_pixels = N * H * W
         ctx.fold_bn = bool(self.fold_eval_bn) and not training     # eval: Conv + BN + ReLU = ONE launch (BatchNorm folded into filter + bias)
         self._pack_all(training and ctx.need_grad)
@@ -307,8 +310,9 @@ class HipDynamicUnet(nn.Module):
         enc: Encoder = L[0]
         last = self._last
         assert last.get("training", False), "backward needs a preceding training-mode forward"
+        ctx.main_stream = torch.cuda.current_stream()           # (once per backward: every event of the program is recorded on / waited for by this object)
         if getattr(ctx, "pack_d_event", None) is not None:      # input-gradient filter images built on the second stream during the forward
-            torch.cuda.current_stream().wait_event(ctx.pack_d_event)
+            ctx.main_stream.wait_event(ctx.pack_d_event)
             ctx.pack_d_event = None
         skips: Dict[int, TS] = last["skips"]
         nb = 4 + len(self.sz_chg_idxs)
@@ -382,6 +386,7 @@ class HipDynamicUnet(nn.Module):
         for t in dskips.values():
             ctx.free(t)
         ctx.side_join()                                         # every .grad view is final behind this point of the launch stream
+        ctx.main_stream = None
         assert not ctx._pool_live, "a backward temporary was not returned to the pool"
 
     # ------------------------------------------------------------------ torch-facing surface

@@ -72,6 +72,7 @@ class Ctx:
         self.wgrad_overlap = mode != "0"
         self.wgrad_overlap_pixels = (1 << 62) if (mode == "all" or act_dtype != torch.float32) else (int(float(mode)) if mode not in ("0", "1") else 1 << 20)
         self.step_pixels = 0                # N * H * W of the current forward (set by HipDynamicUnet._hip_forward)
+        self.main_stream = None             # the launch stream of the running backward program (fetched once per backward: torch.cuda.current_stream() is slow)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_ws: Optional[torch.Tensor] = None
         self._side_dirty = False            # side-stream work launched since the last join
@@ -153,10 +154,11 @@ class Ctx:
     def side_workspace(self, nfloats: int) -> torch.Tensor:
         """scratch of the side stream's launches (they are ordered among themselves; the main stream's ctx.workspace is not theirs)"""
         if self._side_ws is None or self._side_ws.numel() < nfloats:
-            if self._side_ws is not None:
-                self._side_ws.record_stream(self._side)
+            old = self._side_ws
             with torch.cuda.stream(self._side):
                 self._side_ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=self.device)
+            if old is not None:
+                old.record_stream(self._side)          # (its last reader runs on the side stream: the allocator waits for it)
         return self._side_ws
 
     def side_reads(self, t: Optional[TS], ev) -> None:
@@ -166,13 +168,13 @@ class Ctx:
 
     def _side_release_oldest(self):
         ptr, key, ev = self._side_pending.popleft()
-        torch.cuda.current_stream().wait_event(ev)
+        (self.main_stream or torch.cuda.current_stream()).wait_event(ev)
         self._pool[key].append(self._pool_flat[ptr])
 
     def side_join(self):
         """the current stream waits for every weight gradient launched so far (before the optimizer / a gradient bucket leaves)"""
         if self._side is not None and self._side_dirty:
-            torch.cuda.current_stream().wait_stream(self._side)
+            (self.main_stream or torch.cuda.current_stream()).wait_stream(self._side)
             self._side_dirty = False
         while self._side_pending:
             ptr, key, _ = self._side_pending.popleft()
@@ -235,6 +237,7 @@ class _ConvExec:
         self.out_gap: Optional[Tuple[int, int]] = None
         self._wpad = self._bpad = self._gwpad = self._gbpad = None
         self._ver_pad = None
+        self._ws_sizes: Dict[tuple, int] = {}
 
     def set_gaps(self, in_gap=None, out_gap=None):
         self.in_gap = in_gap if in_gap and in_gap[1] else None
@@ -360,20 +363,31 @@ class _ConvExec:
         if side is None or ctx.step_pixels > ctx.wgrad_overlap_pixels:
             self._bwd_w(ctx, x, dy, ctx.workspace)
             return
+        main = ctx.main_stream or torch.cuda.current_stream()
         ready = torch.cuda.Event()
-        ready.record()                          # dy is complete on the main stream (x is a forward activation: long complete)
+        ready.record(main)                      # dy is complete on the main stream (x is a forward activation: long complete)
         side.wait_event(ready)
-        with torch.cuda.stream(side):
-            self._bwd_w(ctx, x, dy, ctx.side_workspace)
-            done = torch.cuda.Event()
-            done.record()
+        if self.gapped or ctx._side_ws is None:         # (torch ops inside: they need torch's own notion of the current stream)
+            with torch.cuda.stream(side):
+                self._bwd_w(ctx, x, dy, ctx.side_workspace)
+        else:
+            ops.STREAM_OVERRIDE = side.cuda_stream
+            try:
+                self._bwd_w(ctx, x, dy, ctx.side_workspace)
+            finally:
+                ops.STREAM_OVERRIDE = None
+        done = torch.cuda.Event()
+        done.record(side)
         ctx._side_dirty = True
         ctx.side_reads(dy, done)
         ctx.side_reads(x, done)
 
     def _bwd_w(self, ctx: Ctx, x: TS, dy: TS, workspace):
         w, b = self.conv.weight, self.conv.bias
-        n = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)
+        key = (x.N, x.H, x.W, x.C, x.cs, dy.C, dy.cs, x.bf16, ops._tuning_ptr() is None)
+        n = self._ws_sizes.get(key)                 # (a planning call per launch otherwise: the geometry decides)
+        if n is None:
+            n = self._ws_sizes[key] = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)
         if self.gapped:          # gradient of the gapped filter, then its live rows / columns into the parameter's .grad
             self.wsrc()
             ops.conv2d_wgrad(x, dy, self._gwpad, self.ks, self.stride, workspace(n), dbias=None if b is None else self._gbpad)

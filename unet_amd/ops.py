@@ -77,8 +77,28 @@ def _tuning_ptr():
     return None if cur is None else C.pointer(cur)
 
 
+# The launch stream of this thread as a raw hipStream_t.  torch.cuda.current_stream() builds a Stream object through several Python layers
+# (device-index parsing, is_available(), an os.environ lookup): 8 us of a ~16 us host budget per launch -- scripts/host_profile.py showed the
+# cfg1 step HOST-bound (issue time 6.95 ms = wall time), 29 % of it in that call.  The C entry points below are what it ends in.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+# a raw stream that replaces the thread's current one for the launches issued while it is set (the side stream of the weight gradients:
+# entering torch.cuda.stream(...) costs four current_stream() round trips per weight gradient)
+STREAM_OVERRIDE: Optional[int] = None
+
+
 def _stream() -> int:
+    if STREAM_OVERRIDE is not None:
+        return STREAM_OVERRIDE
+    if _raw_stream is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def _device_index() -> int:
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -306,7 +326,7 @@ def _splitk_ws(d: ConvDesc):
     if need == 0:
         d.splitk_ws, d.splitk_ws_floats = None, 0
         return
-    dev = torch.cuda.current_device()
+    dev = _device_index()
     buf = _SPLITK_WS.get(dev)
     if buf is None or buf.numel() < need:
         if torch.cuda.is_current_stream_capturing():
