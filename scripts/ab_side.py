@@ -16,6 +16,7 @@ def run(what, thr, **kw):
         orig(self, device, act_dtype)
         self.wgrad_overlap = thr > 0
         self.wgrad_overlap_pixels = (1 << 62) if thr > 0 else 0
+        self.wgrad_overlap_min_pixels = 0
     M.Ctx.__init__ = init
     r = B.step_bench(*kw["args"], dev, log, probe=False)
     M.Ctx.__init__ = orig

@@ -15,6 +15,7 @@ for rep in range(2):
                     orig(self, device, act_dtype)
                     self.wgrad_overlap = _t > 0
                     self.wgrad_overlap_pixels = (1 << 62) if _t > 0 else 0
+                    self.wgrad_overlap_min_pixels = 0
                 M.Ctx.__init__ = init
                 r = B.step_bench("xresnet34", 4, 5, 512, 16, dtype, 8, 3, 0, 1, dev, lambda m: None, probe=probe)
                 M.Ctx.__init__ = orig

@@ -626,3 +626,29 @@ def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs)
         worsts.append(worst)
     es = sorted(w_[1] for w_ in worsts)
     assert es[len(es) // 2] < 2e-3 and es[-1] < 4e-3, worsts
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_weight_gradients_on_the_second_stream_are_the_same_bits(dtype):
+    """the weight gradients (and the input-gradient filter images) of a step may run on a side stream next to the input-gradient
+    chain.  Whether they do is a per-geometry policy; the RESULT must not depend on it: three steps with the overlap forced on equal three
+    steps with it forced off bit for bit (every kernel is deterministic, the program order fixes every buffer address), incl. the Adam
+    update that waits for the join, and the backward-temporary pool ends empty."""
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    x, y = O.synthetic_batch(2, 4, 96, 64, 5)
+    outs = []
+    for force in (True, False):
+        torch.manual_seed(11)
+        m = HipDynamicUnet("xresnet34", 4, 5, (96, 64), act_dtype=dtype)
+        m.ctx.wgrad_overlap = force
+        m.ctx.wgrad_overlap_pixels, m.ctx.wgrad_overlap_min_pixels = 1 << 62, 0
+        m.train()
+        st = TrainStep(m, FlatAdam(m, [1e-4, 3e-4, 1e-3]), torch.full((5,), 0.2, device="cuda"))
+        losses = [float(st(x.cuda(), y.cuda()).item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert (m.ctx._side is not None) == force and not m.ctx._pool_live and not m.ctx._side_pending
+        outs.append((losses, m.flat_grad.clone(), m.flat_param.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

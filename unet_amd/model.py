@@ -191,7 +191,7 @@ class HipDynamicUnet(nn.Module):
         if not jobs:
             return
         bf = self.ctx.act_dtype == torch.bfloat16
-        side = self.ctx.side() if (training and self.ctx.step_pixels <= self.ctx.wgrad_overlap_pixels) else None
+        side = self.ctx.side() if (training and self.ctx.overlap_now()) else None
         if side is None:
             ops.pack_jobs(jobs, bf, self._device, self._pack_tables)
         else:

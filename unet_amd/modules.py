@@ -63,14 +63,22 @@ class Ctx:
         # gradient all-reduce), dL/dx by the very next launch -- so wgrad + its split reduction leave the critical path and run next to
         # the input-gradient / BatchNorm-backward chain.  Large layers fill the chip either way; small grids (deep stages, small batches:
         # BASELINE configs[0]) and the HBM-bound reduce launches overlap.  UNET_WGRAD_STREAM=0 keeps everything on one stream.
-        # Measured (scripts/ab_side.py, ab_side2.py): bf16 storage +3 % on the cfg2 step, cfg1 (fp32, batch 2) +8 %; the fp32 cfg2 step is
-        # MFMA-bound in both chains and gains nothing (144.0 vs 144.0 tiles/s), and moving only SOME launches is worse than either extreme
-        # (the small side-stream kernels starve behind chip-filling main-stream ones and the main stream then waits for them: 136-138).
-        # So the switch is per forward geometry: every weight gradient of the step, or none -- bf16 storage always, fp32 up to
-        # `wgrad_overlap_pixels` input pixels per step.  UNET_WGRAD_STREAM = 0: never, all: always, a number: that pixel limit.
+        # Measured (scripts/ab_side.py, ab_side2.py, r04_j_graph_side.log).  The overlap pays where the step is GPU-bound and the two
+        # chains are not both MFMA-saturated: bf16 storage at cfg2 size +3 %, fp32 cfg1 (batch 2 of 256^2) +7 %.  It costs ~5 HIP event / wait
+        # calls per weight gradient on the host: the bf16 cfg1 step is HOST-bound and loses (3.97 ms without, 4.7-5.6 with).  The fp32 cfg2 step is
+        # MFMA-bound in both chains and gains nothing (144.0 vs 144.0 tiles/s); moving only SOME launches is worse than either extreme (small
+        # side-stream kernels starve behind chip-filling main-stream ones and the main stream then waits for them: 136-138).  So the switch is
+        # per forward geometry, all weight gradients of the step or none: fp32 up to 2^20 input pixels per step, bf16 storage from 2^20 up.
+        # UNET_WGRAD_STREAM = 0: never, all: always.
         mode = os.environ.get("UNET_WGRAD_STREAM", "1")
         self.wgrad_overlap = mode != "0"
-        self.wgrad_overlap_pixels = (1 << 62) if (mode == "all" or act_dtype != torch.float32) else (int(float(mode)) if mode not in ("0", "1") else 1 << 20)
+        big = 1 << 62
+        if mode == "all":
+            self.wgrad_overlap_pixels, self.wgrad_overlap_min_pixels = big, 0
+        elif act_dtype == torch.float32:
+            self.wgrad_overlap_pixels, self.wgrad_overlap_min_pixels = 1 << 20, 0
+        else:
+            self.wgrad_overlap_pixels, self.wgrad_overlap_min_pixels = big, 1 << 20
         self.step_pixels = 0                # N * H * W of the current forward (set by HipDynamicUnet._hip_forward)
         self.main_stream = None             # the launch stream of the running backward program (fetched once per backward: torch.cuda.current_stream() is slow)
         self._side: Optional[torch.cuda.Stream] = None
@@ -150,6 +158,10 @@ class Ctx:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
+
+    def overlap_now(self) -> bool:
+        """do the weight gradients (and the input-gradient filter images) of the current step run on the second stream?"""
+        return self.wgrad_overlap and self.wgrad_overlap_min_pixels <= self.step_pixels <= self.wgrad_overlap_pixels
 
     def side_workspace(self, nfloats: int) -> torch.Tensor:
         """scratch of the side stream's launches (they are ordered among themselves; the main stream's ctx.workspace is not theirs)"""
@@ -360,7 +372,7 @@ class _ConvExec:
         """weight (+bias) gradient into the .grad views of the flat gradient buffer -- on the side stream when ctx.wgrad_overlap (the
         caller goes on with the input gradient; ctx.side_join() before anything reads the .grad views)"""
         side = ctx.side()
-        if side is None or ctx.step_pixels > ctx.wgrad_overlap_pixels:
+        if side is None or not ctx.overlap_now():
             self._bwd_w(ctx, x, dy, ctx.workspace)
             return
         main = ctx.main_stream or torch.cuda.current_stream()
