@@ -228,11 +228,14 @@ def predict_bench(dtype, batch, dev, iters=6):
     for _ in range(3):
         m.predict_probs(x)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        m.predict_probs(x)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    reps = []          # median of three repetitions: a batch-1 window is 30 ms long, one host hiccup inside it halves the figure
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            m.predict_probs(x)
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / iters)
+    dt = sorted(reps)[1]
     del m
     torch.cuda.empty_cache()
     return {"value": round(batch / dt, 1), "unit": "tiles/s", "ms_per_batch": round(dt * 1e3, 3), "dtype": dtype, "batch": batch,

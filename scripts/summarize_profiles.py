@@ -22,14 +22,14 @@ def short(name: str) -> str:
     # template as the plain one; the PMC summary and pmc_traffic.json aggregate both under the name without the flag
     name = re.sub(r"^(conv_igemm16_kernel<[0-9,]+),(?:true|false)>$", r"\1>", name)
     # conv_bf16_t256_kernel<NTOT,TW>: one kernel template, instantiated per channel-tile count of the block and patch width; aggregated under the bare name
-    return re.sub(r"^conv_bf16_t256_kernel<[0-9,]+>$", "conv_bf16_t256_kernel", name)
+    return re.sub(r"^conv_bf16_t256_kernel<[0-9,]+(?:,(?:true|false))?>$", "conv_bf16_t256_kernel", name)
 
 
 def keyed(name: str, grid_threads: int) -> str:
     """conv_bf16_t256_kernel serves the large layers (>= 512 workgroups: the launches bench.py's roofline follows, variant ...7) and, since the
     second half of round 3, narrow-block / small-grid launches (variant ...6): two rows, split by grid size"""
     k = short(name)
-    m = re.search(r"conv_bf16_t256_kernel<\s*(\d+),\s*(\d+)(?:,\s*([A-Za-z ]+))?>", name)
+    m = re.search(r"conv_bf16_t256_kernel<\s*(\d+),\s*(\d+)(?:,\s*([A-Za-z ]+))?(?:,\s*(?:true|false))?>", name)
     if m is not None:
         base = "conv_bf16_t256_kernel<float>" if (m.group(3) and "float" in m.group(3)) else "conv_bf16_t256_kernel"     # (the fp32 form of the same template)
         large = int(m.group(1)) >= 5 and int(m.group(2)) == 32 and grid_threads >= 512 * 256
