@@ -83,9 +83,12 @@ def test_geotiff_reads_foreign_writer(tmp_path):
     Image.fromarray(rgb).save(tmp_path / "c.tif")
     c, _ = read_tiff(tmp_path / "c.tif")
     assert np.array_equal(c, np.moveaxis(rgb, -1, 0))
+    Image.fromarray(a).save(tmp_path / "z.tif", compression="tiff_lzw")          # (round 4: LZW / Deflate / PackBits strips are read)
+    z, _ = read_tiff(tmp_path / "z.tif")
+    assert np.array_equal(a, z)
+    Image.fromarray(rgb).save(tmp_path / "j.tif", compression="jpeg")            # what the reader does not decode raises, loudly
     with pytest.raises(NotImplementedError):
-        Image.fromarray(a).save(tmp_path / "z.tif", compression="tiff_lzw")
-        read_tiff(tmp_path / "z.tif")
+        read_tiff(tmp_path / "j.tif")
 
 
 def test_dataloaders_batches(tmp_path):
