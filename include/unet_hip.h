@@ -70,6 +70,10 @@ typedef struct {
     int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
     int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */
     int wgrad_narrow;       /* 1: the narrow-output (80 < Cout <= 112) flattened-tap fp32 weight-gradient kernel (default) */
+    int plan_batch;         /* 0 (default): the conv planner sizes tiles / split reductions for the batch of the descriptor.  n > 0: it plans as
+                               if the batch were n images, whatever N is -- with 1, every image of a batch runs exactly the kernels, tiles and split
+                               chains it would run alone: predictions become bit-identical ACROSS batch sizes (the reference predicts tile by
+                               tile, predict.py:191-193), at the price of batch-1 plans on full grids (predict.predict_raster(batch_invariant=True)) */
 } unet_tuning;
 void unet_tuning_default(unet_tuning* t);
 

@@ -19,6 +19,7 @@ placed).  The confusion-matrix plots (``predict.py:56-143``) are reporting and o
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import queue
 import threading
@@ -258,7 +259,8 @@ def _want(regression, all_classes, specific_class):
 
 def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_empty: float = 0.9, dtype: str = "int8", nodata=None,
                    regression: bool = False, all_classes: bool = False, specific_class: Optional[int] = None, large_file: bool = False,
-                   batch_size: int = 16, out_path=None, class_zero: bool = False, timing: Optional[dict] = None):
+                   batch_size: int = 16, out_path=None, class_zero: bool = False, timing: Optional[dict] = None,
+                   batch_invariant: bool = False):
     """Sliding-window prediction of a whole raster: equals split_raster(raster, patch_size=size, patch_overlap=overlap, max_empty) ->
     save_predictions(merge=True) on the tiles it writes (create_tiles_unet.py:252-434, predict.py:146-334).
 
@@ -269,6 +271,9 @@ def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_
              batch_size changes the launch grids and with them which deep-stage convs run as split reductions, i.e. the
              logits at rounding level (<= 2e-5 of the logit scale, tests/test_fullsize_gpu.py): masks can differ in numerical-tie pixels.
              The reference's own loop is batch 1 (predict.py:191-193)
+    batch_invariant  True: every launch is planned as if its batch were ONE window (unet_tuning.plan_batch = 1), so each window runs exactly
+             the kernels and split chains it would run alone: the result is bit-identical for every batch_size (and equals the
+             tile-by-tile loop), at the price of batch-1 plans on full grids
     large_file  the reference's int8 merge (predict.py:209-214,288-289,324-329): probabilities as around(p * 31) in int8 rasters, int8 hit
              counters, integer floor division -- same numbers as save_predictions(merge=True, large_file=True)
     Returns on rank 0 the merged array (uint8 argmax [H', W'] by default; float32 [C, H', W'] for all_classes; one float32 plane for
@@ -314,7 +319,8 @@ def predict_raster(model, raster, size: int = 512, overlap: float = 0.2, *, max_
         return ops.WindowBatch(src, gtab, first, n_pad, size, size)
 
     want = _want(regression, all_classes, specific_class)
-    out = _run_merge(model, places, MH, MW, regression, bool(large_file and not regression), rank, world, batch_size, make_input, want, timing)
+    with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):
+        out = _run_merge(model, places, MH, MW, regression, bool(large_file and not regression), rank, world, batch_size, make_input, want, timing)
     if rank == 0 and out_path is not None:
         ogt = None if gt is None else [gt[0] + ox * gt[1], gt[1], 0.0, gt[3] + oy * gt[5], 0.0, gt[5]]
         store_tif(out_path, out, ogt, tags, -9999 if regression else None, class_zero)
@@ -402,7 +408,8 @@ class _TilePrefetcher:
 
 
 def save_predictions(predict_model, predict_path, regression, merge=False, all_classes=False, specific_class=None, large_file=False,
-                     AOI=None, year=None, validation_vision=True, class_zero=False, batch_size=16, timing: Optional[dict] = None):
+                     AOI=None, year=None, validation_vision=True, class_zero=False, batch_size=16, timing: Optional[dict] = None,
+                     batch_invariant: bool = False):
     rank, local_rank, world = _dist_ctx()
     dist = _dist()
     learn = load_learner(Path(predict_model), device=f"cuda:{local_rank}" if world > 1 else "cuda")
@@ -455,7 +462,8 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
             return ops.WindowBatch(ops.WindowSource(pf.upload(buf, dev), div255_twice=div2), ztab, 0, n_pad, buf.shape[2], buf.shape[3])
 
         want = _want(regression, all_classes, specific_class)
-        out = _run_merge(model, places, MH, MW, regression, int8_merge, rank, world, batch_size, make_input, want, timing)
+        with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):          # (see predict_raster)
+            out = _run_merge(model, places, MH, MW, regression, int8_merge, rank, world, batch_size, make_input, want, timing)
         if timing is not None:
             timing["tiles_per_s_end_to_end"] = len(tiles) / (time.perf_counter() - t_start)
         if rank != 0:
@@ -481,7 +489,8 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
     ztab = ops.window_table([[0, 0, j, 0] for j in range(batch_size)], dev)
     for first, n, buf in pf:
         wb = ops.WindowBatch(ops.WindowSource(pf.upload(buf, dev), div255_twice=div2), ztab, 0, buf.shape[0], buf.shape[2], buf.shape[3])
-        z = model.forward_windows(wb)
+        with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):
+            z = model.forward_windows(wb)
         zs = ops.TS(z.buf[:n], z.co, z.C)
         if regression:       # predict.py:195-197: tile_preds[1] = raw outputs [1,H,W]
             probs, amax = torch.empty((n, C, z.H, z.W), dtype=torch.float32, device=dev), None

@@ -82,6 +82,25 @@ def test_batch_of_16_equals_tiles_alone(pair, batch):
             assert int(diff.sum()) <= 4 and bool(((top2[0] - top2[1])[diff] <= 2 * err).all())
 
 
+def test_batch_invariant_plans_make_a_batch_equal_its_tiles_alone_bit_for_bit(pair, batch):
+    """unet_tuning.plan_batch = 1 (predict_raster(batch_invariant=True)): every launch is planned as if its batch were ONE tile, so a tile inside
+    a batch of 16 runs exactly the kernels, tiles and split chains it runs alone -- logits and masks identical BIT FOR BIT, the padded last
+    batch of a raster included.  (Default plans trade that for throughput: the test above.)"""
+    from unet_amd import ops
+    _, model = pair
+    model.eval()
+    x = batch[0].cuda()
+    with torch.no_grad(), ops.tuning(plan_batch=1):
+        zb = model(x).clone()
+        _, mb = model.predict_probs(x)
+        for n in (1, 5):
+            i0 = 3
+            zi = model(x[i0:i0 + n]).clone()
+            assert torch.equal(zi, zb[i0:i0 + n]), n
+            _, mi = model.predict_probs(x[i0:i0 + n])
+            assert torch.equal(mi, mb[i0:i0 + n]), n
+
+
 def test_two_conv_kernels_agree_on_full_batch_logits(pair, batch):
     from unet_amd._lib import lib
     _, model = pair

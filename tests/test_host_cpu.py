@@ -206,6 +206,18 @@ def test_tuning_travels_with_the_descriptor_and_the_library_keeps_no_state():
         assert L.lib.unet_conv2d_variant(C.byref(off)) % 10 == 0
     bad = desc(L.Tuning())          # a zeroed struct is not the default: refused with a message, not silently planned
     assert L.lib.unet_conv2d_variant(C.byref(bad)) == -1 and b"unet_tuning_default" in L.lib.unet_last_error()
+    # plan_batch: the planner sizes tiles / splits for that many images whatever N is (batch-invariant predictions)
+    def deep(N, tuning=None):
+        d = L.ConvDesc()
+        for k, v in dict(x=0x100000, x_cs=512, x_co=0, wp=0x200000, y=0x300000, y_cs=512, y_co=0, N=N, IH=16, IW=16, Cin=512, OH=16,
+                         OW=16, Cout=512, ks=3, stride=1, kind=0, flags=0, dtype=L.F32, splitk_ws=0x400000, splitk_ws_floats=1 << 30).items():
+            setattr(d, k, v)
+        if tuning is not None:
+            d.tuning = C.pointer(tuning)
+        return L.lib.unet_conv2d_variant(C.byref(d))
+    one = L.Tuning.default(plan_batch=1)
+    assert deep(1) != deep(16)                                   # the default plan follows the batch ...
+    assert deep(1, one) == deep(16, one) == deep(1)              # ... plan_batch = 1 plans every batch like a single image
     # the Python-side context manager: thread-local, nests, leaves nothing behind
     assert ops._tuning_ptr() is None
     with ops.tuning(conv_splitk=0) as t0:

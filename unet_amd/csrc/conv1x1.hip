@@ -192,7 +192,8 @@ static bool shape_ok(const unet_conv_desc* d) {
     if (d->Cin < kct || d->Cin % kct != 0) return false;
     if (d->cout_begin % 128 != 0) return false;
     const int cols = d->cout_count ? d->cout_count : d->Cout;
-    const long long P = (long long)d->N * d->OH * d->OW;
+    const int pb = tuning_of(d->tuning).plan_batch;          // (the grid test is a plan decision: unet_tuning.plan_batch makes it batch-invariant)
+    const long long P = (long long)(pb > 0 ? pb : d->N) * d->OH * d->OW;
     return ((P + 127) / 128) * ((cols + 127) / 128) >= 256;
 }
 bool conv_gemm1x1_applies(const unet_conv_desc* d) { return tuning_of(d->tuning).conv1x1_gemm > 0 && shape_ok(d); }

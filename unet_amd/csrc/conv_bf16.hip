@@ -1065,7 +1065,7 @@ int launch_tw(const Plan& p, int y_f32, hipStream_t st) {
 int plan_bf16(const unet_conv_desc* d, Plan* p, int splitk = -1) {
     UNET_CHECK_ARG(d != nullptr, "conv: null desc");
     const unet_tuning t = unetconv::tuning_of(d->tuning);
-    int rc = unetconv::make_plan(d, p, KCB, 8, 16, t.bf16_big_tile, splitk < 0 ? t.conv_splitk : splitk);
+    int rc = unetconv::make_plan(d, p, KCB, 8, 16, t.bf16_big_tile, splitk < 0 ? t.conv_splitk : splitk, t.plan_batch);
     p->tune = t;
     if (rc != UNET_OK) return rc;
     UNET_CHECK_ARG(d->colsum == nullptr && d->colsumsq == nullptr, "conv bf16: column sums are not available in the bf16 kernel");

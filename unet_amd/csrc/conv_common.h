@@ -249,7 +249,8 @@ __device__ __forceinline__ void st_act(unsigned short* p, float v) { *p = __buil
 // strides, offsets and the zero-padded channel count of a slice are multiples of vec; mf: MFMA shape of the fp32 kernels (16 | 32)
 // big_tile: allow the 256-pixel workgroup tile (bf16 kernel: the math is 16x cheaper, so halving the filter-operand loads per MFMA pays)
 // splitk: unet_tuning.conv_splitk of this plan (0: never split; callers that must not split pass 0)
-static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf, int big_tile, int splitk) {
+// plan_batch: unet_tuning.plan_batch (0: the descriptor's N decides tile sizes / splits; n: as if the batch were n images)
+static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, int mf, int big_tile, int splitk, int plan_batch = 0) {
     UNET_CHECK_ARG(d != nullptr, "conv: null desc");
     UNET_CHECK_ARG(d->x && d->wp && d->y, "conv: null tensor pointer");
     UNET_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv: ks must be 1 or 3 (got %d)", d->ks);
@@ -357,7 +358,7 @@ static inline int make_plan(const unet_conv_desc* d, Plan* p, int kc, int vec, i
     // small problems (deep 16x16 / 32x32 stages): shrink the tile until the grid can fill 256 CUs x 2
     auto blocks = [&](int bm, int bn) {
         const int th_ = bm / p->tw;
-        return (long long)d->N * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(cols, bn) * p->nparity;
+        return (long long)(plan_batch > 0 ? plan_batch : d->N) * unet::cdiv(k.TSH, th_) * unet::cdiv(k.TSW, p->tw) * unet::cdiv(cols, bn) * p->nparity;
     };
     // Split-K first: a grid that cannot fill the chip with full-size tiles although the reduction is long (deep low-resolution stages,
     // small batches: BASELINE configs[0], predict at batch 1).  Instead of shrinking the tile -- fewer MACs per operand byte and still one

@@ -736,6 +736,7 @@ const unet_tuning& tuning_defaults() {
         v.wgrad_bf16_k4 = 1;
         v.wgrad_1x1 = 1;
         v.wgrad_narrow = 1;
+        v.plan_batch = 0;
         return v;
     }();
     return t;
@@ -753,7 +754,7 @@ static int make_plan(const unet_conv_desc* d, Plan* p, int splitk = -1) {
     UNET_CHECK_ARG(d != nullptr, "conv: null desc");
     const unet_tuning t = unetconv::tuning_of(d->tuning);
     UNET_CHECK_ARG(t.mfma_shape == 16 || t.mfma_shape == 32, "conv: unet_tuning.mfma_shape must be 16 or 32 (start from unet_tuning_default())");
-    const int rc = unetconv::make_plan(d, p, KC, 4, t.mfma_shape, t.f32_big_tile ? 1 : 0, splitk < 0 ? t.conv_splitk : splitk);
+    const int rc = unetconv::make_plan(d, p, KC, 4, t.mfma_shape, t.f32_big_tile ? 1 : 0, splitk < 0 ? t.conv_splitk : splitk, t.plan_batch);
     p->tune = t;
     return rc;
 }
