@@ -27,6 +27,10 @@ class TrainStep:
         self.reg_kind: Optional[str] = None     # "mse" | "l1" | "smoothl1": regression mode (float targets, n_out = 1)
         self.reg_beta = 0.5
         self.use_graph = use_graph and world == 1
+        if self.use_graph:
+            # a replayed graph has no host in the loop: the second stream of the weight gradients buys nothing there and its
+            # fork / join nodes cost (cfg1 fp32: 7.51 ms per replay without, 7.69 with; bf16: 4.00 / 4.33)
+            model.ctx.wgrad_overlap = False
         self._graph = None
         self._calls = 0
         self._xs = self._ys = self._loss = None
