@@ -190,6 +190,27 @@ def test_raster_kernels_equal_the_tile_path(case):
         assert np.array_equal(am, ref.argmax(0).astype(np.uint8))
 
 
+@pytest.mark.parametrize("act_dtype", ["f32", "bf16"])
+def test_predict_raster_batch_invariant_is_the_same_for_every_batch_size(act_dtype):
+    """predict_raster(batch_invariant=True) = unet_tuning.plan_batch 1: every launch is planned as if its batch were one window, so windows in
+    batches of 1, 3 and 7 (padded last batches included) give the SAME probabilities and the same mask bit for bit -- the reference predicts
+    tile by tile (predict.py:191-193).  Without the flag the results agree to rounding level only (the planner follows the batch)."""
+    import predict as P
+    model, _ = _pair("xresnet18", 4, 3, 128, seed=23, act_dtype=act_dtype)
+    img = _raster(9, 4, 300, 420)
+    ref_mask = ref_probs = None
+    for bs in (1, 3, 7):
+        mask = P.predict_raster(model, img, 128, 0.2, batch_size=bs, batch_invariant=True)
+        probs = P.predict_raster(model, img, 128, 0.2, batch_size=bs, all_classes=True, batch_invariant=True)
+        if ref_mask is None:
+            ref_mask, ref_probs = mask, probs
+        else:
+            assert np.array_equal(mask, ref_mask), bs
+            assert np.array_equal(probs, ref_probs), bs
+    loose = P.predict_raster(model, img, 128, 0.2, batch_size=7, all_classes=True)
+    assert np.abs(loose - ref_probs).max() <= (2e-2 if act_dtype == "bf16" else 1e-4)
+
+
 def test_window_kernels_unit():
     """nodata zeroing, non-zero counts and the window gather against numpy, every sample type"""
     from unet_amd import ops
