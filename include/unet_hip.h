@@ -64,8 +64,9 @@ typedef struct {
                                2 = the planner order of round 3's first half, 3.. = from 64 (n - 2) blocks up */
     int t256_tiles_per_wg;  /* consecutive tiles per workgroup of conv_bf16_t256_kernel; 0 = the launcher's choice (default) */
     int t256_sliver;        /* 1: a 7-tile fp32 block whose last tile holds 1..4 channels multiplies them as a 4x4x1 sliver (default) */
-    int conv1x1_gemm;       /* 1: plain 1x1 / stride-1 convs of whole chunks on conv1x1_gemm_kernel; 0: the implicit-GEMM kernels (default: the
-                               flat-pixel GEMM measured slower on them -- csrc/conv1x1.hip; pixel_shuffle descriptors use it regardless) */
+    int conv1x1_gemm;       /* plain 1x1 / stride-1 convs of whole chunks on conv1x1_gemm_kernel (the flat-pixel GEMM, csrc/conv1x1.hip):
+                               0 = auto (default): its LDS-staged form for bf16 storage, the implicit-GEMM kernels for fp32 (measured);
+                               1 = its direct form, 2 = its staged form (both storage types), -1 = never.  pixel_shuffle descriptors always use it */
     int wgrad_mfma_shape;   /* fp32 weight gradient: 32 (default) | 16 (opt-in: loses to wave imbalance) */
     int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
     int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */

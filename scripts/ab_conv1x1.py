@@ -33,3 +33,21 @@ for H, Cin, Cout in [(16, 512, 1024), (32, 512, 1024), (64, 384, 768), (128, 256
     tot += min(ts)
     print(f"[gemm1x1 {tag} {sys.argv[1] if len(sys.argv) > 1 else 'f32'}] {H:4d}^2 {Cin:4d}->{Cout:4d}  {min(ts) * 1e3:7.1f} us  {fl / min(ts) / 1e9:6.1f} TF  {by / min(ts) / 1e6:7.1f} GB/s  variant {ops.conv2d_variant(x, wp, y, 1, 1)}", flush=True)
 print(f"[gemm1x1 {tag}] sum {tot:.3f} ms")
+# the fused final upsample: conv1x1 96 -> 384 + ReLU + PixelShuffle stored into a 100-wide concat slice at 16 x 512^2
+x = TS(torch.randn((N, 256, 256, 96), device="cuda", generator=g).to(dt), 0, 96)
+X = TS(torch.empty((N, 512, 512, 104 if dt == torch.bfloat16 else 100), device="cuda", dtype=dt), 0, 96)
+w = torch.randn((384, 96, 1, 1), device="cuda", generator=g) / 96 ** 0.5
+b = torch.randn(384, device="cuda", generator=g)
+wp = ops.pack_weights(w, 2, dtype=dt)
+ts = []
+for rep in range(3):
+    for _ in range(2):
+        ops.conv1x1_shuffle(x, wp, X, bias=b, relu=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.conv1x1_shuffle(x, wp, X, bias=b, relu=True)
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 5)
+print(f"[gemm1x1 {tag} {sys.argv[1] if len(sys.argv) > 1 else 'f32'}] fused upsample 96->384 + shuffle  {min(ts) * 1e3:7.1f} us  checksum {float(X.view().double().sum()):.6e}")

@@ -1,2 +1,3 @@
 #!/bin/bash
-python -m pytest tests/test_raster_gpu.py -x -q -k "batch_invariant" 2>&1 | grep -v amdgpu.ids | tail -8
+python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -4
+python scripts/ab_shuffle.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_p_shuffle_staged.log

@@ -114,9 +114,10 @@ def test_conv_forward_dgrad_wgrad_bf16(case):
 
 
 @pytest.mark.parametrize("case", [(96, 384, 64, 64, 8), (64, 256, 61, 67, 5), (256, 96, 128, 128, 2), (32, 200, 128, 128, 2)])
-def test_conv1x1_gemm_kernel_bf16(case):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_conv1x1_gemm_kernel_bf16(case, mode):
     from unet_amd import ops
-    with ops.tuning(conv1x1_gemm=1):
+    with ops.tuning(conv1x1_gemm=mode):
         _conv1x1_gemm_case_bf16(case)
 
 

@@ -354,9 +354,10 @@ def test_conv_f32_t256_kernel(ops, case):
     (16, 200, 128, 128, 2),     # one reduction chunk; 128 + 72 channels = two launches of ops.conv2d (channel ranges)
     (48, 132, 128, 128, 3),     # three chunks (odd count: the second register set ends on a repeated load), last block 4 channels wide
 ])
-def test_conv1x1_gemm_kernel(ops, case):
-    with ops.tuning(conv1x1_gemm=1):          # (off by default: measured slower than the implicit-GEMM kernels on plain 1x1 convs; the
-        _conv1x1_gemm_case(ops, case)         #  pixel-shuffle store uses the same kernel code regardless)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_conv1x1_gemm_kernel(ops, case, mode):
+    with ops.tuning(conv1x1_gemm=mode):       # 1: operands global -> VGPR, 2: the pixel chunk staged once per workgroup through LDS (256-pixel tile)
+        _conv1x1_gemm_case(ops, case)
 
 
 def _conv1x1_gemm_case(ops, case):
@@ -394,8 +395,14 @@ def _conv1x1_gemm_case(ops, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("case", [(96, 96, 64, 64, 8), (64, 32, 61, 67, 8), (32, 16, 128, 128, 2)])
-def test_conv1x1_shuffle_is_conv_relu_pixelshuffle(ops, case, bf16):
+def test_conv1x1_shuffle_is_conv_relu_pixelshuffle(ops, case, bf16, mode):
+    with ops.tuning(conv1x1_gemm=mode):       # (0: the default = LDS-staged form of the kernel, 1: its direct form)
+        _conv1x1_shuffle_case(ops, case, bf16)
+
+
+def _conv1x1_shuffle_case(ops, case, bf16):
     """unet_conv_desc.pixel_shuffle: ONE launch = PixelShuffle(2)(relu(conv1x1(x) + b)) written into a channel slice of the up-sampled buffer
     (mode-2 packed image: columns in pixel-shuffle order); its adjoint unet_shuffle_bwd_xmask takes the ReLU mask from that slice.  Against
     torch: F.pixel_shuffle(F.relu(F.conv2d(..)), 2) and its autograd gradient w.r.t. the conv output."""

@@ -34,10 +34,15 @@ struct G1Args {
     int ps, nf, H, W;
 };
 
-template <typename T>
+// STAGED = false: the pixel operand of a wave goes global -> VGPR directly (128-pixel workgroup tile, 4 x 4 tiles per wave).
+// STAGED = true (unet_tuning.conv1x1_gemm = 2): a 256-pixel workgroup tile whose 64-byte pixel chunk is fetched ONCE per workgroup with coalesced
+// 16-byte items (4 per thread), staged through a double-buffered LDS image (rows of 64 + 32 bytes: conflict-free ds_read_b128 groups, as in the
+// 256-pixel 3x3 kernel) and read by both channel-half waves; 8 x 4 tiles per wave, one barrier per chunk.
+template <typename T, bool STAGED>
 __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
     constexpr int EB = (int)sizeof(T), KCB = 64;                  // bytes per element / per reduction chunk of one pixel
-    constexpr int MT = 4, NT = 4;
+    constexpr int MT = STAGED ? 8 : 4, NT = 4, TPIX = MT * 32, ROWB = 96, BUFB = TPIX * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, kq = lane >> 4;
     const long long per_xcd = (long long)(gridDim.x >> 3);
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
     if (wg >= a.ntiles) return;
     const int nb = (int)(wg % a.ntn);
     const long long pt = wg / a.ntn;
-    const long long p0 = pt * 128 + wm * 64;
+    const long long p0 = pt * TPIX + wm * (TPIX / 2);
     const int c0 = a.n_base + nb * 128;                             // first produced channel of the block
 
     // operand addresses: pixel m * 16 + l15 of this wave's 64 (clamped to the last pixel: rows beyond P are computed and not stored)
@@ -70,13 +75,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xa[MT], wa[NT], xb[MT], wb[NT];
-    auto load = [&](f32x4 (&xs)[MT], f32x4 (&ws)[NT], int c) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xs[m] = *reinterpret_cast<const f32x4*>(xp[m] + (size_t)c * KCB);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) ws[n] = *reinterpret_cast<const f32x4*>(wl + (size_t)c * slab + (size_t)n * 2048);
-    };
     auto mma = [&](const f32x4 (&xs)[MT], const f32x4 (&ws)[NT]) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -95,15 +93,67 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
             }
         }
     };
-    // two chunks per trip, the next chunk's operands in flight behind the current chunk's MFMAs; beyond the last chunk the loads repeat it
-    // (unconditional: the compiler's wait counts stay exact), the MFMAs are skipped
     const int last = a.nchunks - 1;
-    load(xa, wa, 0);
-    for (int c = 0; c < a.nchunks; c += 2) {
-        load(xb, wb, c + 1 < last ? c + 1 : last);
-        mma(xa, wa);
-        load(xa, wa, c + 2 < last ? c + 2 : last);
-        if (c + 1 < a.nchunks) mma(xb, wb);
+    if constexpr (!STAGED) {
+        f32x4 xa[MT], wa[NT], xb[MT], wb[NT];
+        auto load = [&](f32x4 (&xs)[MT], f32x4 (&ws)[NT], int c) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xs[m] = *reinterpret_cast<const f32x4*>(xp[m] + (size_t)c * KCB);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ws[n] = *reinterpret_cast<const f32x4*>(wl + (size_t)c * slab + (size_t)n * 2048);
+        };
+        // two chunks per trip, the next chunk's operands in flight behind the current chunk's MFMAs; beyond the last chunk the loads repeat it
+        // (unconditional: the compiler's wait counts stay exact), the MFMAs are skipped
+        load(xa, wa, 0);
+        for (int c = 0; c < a.nchunks; c += 2) {
+            load(xb, wb, c + 1 < last ? c + 1 : last);
+            mma(xa, wa);
+            load(xa, wa, c + 2 < last ? c + 2 : last);
+            if (c + 1 < a.nchunks) mma(xb, wb);
+        }
+    } else {
+        // staging items of this thread: item e = tid + 256 it covers piece (e & 3) of pixel (e >> 2) of the 256-pixel tile
+        const char* sp[4];
+        unsigned so[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + 256 * it, pe = e >> 2, q = e & 3;
+            long long p = pt * TPIX + pe;
+            p = p < a.P ? p : a.P - 1;
+            sp[it] = a.x + ((size_t)p * a.x_cs + a.x_co) * EB + 16 * q;
+            so[it] = (unsigned)(pe * ROWB + 16 * q);
+        }
+        const unsigned rbase = (unsigned)((wm * (TPIX / 2) + l15) * ROWB + 16 * kq);          // pixel tile m of this wave: + m * 16 * ROWB
+        f32x4 st[4], wa[NT], wb[NT];
+        auto gload = [&](f32x4 (&ws)[NT], int c) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) st[it] = *reinterpret_cast<const f32x4*>(sp[it] + (size_t)c * KCB);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ws[n] = *reinterpret_cast<const f32x4*>(wl + (size_t)c * slab + (size_t)n * 2048);
+        };
+        auto sstore = [&](int buf) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(lds + buf * BUFB + so[it]) = st[it];
+        };
+        auto stage = [&](const f32x4 (&ws)[NT], int buf) {
+            f32x4 xs[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xs[m] = *reinterpret_cast<const f32x4*>(lds + buf * BUFB + rbase + m * 16 * ROWB);
+            mma(xs, ws);
+        };
+        gload(wa, 0);
+        sstore(0);
+        __syncthreads();
+        for (int c = 0; c < a.nchunks; c += 2) {
+            gload(wb, c + 1 < last ? c + 1 : last);          // chunk c + 1: pixel items + filter tiles in flight behind the MFMAs of chunk c
+            stage(wa, 0);
+            sstore(1);
+            __syncthreads();
+            gload(wa, c + 2 < last ? c + 2 : last);
+            if (c + 1 < a.nchunks) stage(wb, 1);
+            sstore(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane (l15, kq) holds channels 4 kq .. 4 kq + 3 of tile n for pixel l15 of pixel tile m
@@ -181,11 +231,13 @@ namespace unetconv {
 
 // the launches this kernel takes (the descriptor was validated by the planner): one filter image for the batch, whole 64-byte reduction
 // chunks, a grid that fills the chip (smaller problems keep the generic kernels and their split reduction)
-// Measured (scripts/ab_conv1x1.py, isolated launches at batch 16, profiles/r04_d_conv1x1.log): as a REPLACEMENT of the implicit-GEMM kernels on
-// plain 1x1 convs this kernel loses -- fp32 5.98 vs 4.12 ms over the ten PixelShuffle-conv launches of a cfg2 step (65-72 vs 100-115 TFLOP/s),
-// bf16 1.77 vs 1.40 ms: two waves fetch every pixel row through the L1 where the LDS-staged kernels fetch it once, and one chunk of prefetch
-// distance does not cover the memory latency at three waves per SIMD.  unet_tuning.conv1x1_gemm therefore defaults to 0; what the kernel is
-// for is the pixel-shuffle store (unet_conv_desc.pixel_shuffle), where it replaces conv + a 1.6 GB shuffle pass and nets 0.6 / 0.4 ms.
+// Measured (scripts/ab_conv1x1.py: the ten PixelShuffle-conv launches of a cfg2 step, isolated, batch 16; profiles/r04_d_conv1x1.log,
+// r04_o_conv1x1_staged.log).  The DIRECT form (operands global -> VGPR) loses to the implicit-GEMM kernels as a replacement on plain 1x1 convs --
+// fp32 5.8 vs 4.1 ms, bf16 1.77 vs 1.38: two waves fetch every pixel row through the L1 and one chunk of prefetch distance leaves the waves
+// waiting (PMC: MFMA busy 0.45-0.55 vs 0.68-0.77, wait / active 21 vs 5).  The STAGED form (pixel chunk once per workgroup through LDS, 256-pixel
+// tile) is level with them in fp32 (4.22 vs 4.08: it loses where 256-pixel tiles leave a half-empty last round of workgroups) and ahead in bf16
+// storage (1.28 vs 1.38 ms; the fused upsample 503 vs 543 us).  unet_tuning.conv1x1_gemm: 0 = auto (default): staged for bf16 storage, the
+// implicit-GEMM kernels for fp32; 1 = direct, 2 = staged (both storage types), -1 = never; pixel_shuffle descriptors always run here (staged).
 static bool shape_ok(const unet_conv_desc* d) {
     if (d->ks != 1 || d->stride != 1 || d->wp_img_stride != 0 || d->colsum != nullptr || d->colsumsq != nullptr) return false;
     const int kct = d->dtype == UNET_BF16 ? 32 : 16;
@@ -196,7 +248,14 @@ static bool shape_ok(const unet_conv_desc* d) {
     const long long P = (long long)(pb > 0 ? pb : d->N) * d->OH * d->OW;
     return ((P + 127) / 128) * ((cols + 127) / 128) >= 256;
 }
-bool conv_gemm1x1_applies(const unet_conv_desc* d) { return tuning_of(d->tuning).conv1x1_gemm > 0 && shape_ok(d); }
+static int form_of(const unet_conv_desc* d) {          // 0: not this kernel, 1: direct, 2: staged
+    const int mode = tuning_of(d->tuning).conv1x1_gemm;
+    if (d->pixel_shuffle) return mode == 1 ? 1 : 2;
+    if (mode < 0) return 0;
+    if (mode == 0) return d->dtype == UNET_BF16 ? 2 : 0;
+    return mode == 1 ? 1 : 2;
+}
+bool conv_gemm1x1_applies(const unet_conv_desc* d) { return form_of(d) != 0 && shape_ok(d); }
 
 // unet_conv_desc.pixel_shuffle: validated here (the planner of the implicit-GEMM kernels never sees these descriptors); only this kernel
 // stores that way, so a descriptor it does not take is UNSUPPORTED (callers ask unet_conv2d_variant first and keep the two-pass form)
@@ -236,13 +295,20 @@ int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
     a.Cout = d->Cout;
     a.relu = (d->flags & UNET_CONV_RELU) ? 1 : 0;
     a.y_f32 = bf ? d->y_f32 : 1;
+    const bool staged = form_of(d) == 2;
+    const int tpix = staged ? 256 : 128;
     a.ntn = unet::cdiv(a.n_end - a.n_base, 128);
-    a.ntiles = ((a.P + 127) / 128) * a.ntn;
+    a.ntiles = ((a.P + tpix - 1) / tpix) * a.ntn;
     a.ps = d->pixel_shuffle ? 1 : 0; a.nf = d->Cout / 4; a.H = d->OH; a.W = d->OW;
     UNET_CHECK_ARG(a.ntiles < (1ll << 31) - 8, "conv 1x1: grid too large");
     const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-    if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv1x1_gemm_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+    if (staged) {
+        if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short, true>), dim3(grid), dim3(256), 2 * 256 * 96, st, a);
+        else hipLaunchKernelGGL((conv1x1_gemm_kernel<float, true>), dim3(grid), dim3(256), 2 * 256 * 96, st, a);
+    } else {
+        if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short, false>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv1x1_gemm_kernel<float, false>), dim3(grid), dim3(256), 0, st, a);
+    }
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
