@@ -5,13 +5,15 @@ DynamicUnet (BASELINE.json configs[1]: batch 16 per MI355X; configs[2]: the same
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0.  `value` = tiles processed by all ranks / wall time of the K timed steps (max over
-ranks), inputs resident in HBM.  `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv,
-all launches of its main instantiation: forward and input-gradient of every wide layer): summed algorithmic FLOPs /
-summed launch durations measured with events on the launch stream inside the timed region.  `cpu_baseline` = the torch-CPU oracle of the same step
-on this host's cores, on a bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`: the other BASELINE configurations measured
-in the same process after the headline -- the bf16-storage variant of configs[1] (with its own roofline object), predict at batch 16 / 1,
-configs[0] (cfg1) and configs[4] (cfg5: predict.predict_raster over a 20000 x 20000 raster) in fp32 and bf16 storage.  Every rank reports its own
-clock and the time its compute stream waited for the gradient all-reduce in `devices`.
+ranks), inputs resident in HBM.  `roofline` is the dominant kernel (the fp32 form of the 256-pixel implicit-GEMM conv tile,
+its large-layer launches: forward and input-gradient of every wide 3x3 layer): summed algorithmic FLOPs / summed launch durations measured with
+events on the launch stream inside the timed region; `roofline.traffic` comes from the committed counter summary it names
+(`traffic_source`, `traffic_code`, `traffic_code_current`).  `cpu_baseline` = the torch-CPU oracle of the same step on this host's cores, on a
+bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`, every entry in its own try: the bf16-storage variant of configs[1]
+(value un-probed, roofline from a second, probed run), predict at batch 16 / 1, configs[0] (cfg1), configs[3] (cfg4: xresnet50 8 -> 10,
+1024 x 1024, fp32), the step with self-attention on (the reference's shipped default) and configs[4] (cfg5: predict.predict_raster over a
+20000 x 20000 raster) in fp32 and bf16 storage.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
+recorded and exits non-zero.  Every rank reports its own clock and the time its compute stream waited for the gradient all-reduce in `devices`.
 """
 from __future__ import annotations
 
