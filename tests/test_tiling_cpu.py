@@ -87,3 +87,36 @@ def test_lzw_decoder_rejects_garbage_and_overflow():
     assert lib.unet_tiff_lzw_decode(src, len(src), dst, 16) == 2 and dst.raw[:2] == b"AB"
     assert lib.unet_tiff_lzw_decode(src, len(src), dst, 1) == -1                     # capacity exceeded
     assert lib.unet_tiff_packbits_decode(bytes([0x02, 1, 2, 3, 0xfe, 9]), 6, dst, 16) == 6 and dst.raw[:6] == bytes([1, 2, 3, 9, 9, 9])
+
+
+def test_tiff_decoders_against_libtiff_on_random_images(tmp_path):
+    """fuzz: random sizes / contents / sample types written by Pillow's libtiff binding with LZW, Deflate and PackBits (with and without
+    Predictor 2) must read back bit for bit -- high-entropy uint8 strips fill the 4096-entry LZW table (ClearCode inside a strip), the
+    run-length images exercise long KwKwK chains"""
+    from PIL import Image
+    rng = np.random.default_rng(20261005)
+    n = 0
+    for trial in range(24):
+        H, W = int(rng.integers(1, 260)), int(rng.integers(1, 260))
+        kind = trial % 4
+        if kind == 0:
+            a = rng.integers(0, 256, (H, W)).astype(np.uint8)
+        elif kind == 1:
+            a = (rng.integers(0, 4, (H, W)) * 60).astype(np.uint8)
+        elif kind == 2:
+            a = rng.integers(0, 65535, (H, W)).astype(np.uint16)
+        else:
+            a = (np.add.outer(np.arange(H), np.arange(W)) % 7).astype(np.uint8)[..., None].repeat(3, 2)
+        ref = a if a.ndim == 2 else np.moveaxis(a, -1, 0)
+        for comp in ("tiff_lzw", "tiff_adobe_deflate", "packbits"):
+            for pred in (False, True):
+                if pred and comp == "packbits":
+                    continue
+                kw = {"compression": comp}
+                if pred:
+                    kw["tiffinfo"] = {317: 2}
+                Image.fromarray(a).save(tmp_path / "t.tif", format="TIFF", **kw)
+                got, _ = read_tiff(tmp_path / "t.tif")
+                assert np.array_equal(got, ref), (trial, comp, pred, a.shape)
+                n += 1
+    assert n == 120
