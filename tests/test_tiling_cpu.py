@@ -120,3 +120,27 @@ def test_tiff_decoders_against_libtiff_on_random_images(tmp_path):
                 assert np.array_equal(got, ref), (trial, comp, pred, a.shape)
                 n += 1
     assert n == 120
+
+
+def test_write_tiff_switches_to_bigtiff_and_both_forms_are_read_by_libtiff(tmp_path):
+    """write_tiff emits BigTIFF when the data would not fit 32-bit offsets (GDAL's BIGTIFF=IF_NEEDED: the all-classes probabilities of a
+    20000 x 20000 scene are 8 GB); both header forms are read back by this reader and by Pillow's libtiff (single-band files: Pillow has
+    no mode for 3 MINISBLACK samples)"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    gt = (400000.0, 0.5, 0.0, 5700000.0, 0.0, -0.5)
+    for big in (False, True):
+        a = rng.integers(0, 255, (3, 37, 53)).astype(np.uint8)
+        write_tiff(tmp_path / "w.tif", a, geotransform=gt, nodata=0, bigtiff=big)
+        assert open(tmp_path / "w.tif", "rb").read(4) == (b"II+\x00" if big else b"II*\x00")
+        b, meta = read_tiff(tmp_path / "w.tif")
+        assert np.array_equal(a, b) and meta["geotransform"] == gt and meta["nodata"] == 0.0
+        for m in (rng.integers(0, 255, (41, 29)).astype(np.uint8), rng.random((41, 29)).astype(np.float32)):
+            write_tiff(tmp_path / "m.tif", m, geotransform=gt, bigtiff=big)
+            assert np.array_equal(np.array(Image.open(tmp_path / "m.tif")), m)
+            g, _ = read_tiff(tmp_path / "m.tif")
+            assert np.array_equal(g, m)
+    # the automatic switch: decided from the byte count alone (not written here: 4 GB)
+    import inspect
+    from unet_amd import tiffio
+    assert "(1 << 32) - (1 << 20)" in inspect.getsource(tiffio.write_tiff)

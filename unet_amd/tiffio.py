@@ -177,8 +177,10 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     return (arr[0] if arr.shape[0] == 1 else arr), meta
 
 
-def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int, tuple]] = None, nodata=None) -> None:
-    """Uncompressed, single strip, pixel-interleaved little-endian TIFF of a [C,H,W] or [H,W] array."""
+def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int, tuple]] = None, nodata=None, bigtiff: Optional[bool] = None) -> None:
+    """Uncompressed, single strip, pixel-interleaved little-endian TIFF of a [C,H,W] or [H,W] array.  bigtiff None: BigTIFF (64-bit offsets)
+    when the file would not fit 32-bit offsets -- what GDAL's BIGTIFF=IF_NEEDED does for the reference's outputs (predict.py:19-52): the
+    all-classes probabilities of a 20000 x 20000 scene are 8 GB."""
     a = np.asarray(arr)
     if a.ndim == 2:
         a = a[None]
@@ -190,8 +192,10 @@ def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int
     if a.dtype == np.float64:
         a = a.astype(np.float32)
     kind = {"u": 1, "i": 2, "f": 3}[a.dtype.kind]
-    data = np.ascontiguousarray(np.moveaxis(a, 0, -1)).astype(a.dtype.newbyteorder("<")).tobytes()
+    nbytes = C * H * W * a.dtype.itemsize
+    big = (nbytes > (1 << 32) - (1 << 20)) if bigtiff is None else bool(bigtiff)
     entries = []          # (tag, type, count, payload-bytes)
+    off_t, off_fmt = (16, "Q") if big else (4, "I")          # LONG8 / LONG for offsets and byte counts
 
     def add(tag, typ, vals):
         if typ == 2:
@@ -204,7 +208,7 @@ def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int
         entries.append((tag, typ, cnt, payload))
 
     add(256, 4, [W]); add(257, 4, [H]); add(258, 3, [a.dtype.itemsize * 8] * C); add(259, 3, [1])
-    add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [C]); add(278, 4, [H]); add(279, 4, [len(data)]); add(284, 3, [1])
+    add(262, 3, [1]); add(273, off_t, [0]); add(277, 3, [C]); add(278, 4, [H]); add(279, off_t, [nbytes]); add(284, 3, [1])
     if C > 1:
         add(338, 3, [0] * (C - 1))      # ExtraSamples: unspecified (what GDAL writes for MINISBLACK multi-band)
     add(339, 3, [kind] * C)
@@ -225,25 +229,34 @@ def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int
             add(t, 12, list(v))
     entries.sort(key=lambda e: e[0])
     n = len(entries)
-    ifd_off = 8
-    extra_off = ifd_off + 2 + 12 * n + 4
+    inl = 8 if big else 4                                     # bytes of the inline value / offset field
+    ifd_off = 16 if big else 8
+    extra_off = ifd_off + (8 + 20 * n + 8 if big else 2 + 12 * n + 4)
     extra = b""
-    body = b""
     placed = []
     for tag, typ, cnt, payload in entries:
-        if len(payload) <= 4:
-            placed.append((tag, typ, cnt, payload.ljust(4, b"\0")))
+        if len(payload) <= inl:
+            placed.append((tag, typ, cnt, payload.ljust(inl, b"\0")))
         else:
             if len(extra) % 2:
                 extra += b"\0"
-            placed.append((tag, typ, cnt, struct.pack("<I", extra_off + len(extra))))
+            placed.append((tag, typ, cnt, struct.pack("<" + off_fmt, extra_off + len(extra))))
             extra += payload
     if len(extra) % 2:
         extra += b"\0"
     data_off = extra_off + len(extra)
+    body = b""
     for tag, typ, cnt, val in placed:
         if tag == 273:
-            val = struct.pack("<I", data_off)
-        body += struct.pack("<HHI", tag, typ, cnt) + val
-    out = b"II" + struct.pack("<HI", 42, ifd_off) + struct.pack("<H", n) + body + struct.pack("<I", 0) + extra + data
-    Path(path).write_bytes(out)
+            val = struct.pack("<" + off_fmt, data_off)
+        body += struct.pack("<HH" + ("Q" if big else "I"), tag, typ, cnt) + val
+    if big:
+        head = b"II" + struct.pack("<HHHQ", 43, 8, 0, ifd_off) + struct.pack("<Q", n) + body + struct.pack("<Q", 0)
+    else:
+        head = b"II" + struct.pack("<HI", 42, ifd_off) + struct.pack("<H", n) + body + struct.pack("<I", 0)
+    with open(path, "wb") as f:                               # the pixel data is streamed band-interleaved row block by row block: no second copy
+        f.write(head + extra)
+        le = a.dtype.newbyteorder("<")
+        rows = max(1, (64 << 20) // max(1, C * W * a.dtype.itemsize))
+        for r0 in range(0, H, rows):
+            f.write(np.ascontiguousarray(np.moveaxis(a[:, r0:r0 + rows], 0, -1)).astype(le, copy=False).tobytes())
