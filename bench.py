@@ -11,8 +11,9 @@ events on the launch stream inside the timed region; `roofline.traffic` comes fr
 (`traffic_source`, `traffic_code`, `traffic_code_current`).  `cpu_baseline` = the torch-CPU oracle of the same step on this host's cores, on a
 bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`, every entry in its own try: the bf16-storage variant of configs[1]
 (value un-probed, roofline from a second, probed run), predict at batch 16 / 1, configs[0] (cfg1), configs[3] (cfg4: xresnet50 8 -> 10,
-1024 x 1024, fp32), the step with self-attention on (the reference's shipped default) and configs[4] (cfg5: predict.predict_raster over a
-20000 x 20000 raster) in fp32 and bf16 storage.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
+1024 x 1024, fp32), the step with self-attention on (the reference's shipped default), configs[4] (cfg5: predict.predict_raster over a
+20000 x 20000 raster) in fp32 and bf16 storage, and `fit_files`: Learner.fit_one_cycle over tile FILES through the product loader next to
+the resident-batch rate.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
 recorded and exits non-zero.  Every rank reports its own clock and the time its compute stream waited for the gradient all-reduce in `devices`.
 """
 from __future__ import annotations
@@ -267,6 +268,100 @@ def cfg5_bench(dtype, dev, side=20000, size=512, overlap=0.2, batch=16):
     return r
 
 
+def _write_tile_files(root: Path, n: int, log):
+    """n uint8 4x512x512 image tiles + uint8 masks as GeoTIFFs, once uncompressed (unet_amd.tiffio.write_tiff: what the reference's
+    create_tiles_unet.save_crop writes through GDAL's default creation options) and once LZW-compressed by libtiff (Pillow; skipped when
+    Pillow is missing).  Content: a ramp + low-amplitude noise, so that LZW compresses to ~2/3 like imagery does (uniform noise would make
+    every code a literal)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from unet_amd.tiffio import write_tiff
+    try:
+        from PIL import Image
+    except Exception:      # noqa: BLE001
+        Image = None
+    sets = {"none": root / "none", "lzw": root / "lzw"} if Image is not None else {"none": root / "none"}
+    for d in sets.values():
+        (d / "img").mkdir(parents=True)
+        (d / "mask").mkdir(parents=True)
+    ramp = (np.add.outer(np.arange(SIZE), np.arange(SIZE)) // 8)[None] + (np.arange(N_IN) * 7)[:, None, None]
+
+    def one(i):
+        g = np.random.default_rng(1000 + i)
+        img = ((ramp + 31 * i) + g.integers(0, 3, (N_IN, SIZE, SIZE))).astype(np.uint8)
+        blocks = g.integers(0, N_CLS, (SIZE // 32, SIZE // 32), dtype=np.uint8)
+        mask = np.repeat(np.repeat(blocks, 32, 0), 32, 1)
+        gt = (1000.0 + 100 * i, 0.2, 0.0, 5000.0, 0.0, -0.2)
+        write_tiff(sets["none"] / "img" / f"t{i:04d}.tif", img, geotransform=gt)
+        write_tiff(sets["none"] / "mask" / f"t{i:04d}.tif", mask, geotransform=gt)
+        if "lzw" in sets:
+            Image.fromarray(np.moveaxis(img, 0, -1), "RGBA").save(sets["lzw"] / "img" / f"t{i:04d}.tif", compression="tiff_lzw")
+            Image.fromarray(mask, "L").save(sets["lzw"] / "mask" / f"t{i:04d}.tif", compression="tiff_lzw")
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(one, range(n)))
+    log(f"fit_files: wrote {n} tiles x {len(sets)} encodings in {time.perf_counter() - t0:.1f} s under {root}")
+    return sets
+
+
+def fit_files_bench(dev, log, resident: dict, n_tiles: int = 512, batch: int = 16):
+    """The workflow the reference actually runs (train.py:345 -> learn.fit_one_cycle, data.py:18-28, utils.py:239-295): ONE epoch of
+    Learner.fit_one_cycle over tile FILES through the product loader (unet_amd/feed.py: decode pool -> pinned integer staging -> asynchronous
+    upload -> scaling / mask widening / flips on the device), default flip augmentation on, timed end to end (first file open to the last
+    optimizer step) and put next to the resident-batch step rate of the same process."""
+    import shutil
+    import tempfile
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, FlipAugment, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    root = Path(tempfile.mkdtemp(prefix="unet_fit_files_"))
+    out = {"tiles": n_tiles, "batch": batch, "what": "Learner.fit_one_cycle(1) over uint8 4x512x512 GeoTIFF tile files + uint8 masks, device feed "
+                                                       "(unet_amd/feed.py), flips on (n_transform_imgs 0.5); tiles/s end to end; ratio = / the "
+                                                       "resident-batch step rate measured in this process"}
+    try:
+        sets = _write_tile_files(root, n_tiles, log)
+        for enc, d in sets.items():
+            imgs = sorted((d / "img").iterdir())
+            masks = [d / "mask" / p.name for p in imgs]
+            for dtype in ("f32", "bf16"):
+                torch.manual_seed(0)
+                model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=dtype)
+                w = torch.full((N_CLS,), 1.0 / N_CLS, device=dev)
+
+                def learner(k):
+                    dls = DataLoaders(TileDataset(imgs[:k], masks[:k], "int8"), None, batch, device=dev, vocab=list("abcde"),
+                                      train_tfm=FlipAugment(n_transform_imgs=0.5, seed=1))
+                    ln = Learner(dls, model, loss_func=CrossEntropyLossFlat(axis=1, weight=w), path=root)
+                    ln._no_logging = True
+                    return ln
+                learner(4 * batch).fit_one_cycle(1, lr_max=slice(1e-5, 1e-4))        # warm-up: buffers, packed filters, page cache of the first files
+                ln = learner(n_tiles)
+                for _ in zip(range(2), ln.dls.train):                                # the loader's threads and pinned ring exist before the clock starts
+                    pass
+                for p in imgs + masks:                                              # page cache warm (the box's disk is not the subject)
+                    with open(p, "rb") as f:
+                        f.read()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ln.fit_one_cycle(1, lr_max=slice(1e-5, 1e-4))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                steps = n_tiles // batch
+                v = steps * batch / dt
+                res = resident.get(dtype)
+                out[f"{enc}_{dtype}"] = {"value": round(v, 2), "unit": "tiles/s", "seconds": round(dt, 3), "steps": steps,
+                                         "ms_per_step": round(dt / steps * 1e3, 3), "resident": res,
+                                         "ratio_to_resident": None if not res else round(v / res, 4),
+                                         "final_train_loss": round(float(ln.recorder.losses[-1]), 5),
+                                         "feed_workers": ln.dls.train._feeder.workers if ln.dls.train._feeder is not None else None}
+                log(f"fit_files {enc} {dtype}: {v:.1f} tiles/s ({dt:.2f} s), resident {res}")
+                del ln, model
+                torch.cuda.empty_cache()
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def cfg5_multi(dtype, dev, rank, world, side=int(os.environ.get("UNET_CFG5_SIDE", "20000")), size=512, overlap=0.2, batch=16):
     """BASELINE configs[4] as worded: the 20000 x 20000 raster predicted by ALL ranks -- predict.predict_raster partitions the windows into
     contiguous row blocks (one per rank), every rank keeps its strip of the mosaic, overlap rows travel as slabs to the neighbouring rank
@@ -449,6 +544,8 @@ def main():
                     lambda: {"f32": sa_line("f32"), "bf16": sa_line("bf16")})
             guarded("cfg5", "cfg5 (BASELINE configs[4]: 20000x20000 sliding-window predict) fp32 + bf16",
                     lambda: {"f32": cfg5_bench("f32", dev), "bf16": cfg5_bench("bf16", dev)})
+            guarded("fit_files", "fit_one_cycle from tile files through the product loader (uncompressed + LZW, fp32 + bf16)",
+                    lambda: fit_files_bench(dev, log, {"f32": round(value, 3), "bf16": (sec.get("bf16") or {}).get("value")}))
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 6
+#define UNET_ABI_VERSION 7
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -369,6 +369,23 @@ int unet_mosaic_accumulate_windows(const float* z, int z_cs, int z_co, int C, in
  * fill_host != NULL: pixels without a hit become *fill_host (regression nodata -9999, predict.py:312-315) */
 int unet_mosaic_finalize_rows(float* mosaic, const int32_t* count, int C, int MH, int MW, int row0, int nrows, uint8_t* argmax,
                               const float* fill_host, void* stream);
+
+/* ------------------------------------------------------- training feed --
+ * What learn.fit_one_cycle's loader does per batch on the host in the reference (train.py:345 -> data.py:18-28 open_npy: tile -> int32 ->
+ * float; utils.py:239-295 SegmentationAlbumentationsTransform: / 255 for int8 data, / 255 twice for int16 data, flips on the first
+ * ceil(B * n_transform_imgs) - B images; MaskBlock: int64 masks), done on the device on the INTEGERS of the tile files: the batch crosses
+ * PCIe as uint8 / uint16 samples (1 / 2 bytes instead of 4 + 8 per pixel).  src = n staged tiles [n, bands, H, W] (masks: [n, H, W]) of
+ * sample type rtype (UNET_RASTER_*), n <= 64 per call; image j is mirrored along x when bit j of hflip is set and along y for vflip.
+ * unet_tiles_stage: dst_nchw [n, bands, H, W] fp32 = float(int32(sample)) / 255 [/ 255], bit-equal to the host arithmetic.
+ * unet_mask_stage: dst [n, H, W] int64 (dst_f32 = 0, classification) or float (dst_f32 = 1, regression targets, data.py:98-99). */
+int unet_tiles_stage(const void* src, int rtype, int n, int bands, int H, int W, int div255_twice, unsigned long long hflip,
+                     unsigned long long vflip, float* dst_nchw, void* stream);
+int unet_mask_stage(const void* src, int rtype, int n, int H, int W, unsigned long long hflip, unsigned long long vflip, void* dst, int dst_f32,
+                    void* stream);
+/* DiceMulti counters of a validation batch (fastai metrics.py DiceMulti; reference train.py:196), ACCUMULATED into counts [3][C] (uint64,
+ * zeroed by the caller at the start of a validation pass): [0][c] += #(pred == c and targ == c), [1][c] += #(pred == c),
+ * [2][c] += #(clamp(targ, 0, C - 1) == c).  C <= 64. */
+int unet_dice_counts(const int64_t* pred, const int64_t* targ, long long P, int C, unsigned long long* counts, void* stream);
 
 /* ---------------------------------------------------- bf16-storage twins --
  * The HBM-bound kernels of the step with bf16 activation / gradient tensors (per-channel vectors, statistics, indices, losses stay

@@ -168,6 +168,9 @@ _sig = {
     "unet_tiff_lzw_decode": (ll, [vp, ll, vp, ll]),
     "unet_tiff_packbits_decode": (ll, [vp, ll, vp, ll]),
     "unet_mosaic_finalize_rows": (i, [vp, vp, i, i, i, i, i, vp, c_float_p, vp]),
+    "unet_tiles_stage": (i, [vp, i, i, i, i, i, i, C.c_ulonglong, C.c_ulonglong, vp, vp]),
+    "unet_mask_stage": (i, [vp, i, i, i, i, C.c_ulonglong, C.c_ulonglong, vp, i, vp]),
+    "unet_dice_counts": (i, [vp, vp, ll, i, vp, vp]),
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
@@ -188,7 +191,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 6:
+if lib.unet_abi_version() != 7:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 

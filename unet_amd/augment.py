@@ -118,6 +118,33 @@ class BatchAugment:
             xb[i], yb[i] = xi, yi
         return xb, yb
 
+    @property
+    def flips_only(self) -> bool:
+        return all(type(t) in (HorizontalFlip, VerticalFlip) for t in self.aug.transforms)
+
+    def __getattr__(self, name):
+        # `flip_flags` exists only for pipelines made of flips (the reference's default, params_and_main.py:105-115): the device feed
+        # (learner.DataLoader) then folds the flips into its staging kernels instead of running torch ops per image
+        if name == "flip_flags" and self.flips_only:
+            return self._flip_flags
+        raise AttributeError(name)
+
+    def _flip_flags(self, B: int) -> list:
+        """the random draws of ``__call__`` in its order, reduced to (mirror along the width, mirror along the height) per image"""
+        n_transform = math.ceil(B * self.n)
+        flags = [(False, False)] * B
+        for i in list(range(B))[:n_transform - B]:
+            h = v = False
+            if self.g.random() < self.aug.p:           # Compose.__call__: `if g.random() >= self.p: return`
+                for t in self.aug.transforms:          # _Transform.__call__: `if g.random() < self.p: apply`
+                    if self.g.random() < t.p:
+                        if type(t) is HorizontalFlip:
+                            h = not h
+                        else:
+                            v = not v
+            flags[i] = (h, v)
+        return flags
+
 
 def default_pipeline() -> Compose:
     """the reference's shipped ``aug_pipe`` (params_and_main.py:105-115)"""

@@ -65,7 +65,20 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    build_host_codecs(force)
     return LIB
+
+
+def build_host_codecs(force: bool = False) -> Path:
+    """libunet_tiff.so: the TIFF strip decoders (csrc/tiff_codecs.hip is plain C++) linked by g++ alone -- unet_amd/tiffio.py loads it without
+    the HIP runtime (tile preparation on a box without a GPU stack)."""
+    src, out = CSRC / "tiff_codecs.hip", LIBDIR / "libunet_tiff.so"
+    if force or _stale(out, [src, REPO / "include" / "unet_hip.h"]):
+        r = subprocess.run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "c++", str(src), "-I", str(REPO / "include"),
+                            "-o", str(out)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed for {src.name}:\n{r.stderr[-4000:]}")
+    return out
 
 
 if __name__ == "__main__":

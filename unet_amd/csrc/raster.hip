@@ -147,6 +147,67 @@ __global__ __launch_bounds__(256) void mosaic_fin_rows_kernel(float* __restrict_
     }
 }
 
+
+// ---- training feed (reference train.py:345 -> data.py:18-28 open_npy, utils.py:239-295 the batch transform, IntToFloatTensor) ----
+// A batch arrives as the INTEGERS of its tile files (pinned staging -> one asynchronous copy); value scaling, the int64 widening of the
+// mask and the default flip augmentation happen here.  Image j is mirrored along x when bit j of hflip is set, along y for vflip
+// (utils.py:239-291 applies the pipeline to the first ceil(B * n_transform_imgs) - B images: the host decides the bits).
+template <typename S>
+__global__ __launch_bounds__(256) void tiles_stage_kernel(const S* __restrict__ src, int n, int Cb, int H, int W, int div2,
+                                                          unsigned long long hflip, unsigned long long vflip, float* __restrict__ dst) {
+    const long long plane = (long long)H * W, per = plane * Cb, total = per * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / per);
+        const long long r = i - (long long)j * per;
+        const int c = (int)(r / plane);
+        const long long p = r - (long long)c * plane;
+        int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        if ((vflip >> j) & 1ull) y = H - 1 - y;
+        if ((hflip >> j) & 1ull) x = W - 1 - x;
+        float v = (float)as_i32(src[(size_t)j * per + (size_t)c * plane + (size_t)y * W + x]);
+        if (div2) v = __fdiv_rn(v, 255.0f);
+        dst[i] = __fdiv_rn(v, 255.0f);
+    }
+}
+
+template <typename S, typename D> __device__ __forceinline__ D mask_cast(S v) { return (D)v; }      // numpy astype: truncation toward zero
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void mask_stage_kernel(const S* __restrict__ src, int n, int H, int W, unsigned long long hflip,
+                                                         unsigned long long vflip, D* __restrict__ dst) {
+    const long long plane = (long long)H * W, total = plane * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / plane);
+        const long long p = i - (long long)j * plane;
+        int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        if ((vflip >> j) & 1ull) y = H - 1 - y;
+        if ((hflip >> j) & 1ull) x = W - 1 - x;
+        dst[i] = mask_cast<S, D>(src[(size_t)j * plane + (size_t)y * W + x]);
+    }
+}
+
+// DiceMulti counters (fastai metrics.py DiceMulti.accumulate; reference train.py:196): counts[0][c] += #(pred == c && targ == c),
+// counts[1][c] += #(pred == c), counts[2][c] += #(clamp(targ) == c).  Integer atomics (LDS histogram per workgroup, one global add per
+// class): the result does not depend on the order.
+__global__ __launch_bounds__(256) void dice_counts_kernel(const long long* __restrict__ pred, const long long* __restrict__ targ, long long P,
+                                                          int C, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int h[3 * MAXC];
+    for (int k = threadIdx.x; k < 3 * C; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = pred[i], t = targ[i];
+        const int tc = t < 0 ? 0 : (t >= C ? C - 1 : (int)t);
+        if (p >= 0 && p < C) {
+            atomicAdd(h + C + (int)p, 1u);
+            if (p == t) atomicAdd(h + (int)p, 1u);
+        }
+        atomicAdd(h + 2 * C + tc, 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * C; k += blockDim.x)
+        if (h[k]) atomicAdd(counts + k, (unsigned long long)h[k]);
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -221,6 +282,39 @@ extern "C" int unet_mosaic_finalize_rows(float* mosaic, const int32_t* count, in
     UNET_CHECK_ARG(mosaic && count && C > 0 && MH > 0 && MW > 0 && row0 >= 0 && nrows > 0 && row0 + nrows <= MH, "mosaic_finalize_rows: bad args");
     hipLaunchKernelGGL(mosaic_fin_rows_kernel, dim3(ew_grid((long long)nrows * MW, 256)), dim3(256), 0, ST, mosaic, count, C, MH, MW, row0, nrows,
                        argmax, fill_host ? 1 : 0, fill_host ? *fill_host : 0.f);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_tiles_stage(const void* src, int rtype, int n, int bands, int H, int W, int div255_twice, unsigned long long hflip,
+                                unsigned long long vflip, float* dst_nchw, void* stream) {
+    UNET_CHECK_ARG(src && dst_nchw && n > 0 && n <= 64 && bands > 0 && H > 0 && W > 0, "tiles_stage: bad args (1..64 images per call)");
+    const int grid = ew_grid((long long)n * bands * H * W, 256);
+    RASTER_DISPATCH(rtype, hipLaunchKernelGGL((tiles_stage_kernel<S>), dim3(grid), dim3(256), 0, ST, (const S*)src, n, bands, H, W, div255_twice,
+                                              hflip, vflip, dst_nchw));
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_mask_stage(const void* src, int rtype, int n, int H, int W, unsigned long long hflip, unsigned long long vflip, void* dst,
+                               int dst_f32, void* stream) {
+    UNET_CHECK_ARG(src && dst && n > 0 && n <= 64 && H > 0 && W > 0 && (dst_f32 == 0 || dst_f32 == 1), "mask_stage: bad args (1..64 masks per call)");
+    const int grid = ew_grid((long long)n * H * W, 256);
+    if (dst_f32) {
+        RASTER_DISPATCH(rtype, hipLaunchKernelGGL((mask_stage_kernel<S, float>), dim3(grid), dim3(256), 0, ST, (const S*)src, n, H, W, hflip, vflip,
+                                                  (float*)dst));
+    } else {
+        RASTER_DISPATCH(rtype, hipLaunchKernelGGL((mask_stage_kernel<S, long long>), dim3(grid), dim3(256), 0, ST, (const S*)src, n, H, W, hflip,
+                                                  vflip, (long long*)dst));
+    }
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+extern "C" int unet_dice_counts(const int64_t* pred, const int64_t* targ, long long P, int C, unsigned long long* counts, void* stream) {
+    UNET_CHECK_ARG(pred && targ && counts && P > 0 && C > 0 && C <= MAXC, "dice_counts: bad args");
+    // a workgroup's LDS counters are 32 bit: at most 2^31 pixels per workgroup
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(ew_grid(P, 256)), dim3(256), 0, ST, (const long long*)pred, (const long long*)targ, P, C, counts);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

@@ -9,16 +9,17 @@
 
 // TIFF 6.0 section 13: LZW with MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, "early change" (the code width grows one
 // code early).  Returns the number of bytes written to dst, or -1 on a malformed stream / overflow of cap.
+// Table entries do not store strings: the string of a new code is, by construction, the bytes just written for the previous code plus the
+// byte that follows them in the output -- so an entry is (offset into dst, length) and emitting a code is one forward copy out of the
+// output already produced (a forward byte copy also gives the KwKwK case, where the last byte of the string is its own first byte).
 extern "C" long long unet_tiff_lzw_decode(const unsigned char* src, long long n, unsigned char* dst, long long cap) {
     if (src == nullptr || dst == nullptr || n < 0 || cap < 0) return -1;
     enum { CLEAR = 256, EOI = 257, MAXC = 4096 };
-    static thread_local int32_t prefix[MAXC];
-    static thread_local uint8_t suffix[MAXC], first[MAXC];
-    static thread_local uint16_t length[MAXC];
-    for (int i = 0; i < 256; ++i) { prefix[i] = -1; suffix[i] = (uint8_t)i; first[i] = (uint8_t)i; length[i] = 1; }
-    long long bitpos = 0, out = 0;
+    long long off[MAXC];             // where in dst the string of a code >= 258 was written when the code was created
+    int len[MAXC];
+    long long bitpos = 0, out = 0, prev_off = 0;
     const long long nbits = n * 8;
-    int width = 9, next = 258, prev = -1;
+    int width = 9, next = 258, prev = -1, prev_len = 0;
     for (;;) {
         if (bitpos + width > nbits) break;          // a stream may end without EOI
         const long long byte = bitpos >> 3;
@@ -27,26 +28,30 @@ extern "C" long long unet_tiff_lzw_decode(const unsigned char* src, long long n,
         bitpos += width;
         if (code == EOI) break;
         if (code == CLEAR) { width = 9; next = 258; prev = -1; continue; }
-        int emit = code;
-        if (prev < 0) {
-            if (code >= 256) return -1;
-        } else if (code >= next) {
-            if (code != next) return -1;
-            emit = prev;                              // KwKwK: the string of prev followed by its own first byte
+        int cur_len;
+        if (code < 256) {
+            if (out + 1 > cap) return -1;
+            dst[out] = (unsigned char)code;
+            cur_len = 1;
+        } else {
+            if (prev < 0 || code > next || (code == next && next >= MAXC)) return -1;      // a code beyond the table
+            long long from;
+            if (code == next) { from = prev_off; cur_len = prev_len + 1; }      // KwKwK: the previous string followed by its own first byte
+            else { from = off[code]; cur_len = len[code]; }
+            if (out + cur_len > cap) return -1;
+            const unsigned char* q = dst + from;
+            unsigned char* p = dst + out;
+            if (from + cur_len <= out && cur_len >= 16) memcpy(p, q, (size_t)cur_len);
+            else for (int k = 0; k < cur_len; ++k) p[k] = q[k];                 // forward, byte by byte: source and destination may overlap
         }
-        const int len = length[emit] + ((prev >= 0 && code >= next) ? 1 : 0);
-        if (out + len > cap) return -1;
-        unsigned char* p = dst + out + length[emit];
-        for (int c = emit; c >= 0; c = prefix[c]) *--p = suffix[c];
-        if (prev >= 0 && code >= next) dst[out + len - 1] = first[prev];
-        if (prev >= 0 && next < MAXC) {
-            prefix[next] = prev;
-            suffix[next] = (code >= next) ? first[prev] : first[code];
-            first[next] = first[prev];
-            length[next] = (uint16_t)(length[prev] + 1);
+        if (prev >= 0 && next < MAXC) {            // new entry = previous string + first byte of this one = dst[prev_off, prev_off + prev_len]
+            off[next] = prev_off;
+            len[next] = prev_len + 1;
             ++next;
         }
-        out += len;
+        prev_off = out;
+        prev_len = cur_len;
+        out += cur_len;
         prev = code;
         if (next + 1 >= (1 << width) && width < 12) ++width;      // early change
     }

@@ -126,21 +126,20 @@ class Rmse:
 
     def accumulate_values(self, pred: torch.Tensor, targ: torch.Tensor):
         d = (pred.reshape(-1).double() - targ.reshape(-1).double())
-        self.se += float((d * d).sum().item())
+        self.se = self.se + (d * d).sum()          # stays a device scalar: no host sync per validation batch
         self.n += d.numel()
-        self._dev = pred.device
 
     # counters as a flat list of floats: Learner.validate packs every metric's counters and the loss sums into ONE all-reduce that every
     # rank takes part in, whether its validation shard held tiles or not (a shard is empty when len(valid) < world)
     def state(self, n_cls: int) -> list:
-        return [self.se, float(self.n)]
+        return [float(self.se), float(self.n)]
 
     def load_state(self, v: list):
         self.se, self.n = float(v[0]), int(round(v[1]))
 
     @property
     def value(self) -> float:
-        return float(np.sqrt(self.se / max(1, self.n)))
+        return float(np.sqrt(float(self.se) / max(1, self.n)))
 
 
 class R2Score:
@@ -153,25 +152,26 @@ class R2Score:
     def accumulate_values(self, pred: torch.Tensor, targ: torch.Tensor):
         p, t = pred.reshape(-1).double(), targ.reshape(-1).double()
         self.n += t.numel()
-        self.st += float(t.sum().item())
-        self.stt += float((t * t).sum().item())
-        self.res += float(((t - p) ** 2).sum().item())
-        self._dev = pred.device
+        self.st = self.st + t.sum()                # device scalars: no host sync per validation batch
+        self.stt = self.stt + (t * t).sum()
+        self.res = self.res + ((t - p) ** 2).sum()
 
     def state(self, n_cls: int) -> list:
-        return [float(self.n), self.st, self.stt, self.res]
+        return [float(self.n), float(self.st), float(self.stt), float(self.res)]
 
     def load_state(self, v: list):
         self.n, self.st, self.stt, self.res = int(round(v[0])), float(v[1]), float(v[2]), float(v[3])
 
     @property
     def value(self) -> float:
-        tot = self.stt - self.st * self.st / max(1, self.n)
-        return float("nan") if tot <= 0 else float(1.0 - self.res / tot)
+        st, stt, res = float(self.st), float(self.stt), float(self.res)
+        tot = stt - st * st / max(1, self.n)
+        return float("nan") if tot <= 0 else float(1.0 - res / tot)
 
 
 class DiceMulti:
-    """fastai ``DiceMulti(axis=1)``: inter/union per class accumulated over the validation set; nanmean of 2I/U."""
+    """fastai ``DiceMulti(axis=1)``: inter/union per class accumulated over the validation set; nanmean of 2I/U.  Device batches are counted
+    by ``unet_dice_counts`` (integer histogram kernel, no host sync per batch); host tensors by ``bincount``."""
     name = "dice_multi"
 
     def __init__(self, axis=1):
@@ -179,16 +179,35 @@ class DiceMulti:
         self.reset()
 
     def reset(self):
-        self.inter = None
-        self.union = None
+        self._inter = self._union = None        # host-side / loaded counters (float64)
+        self._counts = None                     # device counters int64 [3, C]: intersection, predicted, target
 
     def accumulate_argmax(self, pred: torch.Tensor, targ: torch.Tensor, n_cls: int):
+        if pred.is_cuda:
+            if self._counts is None:
+                self._counts = torch.zeros((3, n_cls), dtype=torch.int64, device=pred.device)
+            ops.dice_counts(pred.reshape(-1).long().contiguous(), targ.reshape(-1).long().contiguous(), n_cls, self._counts)
+            return
         p, t = pred.reshape(-1).long(), targ.reshape(-1).long()
         cp = torch.bincount(p, minlength=n_cls)[:n_cls]
         ct = torch.bincount(t.clamp(0, n_cls - 1), minlength=n_cls)[:n_cls]
         inter = torch.bincount(p[p == t], minlength=n_cls)[:n_cls]
-        self.inter = inter.double() if self.inter is None else self.inter + inter.double()
-        self.union = (cp + ct).double() if self.union is None else self.union + (cp + ct).double()
+        self._inter = inter.double() if self._inter is None else self._inter + inter.double()
+        self._union = (cp + ct).double() if self._union is None else self._union + (cp + ct).double()
+
+    @property
+    def inter(self):
+        if self._counts is None:
+            return self._inter
+        d = self._counts[0].double()
+        return d if self._inter is None else d + self._inter.to(d.device)
+
+    @property
+    def union(self):
+        if self._counts is None:
+            return self._union
+        d = (self._counts[1] + self._counts[2]).double()
+        return d if self._union is None else d + self._union.to(d.device)
 
     def state(self, n_cls: int) -> list:
         if self.inter is None:          # this rank saw no validation tile: it contributes zeros
@@ -197,7 +216,8 @@ class DiceMulti:
 
     def load_state(self, v: list):
         n = len(v) // 2
-        self.inter, self.union = torch.tensor(v[:n], dtype=torch.float64), torch.tensor(v[n:], dtype=torch.float64)
+        self._counts = None
+        self._inter, self._union = torch.tensor(v[:n], dtype=torch.float64), torch.tensor(v[n:], dtype=torch.float64)
 
     def all_reduce(self, device=None):
         """sum of the counters over the ranks; every rank must call it (a rank without tiles passes its class count through `reset`-time
@@ -206,7 +226,9 @@ class DiceMulti:
         if dist.is_initialized() and dist.get_world_size() > 1:
             if self.inter is None:
                 raise RuntimeError("DiceMulti.all_reduce on a rank without counters: use Learner.validate, which packs zeros for it")
-            dist.all_reduce(self.inter); dist.all_reduce(self.union)
+            i, u = self.inter.clone(), self.union.clone()
+            dist.all_reduce(i); dist.all_reduce(u)
+            self._counts, self._inter, self._union = None, i, u
 
     @property
     def value(self) -> float:
@@ -247,6 +269,19 @@ class TileDataset:
     def __len__(self):
         return len(self.imgs)
 
+    def raw(self, i) -> tuple:
+        """(image [C,H,W],) or (image, mask [H,W]) as the SAMPLES the files hold: what the device feed stages (unet_amd/feed.py); scaling
+        and the int64 widening of ``__getitem__`` happen on the device"""
+        im = self.imgs[i]
+        a = open_tile(im) if not isinstance(im, np.ndarray) else (im[None] if im.ndim == 2 else im)
+        if self.masks is None:
+            return (a,)
+        mk = self.masks[i]
+        y = np.asarray(open_tile(mk)[0] if not isinstance(mk, np.ndarray) else mk)
+        if self.regression and y.dtype.kind == "f" and y.dtype != np.float32:
+            y = y.astype(np.float32)
+        return a, y
+
     def __getitem__(self, i):
         im = self.imgs[i]
         x = scale_input(open_tile(im) if not isinstance(im, np.ndarray) else im, self.dtype)
@@ -260,14 +295,23 @@ class TileDataset:
 class DataLoader:
     """rank / world (tile-DDP, one process per GPU): every rank draws the SAME permutation (same seed) and keeps items
     rank, rank + world, ... of it.  A shuffled (training) loader truncates to a multiple of world so that all ranks run the
-    same number of steps (the gradient all-reduce is a lock-step collective); a validation loader keeps every item."""
+    same number of steps (the gradient all-reduce is a lock-step collective); a validation loader keeps every item.
+
+    feed: "device" (default on a GPU) = unet_amd/feed.py: a decode pool fills pinned INTEGER staging buffers ``depth`` batches ahead, the
+    batch is uploaded asynchronously (uint8 / uint16 samples and masks) and scaled / widened / flipped on the device; "host" = the
+    reference's order of work (train.py:345, data.py:18-28, utils.py:239-295): every item opened, scaled to fp32 and stacked on the calling
+    thread, then one blocking copy.  Both yield the same (xb fp32 [B,C,H,W], yb int64 [B,H,W]) bit for bit."""
 
     def __init__(self, ds: TileDataset, bs: int, shuffle: bool, device, drop_last: bool = False, seed: int = 0, batch_tfm=None,
-                 rank: int = 0, world: int = 1):
-        self.ds, self.bs, self.shuffle, self.device, self.drop_last = ds, bs, shuffle, device, drop_last
+                 rank: int = 0, world: int = 1, feed: str = "auto", workers: Optional[int] = None, depth: int = 3):
+        self.ds, self.bs, self.shuffle, self.device, self.drop_last = ds, bs, shuffle, torch.device(device), drop_last
         self._g = np.random.default_rng(seed)
         self.batch_tfm = batch_tfm
         self.rank, self.world = rank, world
+        if feed not in ("auto", "device", "host"):
+            raise ValueError(f"feed = {feed!r}: 'auto', 'device' or 'host'")
+        self.feed, self.workers, self.depth = feed, workers, depth
+        self._feeder = None
 
     def shard(self, rank: int, world: int):
         self.rank, self.world = rank, world
@@ -283,7 +327,7 @@ class DataLoader:
         n = self._n_local()
         return n // self.bs if self.drop_last else -(-n // self.bs)
 
-    def __iter__(self):
+    def _batches(self) -> list:
         idx = np.arange(len(self.ds))
         if self.shuffle:
             self._g.shuffle(idx)
@@ -291,23 +335,57 @@ class DataLoader:
             if self.shuffle:
                 idx = idx[:len(idx) // self.world * self.world]
             idx = idx[self.rank::self.world]
-        for b in range(len(self)):
-            items = [self.ds[int(i)] for i in idx[b * self.bs:(b + 1) * self.bs]]
+        return [idx[b * self.bs:(b + 1) * self.bs] for b in range(len(self))]
+
+    def __iter__(self):
+        batches = self._batches()
+        if self.feed == "device" or (self.feed == "auto" and self.device.type == "cuda"):
+            yield from self._iter_device(batches)
+            return
+        for items in batches:
+            items = [self.ds[int(i)] for i in items]
             xb = torch.stack([x for x, _ in items]).to(self.device)
             yb = None if items[0][1] is None else torch.stack([y for _, y in items]).to(self.device)
             if self.batch_tfm is not None and yb is not None:
                 xb, yb = self.batch_tfm(xb, yb)
             yield xb, yb
 
+    def _iter_device(self, batches):
+        from .feed import BatchFeeder
+        if self.device.type != "cuda":
+            raise RuntimeError("feed='device' stages batches for the HIP kernels: it needs a GPU loader (device='cuda')")
+        if self._feeder is None or self._feeder.load.__self__ is not self.ds:
+            self._feeder = BatchFeeder(self.ds.raw, self.bs, self.device, depth=self.depth, workers=self.workers)
+        has_y = self.ds.masks is not None
+        div2 = self.ds.dtype == "int16"
+        tfm = self.batch_tfm if has_y else None
+        with torch.cuda.device(self.device):
+            for slot in self._feeder.run(batches):
+                n = slot.n
+                flips = tfm.flip_flags(n) if hasattr(tfm, "flip_flags") else None       # flips run inside the staging kernels
+                src = slot.dev[0][:n]
+                xb = torch.empty(src.shape, dtype=torch.float32, device=self.device)
+                ops.tiles_stage(src, div2, xb, flips)
+                yb = None
+                if has_y:
+                    yb = torch.empty(slot.dev[1][:n].shape, dtype=torch.float32 if self.ds.regression else torch.int64, device=self.device)
+                    ops.mask_stage(slot.dev[1][:n], yb, flips)
+                slot.release()
+                if tfm is not None and flips is None:
+                    xb, yb = tfm(xb, yb)
+                yield xb, yb
+
 
 class DataLoaders:
     """``dls.train`` / ``dls.valid`` / ``dls.vocab`` / ``dls.device`` / ``dls.train_ds`` as the reference uses them."""
 
-    def __init__(self, train: TileDataset, valid: Optional[TileDataset], bs: int, device="cuda", vocab=None, seed=0, train_tfm=None):
+    def __init__(self, train: TileDataset, valid: Optional[TileDataset], bs: int, device="cuda", vocab=None, seed=0, train_tfm=None,
+                 feed: str = "auto", workers: Optional[int] = None):
         self.device = torch.device(device)
         self.train_ds, self.valid_ds, self.bs, self.vocab = train, valid, bs, vocab
-        self.train = DataLoader(train, bs, True, self.device, drop_last=len(train) >= bs, seed=seed, batch_tfm=train_tfm)
-        self.valid = None if valid is None else DataLoader(valid, bs, False, self.device)
+        self.train = DataLoader(train, bs, True, self.device, drop_last=len(train) >= bs, seed=seed, batch_tfm=train_tfm, feed=feed,
+                                workers=workers)
+        self.valid = None if valid is None else DataLoader(valid, bs, False, self.device, feed=feed, workers=workers)
 
     def test_dl(self, items, dtype=None):
         return DataLoader(TileDataset(items, None, dtype or self.train_ds.dtype), self.bs, False, self.device)
@@ -323,15 +401,23 @@ class FlipAugment:
         self.p_h, self.p_v, self.n, self.g = p_h, p_v, n_transform_imgs, np.random.default_rng(seed)
 
     def __call__(self, xb: torch.Tensor, yb: torch.Tensor):
-        B = xb.shape[0]
-        n_transform = math.ceil(B * self.n)
-        idx = list(range(B))[:n_transform - B]
-        for i in idx:
-            if self.g.random() < self.p_h:
+        for i, (h, v) in enumerate(self.flip_flags(xb.shape[0])):
+            if h:
                 xb[i] = xb[i].flip(-1); yb[i] = yb[i].flip(-1)
-            if self.g.random() < self.p_v:
+            if v:
                 xb[i] = xb[i].flip(-2); yb[i] = yb[i].flip(-2)
         return xb, yb
+
+    def flip_flags(self, B: int) -> list:
+        """(mirror along the width, mirror along the height) per image of a batch of B: the draws of ``__call__`` in its order.  The device
+        feed hands them to the staging kernels, which then write the flipped batch directly."""
+        n_transform = math.ceil(B * self.n)
+        flags = [(False, False)] * B
+        for i in list(range(B))[:n_transform - B]:
+            h = self.g.random() < self.p_h
+            v = self.g.random() < self.p_v
+            flags[i] = (bool(h), bool(v))
+        return flags
 
 
 # --------------------------------------------------------------------------- callbacks
@@ -623,9 +709,9 @@ class Learner:
         model.eval()
         for m in self.metrics:
             m.reset()
-        num = den = 0.0
         ctx = model.ctx
         w = self._weights()
+        acc = torch.zeros(2, dtype=torch.float64, device=model._device)      # loss numerator / denominator: summed on the device, read ONCE
         for xb, yb in dl:
             z = model._hip_forward(xb.to(model._device, torch.float32), False)
             if self.regression:
@@ -634,20 +720,21 @@ class Learner:
                 ops.regloss_fwd(z, yb, self.loss_func.kind, self.loss_func.beta, loss, ctx.workspace(ops.ce_workspace(z.P)))
                 vals = torch.empty((z.N, z.C, z.H, z.W), dtype=torch.float32, device=model._device)
                 ops.nhwc_to_nchw(z, vals)
-                num += float(loss.item()) * z.P
-                den += z.P
+                acc[0] += loss[0].double() * z.P
+                acc[1] += z.P
                 for m in self.metrics:
                     m.accumulate_values(vals[:, 0], yb)
                 continue
+            yb = yb.to(model._device, torch.int64).contiguous()
             loss, denom = ctx.vec(self, "vloss", 1), ctx.vec(self, "vden", 1)
-            ops.ce_fwd(z, yb.contiguous(), w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
+            ops.ce_fwd(z, yb, w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
             amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=model._device)
             ops.softmax_argmax(z, None, amax)
-            d = float(denom.item())
-            num += float(loss.item()) * d
-            den += d
+            acc[0] += loss[0].double() * denom[0].double()
+            acc[1] += denom[0].double()
             for m in self.metrics:
                 m.accumulate_argmax(amax, yb, z.C)
+        num, den = acc.cpu().tolist()          # the one host sync of the pass
         if self.world > 1:
             # ONE collective per validation pass, the same on every rank whether or not its shard held a tile: valid_loss = sum of the
             # ranks' numerators / sum of their denominators, followed by every metric's counters

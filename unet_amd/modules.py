@@ -383,11 +383,11 @@ class _ConvExec:
             with torch.cuda.stream(side):
                 self._bwd_w(ctx, x, dy, ctx.side_workspace)
         else:
-            ops.STREAM_OVERRIDE = side.cuda_stream
+            ops.set_stream_override(side.cuda_stream)
             try:
                 self._bwd_w(ctx, x, dy, ctx.side_workspace)
             finally:
-                ops.STREAM_OVERRIDE = None
+                ops.set_stream_override(None)
         done = torch.cuda.Event()
         done.record(side)
         ctx._side_dirty = True
@@ -396,7 +396,7 @@ class _ConvExec:
 
     def _bwd_w(self, ctx: Ctx, x: TS, dy: TS, workspace):
         w, b = self.conv.weight, self.conv.bias
-        key = (x.N, x.H, x.W, x.C, x.cs, dy.C, dy.cs, x.bf16, ops._tuning_ptr() is None)
+        key = (x.N, x.H, x.W, x.C, x.cs, dy.C, dy.cs, x.bf16, ops.wgrad_tuning_key())    # the plan (and its workspace) follows the switches' VALUES
         n = self._ws_sizes.get(key)                 # (a planning call per launch otherwise: the geometry decides)
         if n is None:
             n = self._ws_sizes[key] = ops.wgrad_workspace(x, dy, self.ks, self.stride, with_bias=b is not None)

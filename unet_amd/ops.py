@@ -77,6 +77,12 @@ def _tuning_ptr():
     return None if cur is None else C.pointer(cur)
 
 
+def wgrad_tuning_key():
+    """the values of the switches a weight-gradient plan depends on (None = the defaults): cache key of planned workspace sizes"""
+    cur = getattr(_TUNE, "cur", None)
+    return None if cur is None else (cur.wgrad_mfma_shape, cur.wgrad_bf16_k4, cur.wgrad_1x1, cur.wgrad_narrow, cur.plan_batch)
+
+
 # The launch stream of this thread as a raw hipStream_t.  torch.cuda.current_stream() builds a Stream object through several Python layers
 # (device-index parsing, is_available(), an os.environ lookup): 8 us of a ~16 us host budget per launch -- scripts/host_profile.py showed the
 # cfg1 step HOST-bound (issue time 6.95 ms = wall time), 29 % of it in that call.  The C entry points below are what it ends in.
@@ -84,14 +90,24 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
-# a raw stream that replaces the thread's current one for the launches issued while it is set (the side stream of the weight gradients:
-# entering torch.cuda.stream(...) costs four current_stream() round trips per weight gradient)
-STREAM_OVERRIDE: Optional[int] = None
+# a raw stream that replaces THIS THREAD's current one for the launches it issues while it is set (the side stream of the weight gradients:
+# entering torch.cuda.stream(...) costs four current_stream() round trips per weight gradient).  Thread-local like the tuning state: a launch
+# from another thread (a second model, a loader) never lands on somebody else's side stream.
+class _StreamOverride(threading.local):
+    raw: Optional[int] = None
+
+
+_OVERRIDE = _StreamOverride()
+
+
+def set_stream_override(raw: Optional[int]) -> None:
+    _OVERRIDE.raw = raw
 
 
 def _stream() -> int:
-    if STREAM_OVERRIDE is not None:
-        return STREAM_OVERRIDE
+    o = _OVERRIDE.raw
+    if o is not None:
+        return o
     if _raw_stream is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
@@ -732,6 +748,51 @@ def window_gather(src: WindowSource, table: torch.Tensor, first: int, n: int, th
     check(lib.unet_window_gather(src.data.data_ptr(), src.rtype, src.C, src.src_stride, src.H * src.W, src.W,
                                  table.data_ptr() + 16 * first, n, th, tw, src.div2, dst_buf.data_ptr(), dst_buf.shape[3], at, dt,
                                  _stream()), "window_gather")
+
+
+# ------------------------------------------------------------------ training feed (csrc/raster.hip: unet_tiles_stage / unet_mask_stage)
+
+def _flip_bits(flips, n: int, at: int):
+    """(hflip, vflip) bit masks of images [at, at + n) from a sequence of (h, v) pairs (None: nothing flipped)"""
+    h = v = 0
+    if flips is not None:
+        for j in range(n):
+            fh, fv = flips[at + j]
+            h |= int(bool(fh)) << j
+            v |= int(bool(fv)) << j
+    return h, v
+
+
+def tiles_stage(src: torch.Tensor, div255_twice: bool, out: torch.Tensor, flips=None):
+    """staged integer tiles [n, C, H, W] (device) -> fp32 NCHW batch `out`, scaled like learner.scale_input (bit-equal); flips[j] = (h, v)"""
+    assert src.is_cuda and src.is_contiguous() and src.dim() == 4 and src.dtype in RASTER_TYPES, (src.shape, src.dtype)
+    assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == tuple(src.shape)
+    n, Cb, H, W = src.shape
+    per = Cb * H * W
+    for at in range(0, n, 64):
+        m = min(64, n - at)
+        hb, vb = _flip_bits(flips, m, at)
+        check(lib.unet_tiles_stage(src.data_ptr() + at * per * src.element_size(), RASTER_TYPES[src.dtype], m, Cb, H, W, int(bool(div255_twice)),
+                                   hb, vb, out.data_ptr() + at * per * 4, _stream()), "tiles_stage")
+
+
+def mask_stage(src: torch.Tensor, out: torch.Tensor, flips=None):
+    """staged masks [n, H, W] (device, any raster sample type) -> `out` int64 (classification) or float32 (regression targets)"""
+    assert src.is_cuda and src.is_contiguous() and src.dim() == 3 and src.dtype in RASTER_TYPES, (src.shape, src.dtype)
+    assert out.is_cuda and out.is_contiguous() and out.dtype in (torch.int64, torch.float32) and tuple(out.shape) == tuple(src.shape)
+    n, H, W = src.shape
+    for at in range(0, n, 64):
+        m = min(64, n - at)
+        hb, vb = _flip_bits(flips, m, at)
+        check(lib.unet_mask_stage(src.data_ptr() + at * H * W * src.element_size(), RASTER_TYPES[src.dtype], m, H, W, hb, vb,
+                                  out.data_ptr() + at * H * W * out.element_size(), int(out.dtype == torch.float32), _stream()), "mask_stage")
+
+
+def dice_counts(pred: torch.Tensor, targ: torch.Tensor, n_cls: int, counts: torch.Tensor):
+    """counts int64 [3, n_cls] += (intersection, predicted, target) pixel counts per class of this batch (DiceMulti)"""
+    assert pred.dtype == torch.int64 and targ.dtype == torch.int64 and pred.is_contiguous() and targ.is_contiguous()
+    assert pred.numel() == targ.numel() and counts.dtype == torch.int64 and counts.numel() == 3 * n_cls and counts.is_contiguous()
+    check(lib.unet_dice_counts(pred.data_ptr(), targ.data_ptr(), pred.numel(), n_cls, counts.data_ptr(), _stream()), "dice_counts")
 
 
 def mosaic_accumulate_windows(z: TS, table: torch.Tensor, first: int, n: int, origin, mosaic: torch.Tensor, count: torch.Tensor,

@@ -65,25 +65,52 @@ def _parse_tags(b, path):
     return tags, bo
 
 
+_codec_lib = None
+
+
+def _codecs():
+    """the two byte-oriented TIFF decoders (csrc/tiff_codecs.hip: plain C++, no device code).  ``python -m unet_amd.build`` also links them
+    into a host-only ``libunet_tiff.so`` (g++), so a tile-preparation box without the HIP runtime reads the rasters GDAL writes by default;
+    libunet_hip.so exports the same two symbols."""
+    global _codec_lib
+    if _codec_lib is None:
+        import ctypes as C
+        host = Path(__file__).resolve().parent / "lib" / "libunet_tiff.so"
+        if host.exists():
+            lib = C.CDLL(str(host))
+        else:
+            from ._lib import lib
+        for fn in (lib.unet_tiff_lzw_decode, lib.unet_tiff_packbits_decode):
+            fn.restype, fn.argtypes = C.c_longlong, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+        _codec_lib = lib
+    return _codec_lib
+
+
 def _decoder(comp: int, path):
-    """bytes of one strip / tile -> decoded bytes (at most `cap`)"""
+    """(uint8 array view of one compressed strip / tile, capacity) -> decoded bytes (a uint8 array of at most `cap` bytes)"""
     if comp == 1:
         return lambda raw, cap: raw
     if comp in (8, 32946):
         import zlib
-        return lambda raw, cap: zlib.decompress(bytes(raw))
+
+        def inflate(raw, cap):
+            d = zlib.decompressobj()
+            out = d.decompress(raw, cap)                   # bounded: a crafted strip cannot expand beyond what the image needs
+            if d.unconsumed_tail and d.decompress(d.unconsumed_tail, 1):
+                raise ValueError(f"{path}: Deflate strip decodes to more than the {cap} bytes its rows hold")
+            return np.frombuffer(out, dtype=np.uint8)
+        return inflate
     if comp in (5, 32773):
-        import ctypes as C
-        from ._lib import lib          # the C decoders of libunet_hip.so (host code; no GPU involved)
+        lib = _codecs()
         fn = lib.unet_tiff_lzw_decode if comp == 5 else lib.unet_tiff_packbits_decode
 
         def dec(raw, cap):
-            src = bytes(raw)
-            dst = C.create_string_buffer(cap)
-            got = fn(src, len(src), dst, cap)
+            src = np.ascontiguousarray(raw)
+            dst = np.empty(cap, dtype=np.uint8)
+            got = fn(src.ctypes.data, src.size, dst.ctypes.data, cap)       # (ctypes releases the GIL: the feed's decode pool runs these in parallel)
             if got < 0:
                 raise ValueError(f"{path}: corrupt {'LZW' if comp == 5 else 'PackBits'} data")
-            return dst.raw[:got]
+            return dst[:got]
         return dec
     raise NotImplementedError(f"{path}: TIFF compression {comp} is not supported (none, LZW, Deflate and PackBits are)")
 
@@ -125,29 +152,52 @@ def tiff_info(path) -> Dict:
 
 def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     """Returns (array [C,H,W] (or [H,W] for one band), meta) with meta['geotransform'] = (ulx, xres, 0, uly, 0, -yres)
-    when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags."""
-    b = Path(path).read_bytes()
-    tags, bo = _parse_tags(b, path)
+    when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags.  The file is memory-mapped (copy-on-write), never slurped:
+    an uncompressed native-endian file with contiguous strips comes back as a VIEW of the mapping (no copy at all: the training feed's one
+    copy is the one into its pinned staging buffer); everything else is decoded strip by strip into one output array."""
+    import mmap
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)
+    b = np.frombuffer(mm, dtype=np.uint8)           # (keeps the mapping alive for as long as a view of it exists)
+    tags, bo = _parse_tags(mm, path)
     W, H = tags[256][0], tags[257][0]
     spp = tags.get(277, (1,))[0]
     bits = tags.get(258, (1,))[0]
     fmt = tags.get(339, (1,))[0]
     comp, predictor = tags.get(259, (1,))[0], tags.get(317, (1,))[0]
-    decode = _decoder(comp, path)
     planar = tags.get(284, (1,))[0]
     dt = _dtype(bits, fmt, bo)
+    native = dt.newbyteorder("=")
     planes = spp if planar == 2 else 1
     pix = 1 if planar == 2 else spp
-    out = np.zeros((planes, H, W, pix), dtype=dt.newbyteorder("="))
+    meta = _geo_meta(tags)
+    meta["dtype"] = native
+
+    def finish(out):          # out: [planes, H, W, pix]
+        arr = out[:, :, :, 0] if planar == 2 else np.moveaxis(out[0], -1, 0)
+        return (arr[0] if arr.shape[0] == 1 else arr), meta
+
+    if comp == 1 and predictor == 1 and 324 not in tags and dt.isnative:
+        offs = tags[273]
+        rps = min(tags.get(278, (H,))[0], H)
+        total = planes * H * W * pix * dt.itemsize
+        cnts = tags.get(279)
+        contiguous = len(offs) == 1 or (cnts is not None and all(offs[k] + cnts[k] == offs[k + 1] for k in range(len(offs) - 1))
+                                        and (planes == 1 or H % rps == 0))
+        if contiguous and offs[0] + total <= b.size:
+            return finish(b[offs[0]:offs[0] + total].view(dt).reshape(planes, H, W, pix))
+
+    decode = _decoder(comp, path)
+    out = np.zeros((planes, H, W, pix), dtype=native)
 
     def block(off, nbytes, rows, cols):
         """one strip / tile as [rows, cols, pix] in native byte order, decompressed and un-differenced"""
         need = rows * cols * pix * dt.itemsize
-        raw = decode(memoryview(b)[off:off + nbytes], need) if comp != 1 else memoryview(b)[off:off + need]
+        raw = decode(b[off:off + nbytes], need) if comp != 1 else b[off:off + need]
         if len(raw) < need:
             raise ValueError(f"{path}: strip / tile holds {len(raw)} bytes, {need} expected")
-        t = np.frombuffer(raw, dtype=dt, count=rows * cols * pix).reshape(rows, cols, pix)
-        return _unpredict(t.astype(dt.newbyteorder("=")), predictor, path)
+        t = raw[:need].view(dt).reshape(rows, cols, pix)
+        return _unpredict(t.astype(native, copy=False), predictor, path)
 
     if 324 in tags:        # tiled
         tw, th = tags[322][0], tags[323][0]
@@ -171,10 +221,7 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
                 r0 = s_ * rps
                 rows = min(rps, H - r0)
                 out[p, r0:r0 + rows] = block(offs[p * spi + s_], cnts[p * spi + s_], rows, W)
-    arr = out[:, :, :, 0] if planar == 2 else np.moveaxis(out[0], -1, 0)
-    meta = _geo_meta(tags)
-    meta["dtype"] = arr.dtype
-    return (arr[0] if arr.shape[0] == 1 else arr), meta
+    return finish(out)
 
 
 def write_tiff(path, arr: np.ndarray, geotransform=None, tags: Optional[Dict[int, tuple]] = None, nodata=None, bigtiff: Optional[bool] = None) -> None:
