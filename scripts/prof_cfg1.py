@@ -13,7 +13,7 @@ if which == "cfg1":
     x = (torch.randint(0, 256, (2, 3, 256, 256), generator=g).float() / 255).cuda(); y = torch.randint(0, 2, (2, 256, 256), generator=g).cuda()
     for _ in range(20): st(x, y)
 else:
-    m = HipDynamicUnet("xresnet34", 4, 5, (512, 512)); m.eval()
+    m = HipDynamicUnet("xresnet34", 4, 5, (512, 512), act_dtype=os.environ.get("UNET_DTYPE", "f32")); m.eval()
     x = torch.rand(1, 4, 512, 512, device="cuda")
     for _ in range(20): m.predict_probs(x)
 torch.cuda.synchronize()

@@ -120,22 +120,16 @@ def _check_grads(rows, tail_from, tail_bar, what):
     _check_grads_draws([rows], tail_from, tail_bar, what)
 
 
-def _comfortable(rows, tail_from, tail_bar, what, margin=0.7):
-    """is this draw inside every bar with room to spare (<= margin x the bar)?  Then further draws add nothing: they are only taken when a
-    draw comes within 30 % of a bar, which keeps the GPU suite short on the ordinary day and the bars robust on the unlucky one"""
-    t, e, c = _grad_stats(rows, tail_from, tail_bar, f"{what} (first draw)")
-    return t[1] <= margin * tail_bar and e[3] <= margin and c[1] <= margin * ENC_CAP
-
-
 def _check_grads_draws(draws, tail_from, tail_bar, what):
     """Flip noise is a property of the DRAW (which pre-activations happen to sit within rounding distance of zero), not of the kernels: a
     kernel that gets CLOSER to fp64 moves which ones flip and can land on the wrong side of a single-draw bar (round 3: a +0.9 % change
     was taken back for 2.001e-3 against 2e-3).  With several draws (different tiles through the same network) the bars are asserted on
-    the MEDIAN draw, and no single draw may be beyond twice the bar."""
+    the MEDIAN of three fixed draws -- always all three -- and no single draw may be beyond 1.25 x the bar (a real regression moves every
+    draw; measured on MI355X, cfg2: worst excess 0.65 / 0.46 / 0.24 of the bar over the three draws)."""
     st = [_grad_stats(rows, tail_from, tail_bar, f"{what} draw {i}") for i, rows in enumerate(draws)]
     med = lambda v: sorted(v)[len(v) // 2]
     tails, exs, caps = [s_[0][1] for s_ in st], [s_[1][3] for s_ in st], [s_[2][1] for s_ in st]
-    lim = 1.0 if len(draws) == 1 else 2.0
+    lim = 1.0 if len(draws) == 1 else 1.25
     assert med(tails) <= tail_bar and max(tails) <= lim * tail_bar, (what, "decoder tail", [s_[0] for s_ in st])
     assert med(exs) <= 1.0 and max(exs) <= lim, (what, "excess over max(tail_bar, ENC_FACTOR x e_cpu32)", [s_[1] for s_ in st])
     assert med(caps) <= ENC_CAP and max(caps) <= lim * ENC_CAP, (what, "absolute cap", [s_[2] for s_ in st])
@@ -154,7 +148,7 @@ def test_cfg2_training_step_every_gradient_against_the_oracle():
     w = torch.tensor([0.1, 0.3, 0.2, 0.25, 0.15])
     ref.train(); ref64.train(); model.train()
     draws = []
-    for seed in (1234, 2024, 77):           # up to three draws of tiles through the same network: the flip-noise bars are set on the median draw
+    for seed in (1234, 2024, 77):           # three draws of tiles through the same network, always all of them: the flip-noise bars are set on the median draw
         x, y = O.synthetic_batch(2, 4, 512, 512, 5, seed=seed)
         for m_ in (ref, ref64):
             m_.zero_grad()
@@ -175,8 +169,6 @@ def test_cfg2_training_step_every_gradient_against_the_oracle():
         rows = _grad_table(model, ref, ref64)
         assert len(rows) == len(list(ref.parameters())) > 150
         draws.append(rows)
-        if len(draws) == 1 and _comfortable(rows, 7, 1e-3, "cfg2 B=2"):
-            break
     _check_grads_draws(draws, tail_from=7, tail_bar=1e-3, what="cfg2 B=2")
     rows = draws[0]
     # the layers served by the narrow weight-gradient kernels, by name: final ResBlock 100->100 pair, last UnetBlock 192->96 / 96->96
@@ -292,7 +284,7 @@ def test_cfg1_xresnet18_rgb_256_batch2_training_step():
     w = torch.tensor([0.5, 0.5])
     ref.train(); ref64.train(); model.train()
     draws = []
-    for seed in (1234, 77, 4242):           # up to three draws of tiles through the same network: the flip-noise bars are set on the median draw
+    for seed in (1234, 77, 4242):           # three draws of tiles through the same network, always all of them: the flip-noise bars are set on the median draw
         x, y = O.synthetic_batch(2, 3, 256, 256, 2, seed=seed)
         for m_ in (ref, ref64):
             m_.zero_grad()
@@ -306,8 +298,6 @@ def test_cfg1_xresnet18_rgb_256_batch2_training_step():
         assert (z.double() - z64.detach()).abs().max().item() < 1e-3 * max(1.0, z64.abs().max().item() / 8)
         assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item())
         draws.append(_grad_table(model, ref, ref64))
-        if len(draws) == 1 and _comfortable(draws[0], 7, 2e-3, "cfg1 B=2"):
-            break
     _check_grads_draws(draws, tail_from=7, tail_bar=2e-3, what="cfg1 B=2")
     x, y = O.synthetic_batch(2, 3, 256, 256, 2)
     ref.eval(); ref64.eval(); model.eval()

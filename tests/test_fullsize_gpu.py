@@ -57,8 +57,12 @@ def test_one_full_tile_against_the_oracle(pair, batch):
     diff = am != am_ref
     top2 = z_ref[0].topk(2, dim=0).values
     gap = (top2[0] - top2[1])
-    assert int(diff.sum()) <= 8, f"{int(diff.sum())} mask pixels differ"
-    assert bool((gap[diff] <= 2 * err).all()), "a mask pixel differs where the oracle's decision is not a tie"
+    # north_star: masks bit-exact -- ONE bar across the suite (tests/test_configs_gpu.py): 0 differing pixels on this fixture.  Should one
+    # ever differ, the margin of the oracle's own decision there is printed before the test fails (a tie below the fp32 evaluation error
+    # is undecidable in fp32; anything larger is a wrong decision)
+    if diff.any():
+        print(f"{int(diff.sum())} mask pixel(s) differ; oracle top-2 margins there {gap[diff].min():.2e} .. {gap[diff].max():.2e}, logit err {err:.2e}")
+    assert int(diff.sum()) == 0, f"{int(diff.sum())} mask pixels differ (margins up to {gap[diff].max():.2e}, logit err {err:.2e})"
     assert (probs.cpu() - torch.softmax(z_ref, 1)).abs().max().item() < 1e-3
 
 
@@ -79,7 +83,15 @@ def test_batch_of_16_equals_tiles_alone(pair, batch):
             _, mi = model.predict_probs(x[i:i + 1])
             diff = mi[0] != mb[i]
             top2 = zb[i].topk(2, dim=0).values
-            assert int(diff.sum()) <= 4 and bool(((top2[0] - top2[1])[diff] <= 2 * err).all())
+            # (this is NOT the oracle bar -- that one is 0 differing pixels, asserted above and in tests/test_configs_gpu.py -- but a statement about
+            #  two HIP evaluation ORDERS of the same tile: by pigeonhole they cannot both equal the oracle where they differ from each other.
+            #  They may differ only at exact numerical ties -- top-2 margin below the measured logit difference of the two orders -- and
+            #  `batch_invariant=True` (next test) removes even those)
+            if diff.any():
+                print(f"tile {i}: {int(diff.sum())} mask pixel(s) differ between the batch and the tile alone; top-2 margins there "
+                      f"{(top2[0] - top2[1])[diff].max():.2e}, logit difference {err:.2e}")
+            assert bool(((top2[0] - top2[1])[diff] <= err).all()), (i, int(diff.sum()))
+            assert int(diff.sum()) <= 2, (i, int(diff.sum()))
 
 
 def test_batch_invariant_plans_make_a_batch_equal_its_tiles_alone_bit_for_bit(pair, batch):

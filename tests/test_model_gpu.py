@@ -591,7 +591,7 @@ def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs)
     ref.train(); model.train(); ref64.train()
     # Three draws of tiles through the same network.  Which pre-activations sit within rounding distance of zero is a property of the draw,
     # so a kernel that is CLOSER to fp64 can still move one of them to the other side (round 3: 2.001e-3 against the 2e-3 bar after a change
-    # that halved the median distance to fp64).  The bar is therefore asserted on the median draw; no draw may be beyond twice the bar.
+    # that halved the median distance to fp64).  The bar is therefore asserted on the median of three fixed draws (all three always run); no draw may be beyond 1.25 x the bar.
     worsts = []
     for seed in (1234, 99, 31337):
         x, y = O.synthetic_batch(bs, n_in, size[0], size[1], n_out, seed=seed)
@@ -624,10 +624,8 @@ def test_train_step_gradients_with_mixed_relu_masks(arch, n_in, n_out, size, bs)
         print("mixed-mask draw", seed, "worst", worst, "live tensors", n_live)
         assert n_live > 0.5 * len(list(ref.parameters()))
         worsts.append(worst)
-        if len(worsts) == 1 and worst[1] <= 0.7 * 2e-3:
-            break           # comfortably inside: further draws are only taken when the first one comes within 30 % of the bar
-    es = sorted(w_[1] for w_ in worsts)
-    assert es[len(es) // 2] < 2e-3 and es[-1] < 4e-3, worsts
+    es = sorted(w_[1] for w_ in worsts)         # always all three draws; the median inside the bar, no draw beyond 1.25 x the bar
+    assert es[len(es) // 2] < 2e-3 and es[-1] < 2.5e-3, worsts
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

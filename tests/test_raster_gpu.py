@@ -159,8 +159,9 @@ def test_predict_raster_equals_tile_files_flow_and_oracle(tmp_path):
     assert err < 1e-4, err                                         # probabilities of O(1) logits: fp32 rounding of two implementations
     diff = acc.argmax(0) != out
     top2 = np.sort(acc, axis=0)[-2:]
-    assert not diff.any() or (top2[1] - top2[0])[diff].max() <= 4 * err, "a mask pixel differs where the oracle is decided"
-    assert int(diff.sum()) <= 8
+    if diff.any():
+        print(f"{int(diff.sum())} mask pixel(s) differ; oracle top-2 margins there up to {(top2[1] - top2[0])[diff].max():.2e}, probability err {err:.2e}")
+    assert int(diff.sum()) == 0, int(diff.sum())          # ONE mask bar across the suite: bit-exact (tests/test_configs_gpu.py)
     assert (out[cnt == 0] == 0).all()                              # nothing placed: class 0, as np.argmax of zeros
 
 

@@ -368,8 +368,8 @@ __device__ unsigned long long* g_stamps = nullptr;
 // T = unsigned short (bf16 storage: a chunk is 32 channels, one v_mfma_f32_16x16x32_bf16 per tile pair and stage) or float (the fp32 parity
 // path, same bytes everywhere: a chunk is 16 channels = 64 bytes per pixel, the filter tile 16 columns x 64 B, four v_mfma_f32_16x16x4_f32 per
 // tile pair and stage with the operand roles of the bf16 form -- A = filter, B = pixels -- so that a lane again holds four consecutive
-// channels of one pixel and results move as 16-byte vectors; no reduction tail, no 4-channel sliver: the planner keeps those launches on
-// conv_igemm16_kernel).
+// channels of one pixel and results move as 16-byte vectors; a reduction tail (Cin % 16) runs as a channel-transposed last chunk, an output
+// width of 16 n + 1..4 as the 4-channel sliver below).
 // SLV (fp32 storage, odd NTOT): the last channel tile of the block holds only 1..4 real channels (the 100-wide final ResBlock: 6 x 16 + 4).
 // It takes the place of the shared odd tile -- same filter loads (lane column l15 & 3 of that tile), same half of the pixel tiles per wave --
 // but multiplies with v_mfma_f32_4x4x1_16B_f32: A = filter (lane 4 b + i: output channel i, reduction channel of the lane's k-slot), B = the
