@@ -850,10 +850,11 @@ def test_row_softmax_and_strided_pack(ops):
     assert_close(from_ts(out), ref, rtol=2e-4, what="strided pack conv, sliver width")
 
 
-@pytest.mark.parametrize("narrow", [1, 0])
+@pytest.mark.parametrize("narrow", [1, 2, 0])
 def test_wgrad_narrow_kernel(ops, narrow):
-    """narrow-output weight gradient (80 < Cout <= 112, 3x3 s1, W >= 32; default on) and its 64x64-tiled fallback on the same
-    cases against torch, incl. bias gradient, ragged tiles and input-channel chunking"""
+    """narrow-output weight gradient (80 < Cout <= 112, 3x3 s1, W >= 32; default on: 97..100 output channels with the last 1..4 on the
+    v_mfma_f32_4x4x1 sliver), the same with seven full 16-row tiles (2) and its 64x64-tiled fallback (0) on the same cases against torch,
+    incl. bias gradient, ragged tiles and input-channel chunking"""
     from unet_amd._lib import lib
     _knobs.set_knob("wgrad_narrow", narrow)
     try:
@@ -864,7 +865,7 @@ def test_wgrad_narrow_kernel(ops, narrow):
 
 def _narrow_cases(ops):
     for case in [(2, 40, 48, 100, 100), (1, 34, 64, 192, 96), (2, 32, 32, 96, 96), (1, 37, 45, 36, 100), (1, 32, 40, 250, 81),
-                 (3, 5, 33, 100, 100)]:
+                 (3, 5, 33, 100, 100), (1, 33, 40, 40, 98), (2, 32, 32, 100, 97), (1, 32, 64, 57, 104)]:
         N, H, W, Cin, Cout = case
         g = torch.Generator().manual_seed(sum(case))
         x = torch.randn(N, Cin, H, W, generator=g)

@@ -377,7 +377,13 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const WArgs a) {
 // two pixel rows of a 32-lane ds_read_b32 group hit disjoint banks.
 //   v_mfma_f32_16x16x4_f32: A[i=l&15][kk=l>>4] = dy[pixel 4*step+kk][16*mt + i]
 //                           B[kk=l>>4][j=l&15] = x[pixel 4*step+kk shifted by tap(n)][c(n)],  n = 16*tile + j
-template <int KT, int NTW>
+// SLV (round 5; Cout = 16 KT + 1..4: the 100 -> 100 pair, 36.9 % of the step's FLOPs): the last 1..4 output channels no longer pay a
+// whole 16-row tile per column tile (100 -> 112 rows: 10.7 % of the issued MFMAs multiplied zeros).  They run as a 4-ROW SLIVER on
+// v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4 x 4, one k each, 8 clocks instead of 32): block b = lane / 4 = 4 kk + cg is (pixel class kk,
+// column group cg), so the B operand IS the register the 16x16x4 tiles of that column tile use (lane 16 kk + 4 cg + j = pixel kk, column
+// 4 cg + j), and A is dy[pixel 4*step + kk][16 KT + (lane & 3)].  D: lane l, VGPR r = row 16 KT + r, column l & 15, summed over the pixels
+// of class kk = l >> 4; the four classes meet in the epilogue, (kk0 + kk1) + (kk2 + kk3), two lane exchanges.
+template <int KT, int NTW, bool SLV = false>
 __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
     constexpr int PT = 32, HW = 34, HPIX = 3 * HW, LD = 112, Q = LD / 4;
     constexpr int DIT = (PT * Q + 255) / 256, XIT = (HPIX * Q + 255) / 256;
@@ -418,17 +424,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         brow[q] = r;
     }
     const int abase = kk * LD + l15;
+    const int sbase = kk * LD + 16 * KT + (l15 & 3);          // sliver: row (l & 3) of the last 4 output channels, pixel class kk
 
     f32x4 acc[KT][NTW];
+    f32x4 sacc[SLV ? NTW : 1];
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int q = 0; q < NTW; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < (SLV ? NTW : 1); ++q) sacc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // Staging (global -> registers -> LDS); pixels outside the image are zero, channels beyond the chunk are never read
     // back.  tile = (img * tiles_x + tx) * OH + oy.  The 35-accumulator form has 32 registers to spare: it fetches the next
     // tile's dy rows and its one new input row BEFORE the MFMA loop of the current tile and stores them after it.
-    constexpr bool PF = (KT * NTW <= 36);
+    constexpr bool PF = (KT * NTW + (SLV ? NTW : 0) <= 36);
     constexpr int RIT = (HW * Q + 255) / 256;     // float4 items per thread per input row
     const int cw4 = (CW + 3) & ~3;
     struct TilePos { int oy, ox0; const float* dyb; const float* xb; };
@@ -584,16 +594,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
         // (a full unroll hoists all 96 operand loads and spills; the 42-accumulator form only has room for one step's operands)
         auto mma_step = [&](int step) {
             float av[KT], bv[NTW];
+            float as_ = 0.f;
 #pragma unroll
             for (int m = 0; m < KT; ++m) av[m] = dyT[abase + step * 4 * LD + m * 16];
+            if constexpr (SLV) as_ = dyT[sbase + step * 4 * LD];
 #pragma unroll
             for (int q = 0; q < NTW; ++q) bv[q] = xh[bq[q] + step * 4 * LD];
 #pragma unroll
             for (int m = 0; m < KT; ++m)
 #pragma unroll
                 for (int q = 0; q < NTW; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+            if constexpr (SLV) {
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) sacc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(as_, bv[q], sacc[q], 0, 0, 0);
+            }
         };
-        if constexpr (KT * NTW > 36) {
+        if constexpr (!PF) {
 #pragma unroll 1
             for (int step = 0; step < PT / 4; ++step) mma_step(step);
         } else {
@@ -636,6 +652,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(const WArgs a) {
                 const int k = 16 * m + 4 * kk + r;
                 if (k < a.Cout) pt[(size_t)k * a.Cin] = acc[m][q][r];
             }
+    }
+    if constexpr (SLV) {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            f32x4 v = sacc[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {          // the four pixel classes of a column: (kk0 + kk1) + (kk2 + kk3), the same order in every lane
+                v[r] += __shfl_xor(v[r], 16);
+                v[r] += __shfl_xor(v[r], 32);
+            }
+            const int n = ((nb * 4 + wave) * NTW + q) * 16 + l15;
+            if (n >= NTOT || kk != 0) continue;
+            const int t = n / CW, c = n - t * CW;
+            float* pt = pb + (size_t)t * KC_ + c0 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * KT + r < a.Cout) pt[(size_t)(16 * KT + r) * a.Cin] = v[r];
+        }
     }
 }
 
@@ -1557,9 +1591,12 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
         static unsigned long long configured = 0;   // one bit per device
         if (unet::first_use_on_device(&configured)) {
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<6, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             UNET_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<6, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
-        if (d->Cout > 96) hipLaunchKernelGGL((wgrad_flat_kernel<7, 5>), grid, dim3(256), lds, st, p.k);
+        // 97..100 output channels (the 100 -> 100 pair): six 16-row tiles + a 4-row sliver; unet_tuning.wgrad_narrow = 2 keeps the seven-tile form (A/B)
+        if (d->Cout > 96 && d->Cout <= 100 && p.tune.wgrad_narrow != 2) hipLaunchKernelGGL((wgrad_flat_kernel<6, 5, true>), grid, dim3(256), lds, st, p.k);
+        else if (d->Cout > 96) hipLaunchKernelGGL((wgrad_flat_kernel<7, 5>), grid, dim3(256), lds, st, p.k);
         else hipLaunchKernelGGL((wgrad_flat_kernel<6, 7>), grid, dim3(256), lds, st, p.k);
         UNET_CHECK_LAUNCH();
         rc = UNET_OK;
