@@ -76,6 +76,9 @@ typedef struct {
                                if the batch were n images, whatever N is -- with 1, every image of a batch runs exactly the kernels, tiles and split
                                chains it would run alone: predictions become bit-identical ACROSS batch sizes (the reference predicts tile by
                                tile, predict.py:191-193), at the price of batch-1 plans on full grids (predict.predict_raster(batch_invariant=True)) */
+    int wgrad_wgs;          /* workgroups a weight-gradient launch is split into (split-K over pixel tiles).  0 (default): ~512 (two per CU); bf16
+                               storage, 3x3 layers up to ~175 GFLOP: ~256 (one per CU: half the partial filter images to write and read back,
+                               measured faster).  n > 0: ~n workgroups (A/B) */
 } unet_tuning;
 void unet_tuning_default(unet_tuning* t);
 

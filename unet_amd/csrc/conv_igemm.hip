@@ -737,6 +737,7 @@ const unet_tuning& tuning_defaults() {
         v.wgrad_1x1 = 1;
         v.wgrad_narrow = 1;
         v.plan_batch = 0;
+        v.wgrad_wgs = env_int("UNET_WGRAD_WGS", 0);
         return v;
     }();
     return t;

@@ -1430,8 +1430,18 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         k.tiles_y = k.tiles_x = 1;
         cols = k.kt * k.ct;
     }
-    // aim for ~512 workgroups (256 CUs x 2 resident); at least 4 tiles per block
-    int want = 512 / cols;
+    // aim for ~512 workgroups (256 CUs x 2 resident); at least 4 tiles per block.
+    // bf16 storage (round 5): a workgroup's pixel tiles cost 8 x fewer MFMA clocks than in fp32, but its partial filter image -- T x 64 x 64
+    // floats, written once and read once by the reduce kernel -- costs the same: at 512 workgroups the 19 GFLOP encoder layers spend ~4 us
+    // multiplying and ~40 us moving 2 x 75 MB of partials (profiles/r05_a_layer_bench_bf16.txt: 64 -> 64 at 16 x 128^2 73 us, MFMA roof 8).
+    // One workgroup per CU halves the partials and doubles the reduction length of each.  Measured alone on the chip
+    // (scripts/ab_wgrad_wgs.py, profiles/r05_b_wgrad_wgs.txt), 256 against 512 workgroups: 64 -> 64 at 128^2 54.6 / 73.3 us, 128 -> 128 at 64^2
+    // 42.1 / 49.9, 512 -> 512 at 16^2 56.7 / 66.3, 384 -> 384 at 64^2 188.8 / 238.3; from 256 -> 256 at 128^2 (309 GFLOP) up the longer
+    // reductions win with two workgroups per CU (277.7 / 325.4), and so do the 1x1 launches (one tap: a ninth of the partial bytes).
+    int target = 512;
+    if (p->tune.wgrad_wgs > 0) target = p->tune.wgrad_wgs;
+    else if (p->bf16 && d->ks == 3 && d->stride == 1 && (long long)k.total_tiles * cols <= 20000) target = 256;
+    int want = target / cols;
     if ((p->narrow || p->bf16) && want >= 8) want &= ~7;      // the XCD-aware mapping pads the split count to a multiple of 8: stay within 512
     if (want < 1) want = 1;
     int tpb = unet::cdiv(k.total_tiles, want);

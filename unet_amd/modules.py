@@ -86,7 +86,7 @@ class Ctx:
         self._side_dirty = False            # side-stream work launched since the last join
         self._side_tag: Dict[int, torch.cuda.Event] = {}     # pool buffer -> event behind its last side-stream reader
         self._side_pending = collections.deque()             # freed buffers withheld from the pool until that reader is done
-        self.side_depth = 3                 # how many such buffers may be withheld (= how far the main stream may run ahead)
+        self.side_depth = int(os.environ.get("UNET_SIDE_DEPTH", "3"))     # how many such buffers may be withheld (= how far the main stream may run ahead)
 
     # activations are keyed by (owner id, tag, shape): allocated once per input geometry
     def act(self, owner, tag, N, H, W, C, zero=False, dtype=None) -> TS:

@@ -80,7 +80,7 @@ def _tuning_ptr():
 def wgrad_tuning_key():
     """the values of the switches a weight-gradient plan depends on (None = the defaults): cache key of planned workspace sizes"""
     cur = getattr(_TUNE, "cur", None)
-    return None if cur is None else (cur.wgrad_mfma_shape, cur.wgrad_bf16_k4, cur.wgrad_1x1, cur.wgrad_narrow, cur.plan_batch)
+    return None if cur is None else (cur.wgrad_mfma_shape, cur.wgrad_bf16_k4, cur.wgrad_1x1, cur.wgrad_narrow, cur.plan_batch, cur.wgrad_wgs)
 
 
 # The launch stream of this thread as a raw hipStream_t.  torch.cuda.current_stream() builds a Stream object through several Python layers
