@@ -71,7 +71,8 @@ typedef struct {
     int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
     int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */
     int wgrad_narrow;       /* 1: the narrow-output (80 < Cout <= 112) flattened-tap fp32 weight-gradient kernel (default); 2: the same without the
-                               4-row v_mfma_f32_4x4x1 sliver for 97..100 output channels (seven 16-row tiles: A/B, cross-check) */
+                               4-row v_mfma_f32_4x4x1 sliver for 97..100 output channels (seven 16-row tiles: A/B, cross-check); 3: as 1, and the
+                               general fp32 kernel without the pixel sub-splits of layers with <= 32 input / output channels (A/B) */
     int plan_batch;         /* 0 (default): the conv planner sizes tiles / split reductions for the batch of the descriptor.  n > 0: it plans as
                                if the batch were n images, whatever N is -- with 1, every image of a batch runs exactly the kernels, tiles and split
                                chains it would run alone: predictions become bit-identical ACROSS batch sizes (the reference predicts tile by

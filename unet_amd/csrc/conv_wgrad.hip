@@ -45,6 +45,8 @@ struct WArgs {
     int kt, ct;  // number of k / c block tiles
     int cw, nnb; // narrow-output kernel: input-channel chunk width, column blocks per chunk
     int xcd_map; // bf16 kernel: grid.y is a multiple of 8 and the channel blocks of ONE pixel split are dealt to ONE XCD
+    int csub, ksub;   // wgrad_kernel (fp32): Cin <= 32 / Cout <= 32 -- the waves whose channel half would be empty take the other HALF OF THE PIXELS
+                      // of every tile instead and write a partial image of their own (the reduce kernel sums splits x sub-splits slices)
 };
 
 template <int PTW, int S, int KS>
@@ -62,7 +64,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     float* xh = smem + PT * BK;        // [HPIX][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave >> 1, wc = wave & 1;
+    // wave = (output-channel half, input-channel half) of the 64 x 64 block.  Narrow layers (the stem: 32 -> 32 pads BOTH to 64, a quarter of
+    // the MFMAs useful: 29 TFLOP/s at 16 x 256^2, profiles/r05_a_layer_bench_f32.txt): a half that holds no channels becomes a half of the
+    // PIXELS instead (a.csub / a.ksub) -- the wave multiplies the step groups of its pixel sub-split for channel half 0 and writes a partial
+    // image of its own.
+    const int wk_raw = __builtin_amdgcn_readfirstlane(wave >> 1), wc_raw = __builtin_amdgcn_readfirstlane(wave & 1);
+    const int wk = a.ksub ? 0 : wk_raw, wc = a.csub ? 0 : wc_raw;
+    const int nsub = (a.ksub ? 2 : 1) * (a.csub ? 2 : 1);
+    const int sub = (a.ksub ? wk_raw : 0) * (a.csub ? 2 : 1) + (a.csub ? wc_raw : 0);
     const int l31 = lane & 31, h = lane >> 5;
     const int kblk = blockIdx.x / a.ct, cblk = blockIdx.x % a.ct;
     const int k0 = kblk * BK, c0 = cblk * BC;
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
         static_for<NG>([&](auto g) {
             constexpr int G = decltype(g)::value;
             if (has_next) static_for<IPG>([&](auto kk) { load_item(nx, std::integral_constant<int, G * IPG + decltype(kk)::value>{}); });
+            if (nsub == 1 || G * nsub / NG == sub) {          // (wave-uniform: the step groups of this wave's pixel sub-split)
 #pragma unroll
             for (int sg = 0; sg < GS; ++sg) {
                 const int step = G * GS + sg;
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
                         const float bv = bbase[((py * S + r) * HW + px * S + s) * BC];
                         acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KS + s], 0, 0, 0);
                     }
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WArgs a) {
     }
     // ---- write partials: part[split][tap][k][c] ----
     const size_t KC_ = (size_t)a.Cout * a.Cin;
-    float* pb = a.part + (size_t)split * T * KC_;
+    float* pb = a.part + ((size_t)split * nsub + sub) * T * KC_;
     const int c = c0 + wc * 32 + l31;
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -1349,6 +1360,7 @@ struct WPlan {
     unet_tuning tune;
     WArgs k;
     int ptw, splits, T, narrow, gemm1x1, small1x1, ps, bf16;
+    int nsub;        // partial images per workgroup (wgrad_kernel's pixel sub-splits of narrow layers): the reduce kernels sum splits * nsub slices
     long long pix_per_block;
     size_t lds_bytes, lds_bytes16;
 };
@@ -1379,6 +1391,7 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.Cin4 = unet::roundup(d->Cin, vec);
     k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cout4 = unet::roundup(d->Cout, vec);
     p->T = d->ks * d->ks;
+    p->nsub = 1;
     p->ptw = d->OW >= 32 ? 32 : (d->OW >= 16 ? 16 : 8);
     const int pt = p->bf16 ? (d->stride == 1 ? 128 : 32) : (d->stride == 1 ? 64 : 32);   // bf16: four (stride 2: one) MFMA k-blocks of 32 pixels
     const int pth = pt / p->ptw;
@@ -1449,6 +1462,12 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
     if (tpb > k.total_tiles) tpb = k.total_tiles;
     k.tiles_per_block = tpb;
     p->splits = unet::cdiv(k.total_tiles, tpb);
+    // fp32 wgrad_kernel on layers of <= 32 input and / or output channels: empty channel halves become pixel sub-splits (see the kernel)
+    if (!p->bf16 && !p->narrow && !p->gemm1x1 && p->tune.wgrad_mfma_shape == 32 && p->tune.wgrad_narrow != 3) {
+        k.csub = d->Cin <= 32 ? 1 : 0;
+        k.ksub = d->Cout <= 32 ? 1 : 0;
+        p->nsub = (1 + k.csub) * (1 + k.ksub);
+    }
     const int hh = (pth - 1) * d->stride + d->ks, hw = (p->ptw - 1) * d->stride + d->ks;
     p->lds_bytes = (size_t)(pt * BK + hh * hw * BC) * sizeof(float);
     p->lds_bytes16 = (size_t)(pt + hh * hw) * (d->stride == 1 ? 80 : 72) * sizeof(float);
@@ -1553,14 +1572,14 @@ extern "C" size_t unet_conv2d_wgrad_workspace(const unet_wgrad_desc* d) {
     WPlan p;
     if (make_wplan(d, &p) != UNET_OK) return 0;
     // split-K partials of dW followed by the [splits][Cout] partial column sums of dy (bias gradient)
-    return (size_t)p.splits * p.T * d->Cout * d->Cin + (size_t)p.splits * d->Cout;
+    return (size_t)p.splits * p.nsub * p.T * d->Cout * d->Cin + (size_t)p.splits * d->Cout;
 }
 
 extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     WPlan p;
     int rc = make_wplan(d, &p);
     if (rc != UNET_OK) return rc;
-    const size_t npart = (size_t)p.splits * p.T * d->Cout * d->Cin;
+    const size_t npart = (size_t)p.splits * p.nsub * p.T * d->Cout * d->Cin;
     const size_t need = npart + (size_t)p.splits * d->Cout;
     UNET_CHECK_ARG(d->workspace != nullptr && d->workspace_floats >= need, "wgrad: workspace too small (%zu < %zu floats)",
                    d->workspace_floats, need);
@@ -1618,18 +1637,19 @@ extern "C" int unet_conv2d_wgrad(const unet_wgrad_desc* d, void* stream) {
     }
     if (rc != UNET_OK) return rc;
     const size_t KC_ = (size_t)d->Cout * d->Cin;
+    const int slices = p.splits * p.nsub;          // partial images to sum
     if (p.small1x1)
         hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(unet::cdiv((int)(KC_ * p.T), 64)), dim3(256), 0, st, d->workspace, d->dw,
                            p.splits, p.T, KC_, d->accumulate);
-    else if (p.splits >= 32 && KC_ * p.T < ((size_t)1 << 31) / 8)
+    else if (slices >= 32 && KC_ * p.T < ((size_t)1 << 31) / 8)
         hipLaunchKernelGGL(wgrad_reduce_q_kernel<8>, dim3((unsigned)unet::cdiv((long long)(KC_ * p.T), 32LL)), dim3(256), 0, st, d->workspace, d->dw,
-                           p.splits, p.T, KC_, d->accumulate);
-    else if (p.splits >= 8 && KC_ * p.T < ((size_t)1 << 31) / 8)
+                           slices, p.T, KC_, d->accumulate);
+    else if (slices >= 8 && KC_ * p.T < ((size_t)1 << 31) / 8)
         hipLaunchKernelGGL(wgrad_reduce_q_kernel<4>, dim3((unsigned)unet::cdiv((long long)(KC_ * p.T), 64LL)), dim3(256), 0, st, d->workspace, d->dw,
-                           p.splits, p.T, KC_, d->accumulate);
+                           slices, p.T, KC_, d->accumulate);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(unet::ew_grid((long long)KC_ * p.T, 256)), dim3(256), 0, st, d->workspace, d->dw,
-                           p.splits, p.T, KC_, d->accumulate);
+                           slices, p.T, KC_, d->accumulate);
     UNET_CHECK_LAUNCH();
     if (d->dbias != nullptr) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(unet::cdiv(d->Cout, 64)), dim3(256), 0, st, p.k.bpart, d->dbias, p.splits,
