@@ -6,7 +6,8 @@ strips or tiles, chunky or planar, 8/16/32/64-bit unsigned / signed / float samp
 on request -- none, LZW (5), Deflate (8 / 32946), PackBits (32773) -- with horizontal differencing (Predictor 2), plus the GeoTIFF
 georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922, GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams
 34737, GDAL_NODATA 42113) which are passed through verbatim.  Anything else (JPEG, floating-point predictor 3, ...) raises loudly.
-The byte-oriented decoders are C functions of libunet_hip.so (csrc/tiff_codecs.hip); files are written uncompressed.
+The byte-oriented decoders are C functions (csrc/tiff_codecs.hip: in libunet_hip.so, and linked by g++ alone into the host-only
+libunet_tiff.so); files are memory-mapped for reading and written uncompressed.
 """
 from __future__ import annotations
 
