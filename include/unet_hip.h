@@ -297,6 +297,14 @@ int unet_ce_fwd_parts(const float* z, int z_cs, int z_co, const int64_t* target,
 /* dz = gscale * w[y] * (softmax(z) - onehot(y)) / denom ; gscale multiplies (loss scaling / DDP averaging) */
 int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
                 const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream);
+/* FocalLossFlat(gamma, axis=1): the alternative classification loss the reference's configuration names (params_and_main.py:87-89).  fastai 2.5.1
+ * losses.FocalLoss: ce = w[y] * nll per pixel (F.cross_entropy(weight, reduction="none"); train.py:211 assigns the class weights to every
+ * loss), loss = mean over ALL P pixels of (1 - exp(-ce))^gamma * ce.  dz = gscale * d loss / d z.  workspace = unet_ce_workspace(P) floats.
+ * Where ce == 0 exactly and gamma < 1, torch's autograd returns NaN (0 * inf); these kernels return the limit, 0. */
+int unet_focal_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                   float* loss /*[1]*/, float* workspace, void* stream);
+int unet_focal_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                   float gscale, float* dz, int dz_cs, int dz_co, void* stream);
 /* Regression mode (enable_regression, reference train.py:137-138,189-193; utils.py:145-147): n_out = 1, the loss is the mean over all
  * pixels of kind 0 = (z - t)^2 (MSELossFlat), 1 = |z - t| (L1LossFlat), 2 = SmoothL1(beta) (Smoothl1: beta 0.5).  z = channel z_co of
  * the NHWC output [P,z_cs], float targets [P]; workspace = unet_ce_workspace(P) floats.
@@ -413,6 +421,7 @@ int unet_resize_nearest_bwd_bf16(const unet_bf16* dy, int dy_cs, int dy_co, unet
 int unet_nchw_to_nhwc_bf16(const float* x, unet_bf16* y, int y_cs, int y_co, int N, int C, int H, int W, void* stream);
 int unet_copy_slice_bf16(const unet_bf16* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, int accumulate, void* stream);
 int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream);
+int unet_focal_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream);
 /* bf16 SelfAttention (round 3): the attention logits and the gradient of the attention weights stay fp32 (the products that make them write
  * fp32: unet_conv_desc.y_f32), the weights themselves and every other tensor are bf16 */
 int unet_pack_weights_strided_bf16(const unet_bf16* w, long long so, long long sr, unet_bf16* wp, int O, int R, void* stream);

@@ -366,6 +366,35 @@ class CrossEntropyLossFlat:
         return x.argmax(dim=self.axis)
 
 
+class FocalLossFlat:
+    """fastai 2.5.1 ``FocalLossFlat(gamma, axis=1)`` = ``BaseLoss(FocalLoss, gamma=gamma, axis=axis)`` -- the alternative classification
+    loss of the reference's configuration (params_and_main.py:87-89).  ``FocalLoss.forward``: ``ce = F.cross_entropy(inp, targ,
+    weight=self.weight, reduction="none"); p_t = exp(-ce); loss = ((1 - p_t) ** gamma * ce).mean()``; ``.func.weight`` is assigned by
+    the reference for every loss (train.py:211)."""
+
+    class _Func:
+        def __init__(self, gamma, weight):
+            self.gamma, self.weight = gamma, weight
+
+    def __init__(self, gamma: float = 2.0, weight: Optional[torch.Tensor] = None, axis: int = 1):
+        self.func = FocalLossFlat._Func(gamma, weight)
+        self.axis = axis
+
+    def __call__(self, inp: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        inp = inp.transpose(self.axis, -1).contiguous()          # BaseLoss.__call__: input AND target transposed, then flattened
+        targ = targ.transpose(self.axis, -1).contiguous()
+        w = self.func.weight
+        ce = F.cross_entropy(inp.view(-1, inp.shape[-1]), targ.view(-1), weight=None if w is None else w.to(inp.dtype), reduction="none")
+        p_t = torch.exp(-ce)
+        return ((1 - p_t) ** self.func.gamma * ce).mean()
+
+    def activation(self, x):
+        return F.softmax(x, dim=self.axis)
+
+    def decodes(self, x):
+        return x.argmax(dim=self.axis)
+
+
 class _FlatRegLoss:
     """fastai ``BaseLoss(loss_cls, axis=1, floatify=True, is_2d=False)`` as used by the regression branch
     (train.py:189-193 ``MSELossFlat(axis=1)``; utils.py:145-147 ``Smoothl1``): both tensors are transposed

@@ -52,7 +52,8 @@ self_attention = True
 ENCODER_FACTOR = 10
 LR_FINDER = None               # None, "minimum", "steep", "valley", "slide"
 VALID_SCENES = ["vali"]
-loss_func = None               # None = CrossEntropyLossFlat(axis=1) (the reference's default object); regression: MSELossFlat(axis=1), L1LossFlat
+loss_func = None               # None = CrossEntropyLossFlat(axis=1) (the reference's default object) | FocalLossFlat(gamma=2, axis=1) (from unet_amd.learner);
+                               # regression: MSELossFlat(axis=1), L1LossFlat
 monitor = "valid_loss"         # 'dice_multi', 'r2_score', 'train_loss', 'valid_loss'
 all_classes = False
 specific_class = None

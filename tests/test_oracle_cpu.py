@@ -133,3 +133,22 @@ def test_merge_golden_fixture_is_self_consistent():
         cnt[y0:y0 + 8, x0:x0 + 8] += 1
     m = np.where(cnt > 0, acc / np.maximum(cnt, 1), acc)
     assert np.allclose(m, g["merged"]) and np.array_equal(m.argmax(0).astype(np.uint8), g["argmax"])
+
+
+def test_focal_loss_restatement_is_fastai_focal_loss():
+    """oracle FocalLossFlat = fastai 2.5.1 FocalLoss.forward behind BaseLoss's transpose + flatten: (1 - exp(-ce))^gamma * ce, ce = weighted
+    per-pixel cross-entropy, plain mean; gamma = 0 without weights is the cross-entropy"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import unet_oracle as O
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(2, 4, 5, 6, generator=g)
+    y = torch.randint(0, 4, (2, 5, 6), generator=g)
+    w = torch.tensor([0.4, 1.0, 2.0, 0.7])
+    for gamma in (2.0, 0.5):
+        ce = F.cross_entropy(z, y, weight=w, reduction="none")
+        want = ((1 - torch.exp(-ce)) ** gamma * ce).mean()
+        assert torch.allclose(O.FocalLossFlat(gamma=gamma, weight=w)(z, y), want, rtol=1e-6)
+    assert torch.allclose(O.FocalLossFlat(gamma=0.0)(z, y), O.CrossEntropyLossFlat()(z, y), rtol=1e-6)
+    f = O.FocalLossFlat()
+    assert f.func.gamma == 2.0 and torch.equal(f.decodes(z), z.argmax(1)) and torch.allclose(f.activation(z), torch.softmax(z, 1))

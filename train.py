@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from unet_amd import xresnet34  # noqa: F401  (architecture tokens, like `from fastai.vision.all import xresnet34`)
-from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, FlipAugment, L1LossFlat, Learner,
+from unet_amd.learner import (Adam, CrossEntropyLossFlat, CSVLogger, DataLoaders, DiceMulti, FlipAugment, FocalLossFlat, L1LossFlat, Learner,  # noqa: F401
                               Learner_adjust, MSELossFlat, R2Score, Rmse, SaveModelCallback, Smoothl1, TileDataset, load_learner,
                               open_tile)
 from unet_amd.model import HipDynamicUnet

@@ -152,6 +152,8 @@ _sig = {
     "unet_ce_fwd": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp, vp]),
     "unet_ce_fwd_parts": (i, [vp, i, i, vp, vp, ll, i, vp, vp, vp]),
     "unet_ce_bwd": (i, [vp, i, i, vp, vp, ll, i, vp, f, vp, i, i, vp]),
+    "unet_focal_fwd": (i, [vp, i, i, vp, vp, ll, i, f, vp, vp, vp]),
+    "unet_focal_bwd": (i, [vp, i, i, vp, vp, ll, i, f, f, vp, i, i, vp]),
     "unet_regloss_fwd": (i, [vp, i, i, vp, ll, i, f, vp, vp, vp]),
     "unet_regloss_bwd": (i, [vp, i, i, vp, ll, i, f, f, vp, i, i, vp]),
     "unet_softmax_argmax": (i, [vp, i, i, i, i, i, i, vp, vp, vp]),
@@ -174,7 +176,7 @@ _sig = {
 }
 # bf16-storage twins: same argument lists (every tensor is a void pointer on this side)
 for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x3s2", "maxpool3x3s2_bwd", "avgpool2_ceil",
-           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "shuffle_bwd_xmask", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd"):
+           "avgpool2_ceil_bwd", "shuffle_blur", "shuffle_blur_bwd", "shuffle_bwd_xmask", "resize_nearest", "resize_nearest_bwd", "nchw_to_nhwc", "copy_slice", "ce_bwd", "focal_bwd"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
 for _n in ("pack_weights_strided", "row_softmax", "row_softmax_bwd", "relu_mask", "dot"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]

@@ -1037,6 +1037,69 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
     }
 }
 
+// FocalLossFlat(gamma, axis=1) -- the alternative classification loss the reference's configuration names (params_and_main.py:87-89:
+// `FocalLossFlat(gamma=2, axis=1)`, `gamma=0.5`).  fastai 2.5.1 losses.FocalLoss.forward, per pixel:
+//     ce = F.cross_entropy(inp, targ, weight, reduction="none") = w[y] * nll      (train.py:211 assigns loss_func.func.weight for every loss)
+//     p_t = exp(-ce);   loss = (1 - p_t)^gamma * ce;   'mean' = sum / P over ALL pixels (a plain mean, not the weighted mean of the CE)
+// d loss / d z_c = [gamma (1 - p_t)^(gamma-1) p_t ce + (1 - p_t)^gamma] * w[y] (softmax_c - [c == y]) / P.  Where ce == 0 exactly (a logit margin
+// beyond fp32's exp range) the first term is 0 * inf for gamma < 1 -- torch's autograd yields NaN there; this kernel yields the limit, 0.
+__device__ __forceinline__ void focal_terms(float ce, float gamma, float& val, float& dval) {
+    const float pt = expf(-ce), q = 1.f - pt;
+    if (q <= 0.f) { val = 0.f; dval = 0.f; return; }
+    const float qg = powf(q, gamma);
+    val = qg * ce;
+    dval = gamma * (qg / q) * pt * ce + qg;
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const int64_t* __restrict__ target,
+                                                        const float* __restrict__ weight, long long P, int C, float gamma, float* __restrict__ part) {
+    float num = 0.f;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const long long y = target[p];
+        if (y < 0 || y >= C) continue;  // ignore_index semantics: contributes 0 to the sum, still counts in the mean
+        const float* zp = z + (size_t)p * z_cs + z_co;
+        float m = zp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zp[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
+        const float ce = (weight ? weight[y] : 1.f) * ((m + logf(s)) - zp[y]);
+        float v, dv;
+        focal_terms(ce, gamma, v, dv);
+        num += v;
+    }
+    __shared__ float sn[4];
+    for (int o = 32; o > 0; o >>= 1) num += __shfl_down(num, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sn[wv] = num;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sn[0] + sn[1] + sn[2] + sn[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ z, int z_cs, int z_co, const int64_t* __restrict__ target,
+                                                        const float* __restrict__ weight, long long P, int C, float gamma, float gscale,
+                                                        T* __restrict__ dz, int dz_cs, int dz_co) {
+    const float inv = gscale / (float)P;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const long long y = target[p];
+        T* dp = dz + (size_t)p * dz_cs + dz_co;
+        if (y < 0 || y >= C) {
+            for (int c = 0; c < C; ++c) st1(dp + c, 0.f);
+            continue;
+        }
+        const float* zp = z + (size_t)p * z_cs + z_co;
+        float m = zp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zp[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(zp[c] - m);
+        const float w = weight ? weight[y] : 1.f;
+        float v, dv;
+        focal_terms(w * ((m + logf(s)) - zp[y]), gamma, v, dv);
+        const float g = dv * w * inv, is = 1.f / s;
+        for (int c = 0; c < C; ++c) st1(dp + c, g * (expf(zp[c] - m) * is - (c == y ? 1.f : 0.f)));
+    }
+}
+
 // Regression losses of the enable_regression branch (reference train.py:189-193: MSELossFlat(axis=1); utils.py:145-147:
 // Smoothl1 = SmoothL1Loss(beta=0.5); fastai L1LossFlat): prediction = channel 0 of the [P,1] output slice, float targets,
 // 'mean' reduction over all P pixels.  kind 0: d^2   1: |d|   2: |d| < beta ? d^2 / (2 beta) : |d| - beta / 2
@@ -1664,6 +1727,33 @@ extern "C" int unet_ce_bwd(const float* z, int z_cs, int z_co, const int64_t* ta
                            const float* denom, float gscale, float* dz, int dz_cs, int dz_co, void* stream) { return ce_bwd_impl<float>(z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs, dz_co, stream); }
 extern "C" int unet_ce_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C,
                            const float* denom, float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream) { return ce_bwd_impl<unet_bf16>(z, z_cs, z_co, target, weight, P, C, denom, gscale, dz, dz_cs, dz_co, stream); }
+
+extern "C" int unet_focal_fwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                              float* loss, float* workspace, void* stream) {
+    UNET_CHECK_ARG(z && target && loss && workspace && P > 0 && C > 0 && C <= CE_MAXC && gamma >= 0.f, "focal_fwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs, "focal_fwd: bad slice");
+    const int rows = ce_rows(P);
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(rows), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, gamma, workspace);
+    UNET_CHECK_LAUNCH();
+    hipLaunchKernelGGL(regloss_finalize_kernel, dim3(1), dim3(64), 0, ST, workspace, rows, P, loss);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+template <typename T>
+static int focal_bwd_impl(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                          float gscale, T* dz, int dz_cs, int dz_co, void* stream) {
+    UNET_CHECK_ARG(z && target && dz && P > 0 && C > 0 && C <= CE_MAXC && gamma >= 0.f, "focal_bwd: bad args");
+    UNET_CHECK_ARG(z_co >= 0 && z_co + C <= z_cs && dz_co >= 0 && dz_co + C <= dz_cs, "focal_bwd: bad slice");
+    hipLaunchKernelGGL((focal_bwd_kernel<T>), dim3(ew_grid(P, 256)), dim3(256), 0, ST, z, z_cs, z_co, target, weight, P, C, gamma, gscale, dz, dz_cs,
+                       dz_co);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+extern "C" int unet_focal_bwd(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                              float gscale, float* dz, int dz_cs, int dz_co, void* stream) { return focal_bwd_impl<float>(z, z_cs, z_co, target, weight, P, C, gamma, gscale, dz, dz_cs, dz_co, stream); }
+extern "C" int unet_focal_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* target, const float* weight, long long P, int C, float gamma,
+                              float gscale, unet_bf16* dz, int dz_cs, int dz_co, void* stream) { return focal_bwd_impl<unet_bf16>(z, z_cs, z_co, target, weight, P, C, gamma, gscale, dz, dz_cs, dz_co, stream); }
 
 extern "C" int unet_regloss_fwd(const float* z, int z_cs, int z_co, const float* target, long long P, int kind, float beta, float* loss,
                                 float* workspace, void* stream) {

@@ -7,7 +7,8 @@ train_bn, moms`` (``train.py:148-154``); ``unfreeze`` (``:246``); ``fit_one_cycl
 ``loss_func=`` / ``opt_func=`` (``:226-229,258``); ``export`` (``:373``); ``load_learner`` (``:225``, ``predict.py:161``);
 ``predict(item)`` -> 3-tuple whose [2] is per-class probabilities [C,H,W] (``predict.py:193-203``);
 ``get_preds``; ``summary``; callbacks ``SaveModelCallback(monitor, comp, fname)`` and ``CSVLogger`` (``train.py:209``);
-``CrossEntropyLossFlat(axis=1, weight)`` with assignable ``.func.weight`` (``train.py:195,211``); ``DiceMulti``.
+``CrossEntropyLossFlat(axis=1, weight)`` with assignable ``.func.weight`` (``train.py:195,211``), ``FocalLossFlat(gamma, axis=1)``
+(``params_and_main.py:87-89``); ``DiceMulti``.
 """
 from __future__ import annotations
 
@@ -76,6 +77,25 @@ class CrossEntropyLossFlat:
 
     def decodes(self, x):
         return x.argmax(dim=self.axis)
+
+
+class FocalLossFlat(CrossEntropyLossFlat):
+    """fastai ``FocalLossFlat(gamma=2.0, axis=1)``, the alternative classification loss of the reference's configuration
+    (params_and_main.py:87-89): mean over all pixels of ``(1 - exp(-ce)) ** gamma * ce`` with ``ce = w[y] * nll`` (train.py:211 assigns
+    ``.func.weight`` for every loss).  Fused on the device (unet_focal_fwd / unet_focal_bwd) like the cross-entropy."""
+
+    def __init__(self, *args, gamma: float = 2.0, axis: int = 1, weight: Optional[torch.Tensor] = None):
+        super().__init__(axis=axis, weight=weight)
+        self.func.gamma = float(gamma)
+
+    @property
+    def gamma(self) -> float:
+        return float(self.func.gamma)
+
+    def __call__(self, logits: torch.Tensor, targ: torch.Tensor) -> torch.Tensor:
+        """Generic path (torch autograd)."""
+        ce = torch.nn.functional.cross_entropy(logits, targ.long(), weight=self._w(logits.device), reduction="none")
+        return ((1 - torch.exp(-ce)) ** self.gamma * ce).mean()
 
 
 class _RegLoss:
@@ -624,6 +644,10 @@ class Learner:
         return self.loss_func._w(self.dls.device) if isinstance(self.loss_func, CrossEntropyLossFlat) else None
 
     @property
+    def _focal_gamma(self) -> Optional[float]:
+        return self.loss_func.gamma if isinstance(self.loss_func, FocalLossFlat) else None
+
+    @property
     def regression(self) -> bool:
         return isinstance(self.loss_func, _RegLoss)
 
@@ -660,6 +684,8 @@ class Learner:
         step = TrainStep(model, opt, self._weights(), self.world) if fused else None
         if fused and self.regression:
             step.reg_kind, step.reg_beta = self.loss_func.kind, self.loss_func.beta
+        if fused:
+            step.focal_gamma = self._focal_gamma
         n_iter = len(self.dls.train)
         total = max(1, n_epoch * n_iter)
         for cb in self.cbs:
@@ -727,11 +753,16 @@ class Learner:
                 continue
             yb = yb.to(model._device, torch.int64).contiguous()
             loss, denom = ctx.vec(self, "vloss", 1), ctx.vec(self, "vden", 1)
-            ops.ce_fwd(z, yb, w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
+            if self._focal_gamma is not None:          # a plain mean over the pixels: numerator = loss * P, denominator = P
+                ops.focal_fwd(z, yb, w, self._focal_gamma, loss, ctx.workspace(ops.ce_workspace(z.P)))
+                acc[0] += loss[0].double() * z.P
+                acc[1] += z.P
+            else:
+                ops.ce_fwd(z, yb, w, loss, denom, ctx.workspace(ops.ce_workspace(z.P)))
+                acc[0] += loss[0].double() * denom[0].double()
+                acc[1] += denom[0].double()
             amax = torch.empty((z.N, z.H, z.W), dtype=torch.int64, device=model._device)
             ops.softmax_argmax(z, None, amax)
-            acc[0] += loss[0].double() * denom[0].double()
-            acc[1] += denom[0].double()
             for m in self.metrics:
                 m.accumulate_argmax(amax, yb, z.C)
         num, den = acc.cpu().tolist()          # the one host sync of the pass
@@ -882,6 +913,7 @@ class Learner:
                 "dtype": self.dls.train_ds.dtype if self.dls is not None else "int8",
                 "class_weights": None if w is None else [float(v) for v in torch.as_tensor(w).cpu()],
                 "regression": self.loss_func.kind if self.regression else None,
+                "focal_gamma": self._focal_gamma,
                 "self_attention": bool(getattr(m, "self_attention", False)), "act_dtype": getattr(m, "act_dtype", "f32")}
         p = Path(fname)
         p = p if p.is_absolute() else self.path / p
@@ -920,5 +952,6 @@ def load_learner(fname, device="cuda", act_dtype: Optional[str] = None) -> Learn
     if meta.get("regression"):
         loss = {"mse": MSELossFlat, "l1": L1LossFlat, "smoothl1": Smoothl1}[meta["regression"]](axis=1)
         return Learner_adjust(dls, model, loss_func=loss, metrics=[Rmse(), R2Score()])
-    loss = CrossEntropyLossFlat(axis=1, weight=None if w is None else torch.tensor(w))
+    wt = None if w is None else torch.tensor(w)
+    loss = CrossEntropyLossFlat(axis=1, weight=wt) if meta.get("focal_gamma") is None else FocalLossFlat(gamma=meta["focal_gamma"], axis=1, weight=wt)
     return Learner(dls, model, loss_func=loss, metrics=[DiceMulti()])

@@ -437,7 +437,7 @@ class HipDynamicUnet(nn.Module):
 
     def forward_loss_backward(self, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,
                               grad_scale: float = 1.0, reg_kind: Optional[str] = None, reg_beta: float = 0.5,
-                              world: int = 1) -> torch.Tensor:
+                              world: int = 1, focal_gamma: Optional[float] = None) -> torch.Tensor:
         """One fused training pass: logits -> loss -> backward into the flat gradient buffer.  Returns the loss as a 1-element
         device tensor (no host sync).  grad_scale multiplies the gradient.
         world > 1 (tile-DDP): the weighted cross-entropy is sum_r num_r / sum_r den_r over the ranks (den_r = sum of w[y] on
@@ -446,13 +446,25 @@ class HipDynamicUnet(nn.Module):
         and the SUM all-reduce of the gradients then equals the single-process gradient of the global batch.  Regression
         losses are plain means over equally many pixels per rank: gradient pre-scaled by 1/world.
         Classification (default): weighted per-pixel cross-entropy, CrossEntropyLossFlat(axis=1, weight) (train.py:195,211).
+        focal_gamma: FocalLossFlat(gamma, axis=1) instead (params_and_main.py:87-89): a plain mean over equally many pixels per rank, like the
+        regression losses -- loss averaged over the ranks, gradient pre-scaled by 1 / world.
         Regression (reg_kind = "mse" | "l1" | "smoothl1", n_out = 1, float targets [B,H,W]): train.py:189-193."""
         x = x.to(self._device, torch.float32)
         z = self._hip_forward(x, True)
         ctx = self.ctx
         P = z.P
         dz = ctx.act(self, "dlogits", z.N, z.H, z.W, z.C, zero=True)
-        if reg_kind is None:
+        if reg_kind is None and focal_gamma is not None:
+            y = y.to(self._device, torch.int64).contiguous()
+            loss = ctx.vec(self, "loss", 1)
+            ops.focal_fwd(z, y, weight, focal_gamma, loss, ctx.workspace(ops.ce_workspace(P)))
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(loss)
+                loss.div_(world)
+                grad_scale = grad_scale / world
+            ops.focal_bwd(z, y, weight, focal_gamma, grad_scale, dz)
+        elif reg_kind is None:
             y = y.to(self._device, torch.int64).contiguous()
             loss, denom = ctx.vec(self, "loss", 1), ctx.vec(self, "denom", 1)
             if world > 1:

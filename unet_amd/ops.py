@@ -644,6 +644,19 @@ def ce_bwd(z: TS, target, weight, denom, gscale: float, dz: TS):
                           dz.co, _stream()), "ce_bwd")
 
 
+def focal_fwd(z: TS, target: torch.Tensor, weight, gamma: float, loss, ws):
+    """loss[0] = mean over all pixels of (1 - exp(-ce))^gamma * ce, ce = w[y] * nll (fastai FocalLossFlat(gamma, axis=1))"""
+    _need_f32("focal_fwd", z)
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == z.P
+    check(lib.unet_focal_fwd(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, float(gamma), loss.data_ptr(), ws.data_ptr(), _stream()),
+          "focal_fwd")
+
+
+def focal_bwd(z: TS, target, weight, gamma: float, gscale: float, dz: TS):
+    check(_fn("focal_bwd", dz)(z.ptr, z.cs, z.co, target.data_ptr(), _p(weight), z.P, z.C, float(gamma), gscale, dz.ptr, dz.cs, dz.co, _stream()),
+          "focal_bwd")
+
+
 REG_KINDS = {"mse": 0, "l1": 1, "smoothl1": 2}
 
 

@@ -26,6 +26,7 @@ class TrainStep:
         self.weights = class_weights
         self.reg_kind: Optional[str] = None     # "mse" | "l1" | "smoothl1": regression mode (float targets, n_out = 1)
         self.reg_beta = 0.5
+        self.focal_gamma: Optional[float] = None    # FocalLossFlat(gamma) instead of the weighted cross-entropy (params_and_main.py:87-89)
         self.use_graph = use_graph and world == 1
         if self.use_graph:
             # a replayed graph has no host in the loop: the second stream of the weight gradients buys nothing there and its
@@ -50,7 +51,7 @@ class TrainStep:
         if self._graph is None:
             if self._calls < 2:                     # eager warm-up: allocates every persistent buffer / workspace
                 self._calls += 1
-                loss = m.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta)
+                loss = m.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta, focal_gamma=self.focal_gamma)
                 opt.step()
                 return loss
             self._xs = x.to(m._device, torch.float32).clone()
@@ -60,7 +61,7 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._loss = m.forward_loss_backward(self._xs, self._ys, self.weights, grad_scale=1.0, reg_kind=self.reg_kind,
-                                                     reg_beta=self.reg_beta)
+                                                     reg_beta=self.reg_beta, focal_gamma=self.focal_gamma)
                 opt.step_from_device_hyper()
             # (the capture itself does not execute the step)
         self._xs.copy_(x, non_blocking=True)
@@ -80,7 +81,7 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.reset()
         loss = self.model.forward_loss_backward(x, y, self.weights, grad_scale=1.0, reg_kind=self.reg_kind, reg_beta=self.reg_beta,
-                                                world=self.world)
+                                                world=self.world, focal_gamma=self.focal_gamma)
         if self.reducer is not None:
             ev = self.comm_events
             if ev is not None:
