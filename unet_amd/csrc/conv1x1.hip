@@ -244,6 +244,7 @@ static bool shape_ok(const unet_conv_desc* d) {
     if (d->Cin < kct || d->Cin % kct != 0) return false;
     if (d->cout_begin % 128 != 0) return false;
     const int cols = d->cout_count ? d->cout_count : d->Cout;
+    if (cols % 4 != 0 && d->cout_begin + cols != d->Cout) return false;      // (a channel range ends on a 4-channel vector unless it ends the tensor)
     const int pb = tuning_of(d->tuning).plan_batch;          // (the grid test is a plan decision: unet_tuning.plan_batch makes it batch-invariant)
     const long long P = (long long)(pb > 0 ? pb : d->N) * d->OH * d->OW;
     return ((P + 127) / 128) * ((cols + 127) / 128) >= 256;
@@ -267,7 +268,9 @@ int conv_gemm1x1_ps_check(const unet_conv_desc* d) {
                    "conv pixel_shuffle: a 1x1 / stride-1 forward convolution");
     UNET_CHECK_ARG(d->Cout % 64 == 0, "conv pixel_shuffle: Cout = 4 nf with nf a multiple of 16 (got %d)", d->Cout);
     UNET_CHECK_ARG(unet::slice_ok_v(d->x_cs, d->x_co, d->Cin, vec), "conv pixel_shuffle: bad x slice");
-    UNET_CHECK_ARG(unet::slice_ok_v(d->y_cs, d->y_co, d->Cout / 4, (d->dtype == UNET_BF16 && !d->y_f32) ? 4 : 4), "conv pixel_shuffle: bad y slice (Cout / 4 channels of a [N, 2 OH, 2 OW] tensor)");
+    UNET_CHECK_ARG(unet::slice_ok_v(d->y_cs, d->y_co, d->Cout / 4, 4), "conv pixel_shuffle: bad y slice (Cout / 4 channels of a [N, 2 OH, 2 OW] tensor)");
+    UNET_CHECK_ARG((d->flags & ~(UNET_CONV_RELU | UNET_CONV_MASK)) == 0, "conv pixel_shuffle: unknown flag bits 0x%x", d->flags);
+    UNET_CHECK_ARG(d->bias == nullptr || (((uintptr_t)d->bias) & 3) == 0, "conv pixel_shuffle: bias must be a float pointer");
     UNET_CHECK_ARG(d->res == nullptr && !(d->flags & UNET_CONV_MASK) && d->colsum == nullptr && d->colsumsq == nullptr && d->cout_begin == 0 &&
                    d->cout_count == 0 && d->wp_img_stride == 0, "conv pixel_shuffle: no residual / mask / column sums / channel range / per-image filters");
     UNET_CHECK_ARG((long long)d->N * d->OH * d->OW * 4 < (1ll << 31), "conv pixel_shuffle: more than 2^31 output pixels");

@@ -188,6 +188,11 @@ class HipDynamicUnet(nn.Module):
             if training and cx._ver_d != ver:
                 jobs.append((cx.wsrc(), cx.wp_d, 1, None))
                 marks.append((cx, 1, ver))
+            # the pixel-shuffle image of the final upsample conv (built on demand the first time, ops.conv1x1_shuffle): once it exists it is
+            # rebuilt with everything else instead of by a launch of its own per step
+            if cx.wp_s is not None and cx.wp_s.dtype == self.ctx.act_dtype and cx._ver_s != ver and not cx.gapped:
+                jobs.append((cx.conv.weight.data, cx.wp_s, 2, None))
+                marks.append((cx, 2, ver))
         if not jobs:
             return
         bf = self.ctx.act_dtype == torch.bfloat16
@@ -197,7 +202,7 @@ class HipDynamicUnet(nn.Module):
         else:
             # the input-gradient images are first read when the backward starts: they are built on the weight-gradient stream next to the
             # forward pass (half of an HBM-bound launch over every parameter leaves the critical path); _hip_backward waits for the event
-            fwd = [j for j in jobs if j[2] != 1]
+            fwd = [j for j in jobs if j[2] != 1]          # (modes 0 and 2: read by the forward pass)
             bwd = [j for j in jobs if j[2] == 1]
             if fwd:
                 ops.pack_jobs(fwd, bf, self._device, self._pack_tables)
@@ -213,6 +218,8 @@ class HipDynamicUnet(nn.Module):
         for cx, mode, ver in marks:
             if mode == 0:
                 cx._ver_f = ver
+            elif mode == 2:
+                cx._ver_s = ver
             else:
                 cx._ver_d = ver
 
