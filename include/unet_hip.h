@@ -69,7 +69,8 @@ typedef struct {
                                1 = its direct form, 2 = its staged form (both storage types), -1 = never.  pixel_shuffle descriptors always use it */
     int wgrad_mfma_shape;   /* fp32 weight gradient: 32 (default) | 16 (opt-in: loses to wave imbalance) */
     int wgrad_bf16_k4;      /* 1: bf16 3x3 / 1x1 stride-1 weight gradients on wgrad_bf16_k4_kernel (default); 0: wgrad_bf16_kernel */
-    int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default) */
+    int wgrad_1x1;          /* 1: the 128x128-tiled GEMM kernel (and the small-output FMA kernel) for fp32 1x1 weight gradients (default; launches of
+                               <= 64 input / output channels or < 3 GFLOP stay on the 64x64-blocked general kernel); 2: the GEMM kernel for all; 0: never */
     int wgrad_narrow;       /* 1: the narrow-output (80 < Cout <= 112) flattened-tap fp32 weight-gradient kernel (default); 2: the same without the
                                4-row v_mfma_f32_4x4x1 sliver for 97..100 output channels (seven 16-row tiles: A/B, cross-check); 3: as 1, and the
                                general fp32 kernel without the pixel sub-splits of layers with <= 32 input / output channels (A/B) */

@@ -491,6 +491,31 @@ def test_conv_wgrad(ops, case):
     assert_close(dw.cpu(), 2 * ref, rtol=3e-4, atol=2e-4, what=f"wgrad accumulate {case}")
 
 
+@pytest.mark.parametrize("mode", [2, 0])
+def test_wgrad_1x1_kernels_agree(ops, mode):
+    """1x1 weight gradients on the 128 x 128-blocked GEMM kernel (unet_tuning.wgrad_1x1 = 2: forced; the planner keeps it for launches of more
+    than 64 channels on both sides and >= 3 GFLOP) and on the 64 x 64-blocked general kernel (0), against torch: ragged channel counts on
+    both sides of the block sizes, SelfAttention's 48-wide operands, bias gradient, accumulate"""
+    for case in [(2, 16, 16, 128, 256), (1, 24, 40, 48, 300), (1, 24, 40, 300, 48), (2, 17, 19, 130, 70), (1, 64, 64, 96, 384)]:
+        N, H, W, Cin, Cout = case
+        g = torch.Generator().manual_seed(sum(case) + mode)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        dy = torch.randn(N, Cout, H, W, generator=g)
+        ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 1, 1), dy)
+        xt, dyt = to_ts(x), to_ts(dy)
+        with ops.tuning(wgrad_1x1=mode):
+            ws = torch.empty(ops.wgrad_workspace(xt, dyt, 1, 1, with_bias=True), device="cuda")
+            dw = torch.full((Cout, Cin, 1, 1), 3.0, device="cuda")
+            db = torch.full((Cout,), 3.0, device="cuda")
+            ops.conv2d_wgrad(xt, dyt, dw, 1, 1, ws, dbias=db)
+            torch.cuda.synchronize()
+            assert_close(dw.cpu(), ref, rtol=3e-4, atol=1e-4, what=f"1x1 wgrad mode {mode} {case}")
+            assert_close(db.cpu(), dy.sum((0, 2, 3)), rtol=3e-4, atol=1e-4, what=f"1x1 dbias mode {mode} {case}")
+            ops.conv2d_wgrad(xt, dyt, dw, 1, 1, ws, accumulate=True)
+            torch.cuda.synchronize()
+            assert_close(dw.cpu(), 2 * ref, rtol=3e-4, atol=2e-4, what=f"1x1 wgrad accumulate mode {mode} {case}")
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 32, 9, 7), (1, 512, 4, 4), (2, 256, 40, 40), (1, 512, 2, 2), (16, 64, 128, 128)])
 def test_batchnorm_train_fwd_bwd(ops, shape):
     N, Cc, H, W = shape

@@ -1436,6 +1436,12 @@ int make_wplan(const unet_wgrad_desc* d, WPlan* p) {
         return UNET_OK;
     }
     p->gemm1x1 = (!p->bf16 && d->ks == 1 && p->tune.wgrad_1x1) ? 1 : 0;
+    // ... except where its 128 x 128 blocks are mostly padding or the whole launch is a few GFLOP: there the 64 x 64-blocked general kernel wins
+    // (scripts/ab_wgrad1x1.py: SelfAttention's 48 x 4096 products 54 -> 39 us, the identity-path convs 64 -> 128 at 64^2 35 -> 25 us,
+    // 256 -> 512 at 16^2 32 -> 24 us; from 4.3 GFLOP up the GEMM kernel is 1.4-1.8 x faster).  unet_tuning.wgrad_1x1 = 2 forces the GEMM kernel.
+    if (p->gemm1x1 && p->tune.wgrad_1x1 != 2 &&
+        ((d->Cin <= 64 || d->Cout <= 64) || 2.0 * d->N * d->OH * d->OW * (double)d->Cin * d->Cout < 3.0e9))
+        p->gemm1x1 = 0;
     if (p->gemm1x1) {       // flat 64-pixel tiles, 128 x 128 channel blocks
         k.kt = unet::cdiv(d->Cout, 128);
         k.ct = unet::cdiv(d->Cin, 128);
