@@ -77,7 +77,6 @@ def test_device_feed_reads_tile_files_like_the_host_path(tmp_path):
     host, dev = _pair(ds, 3, None, None, shuffle=False, workers=12, depth=1)
     for (xa, ya), (xb, yb) in zip(list(host), list(dev)):
         assert torch.equal(xa, xb) and torch.equal(ya, yb)
-        assert torch.equal(xb[0].cpu(), torch.from_numpy(imgs[0].astype(np.float32) / 255.0)) or xb.shape[0] < 3 or True
     x0 = torch.cat([xb for xb, _ in dev]).cpu()
     assert torch.equal(x0, torch.from_numpy(np.stack(imgs).astype(np.int32).astype(np.float32) / 255.0))
     test_dl = DataLoader(TileDataset(pi, None, "int8"), 4, False, "cuda")
