@@ -10,7 +10,7 @@ its large-layer launches: forward and input-gradient of every wide 3x3 layer): s
 events on the launch stream inside the timed region; `roofline.traffic` comes from the committed counter summary it names
 (`traffic_source`, `traffic_code`, `traffic_code_current`).  `cpu_baseline` = the torch-CPU oracle of the same step on this host's cores, on a
 bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`, every entry in its own try: the bf16-storage variant of configs[1]
-(value un-probed, roofline from a second, probed run), predict at batch 16 / 1, configs[0] (cfg1), configs[3] (cfg4: xresnet50 8 -> 10,
+(value un-probed, roofline from a second, probed run), predict at batch 16 / 1, `Learner.predict` per tile, configs[0] (cfg1), configs[3] (cfg4: xresnet50 8 -> 10,
 1024 x 1024, fp32), the step with self-attention on (the reference's shipped default), configs[4] (cfg5: predict.predict_raster over a
 20000 x 20000 raster) in fp32 and bf16 storage, and `fit_files`: Learner.fit_one_cycle over tile FILES through the product loader next to
 the resident-batch rate.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
@@ -243,6 +243,35 @@ def predict_bench(dtype, batch, dev, iters=6):
     torch.cuda.empty_cache()
     return {"value": round(batch / dt, 1), "unit": "tiles/s", "ms_per_batch": round(dt * 1e3, 3), "dtype": dtype, "batch": batch,
             "fwd_tflops": round(batch / dt * GFLOP_PER_TILE_FWD / 1e3, 1)}
+
+
+def learner_predict_bench(dtype, dev, iters=20):
+    """the reference's literal prediction loop (predict.py:191-193: `learn.predict(tile)` per tile): Learner.predict on one uint8 4x512x512
+    tile -- integer upload, scaling on the device, eval forward + softmax + argmax, class probabilities and mask back on the host"""
+    import numpy as np
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    torch.manual_seed(0)
+    m = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=dtype)
+    dls = DataLoaders(TileDataset([np.zeros((N_IN, SIZE, SIZE), np.uint8)], None, "int8"), None, 16, device=dev, vocab=list("abcde"))
+    ln = Learner(dls, m, loss_func=CrossEntropyLossFlat(axis=1))
+    x = np.random.default_rng(0).integers(0, 256, (N_IN, SIZE, SIZE)).astype(np.uint8)
+    for _ in range(3):
+        ln.predict(x)
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = ln.predict(x)
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / iters)
+    dt = sorted(reps)[1]
+    r = {"value": round(1.0 / dt, 1), "unit": "tiles/s", "ms_per_tile": round(dt * 1e3, 3), "dtype": dtype,
+         "returns": [list(out[1].shape), list(out[2].shape)]}
+    del ln, m
+    torch.cuda.empty_cache()
+    return r
 
 
 def cfg5_bench(dtype, dev, side=20000, size=512, overlap=0.2, batch=16):
@@ -538,6 +567,8 @@ def main():
                     lambda: {"f32": predict_bench("f32", 16, dev), "bf16": predict_bench("bf16", 16, dev)})
             guarded("predict_b1", "predict, batch 1",
                     lambda: {"f32": predict_bench("f32", 1, dev, iters=20), "bf16": predict_bench("bf16", 1, dev, iters=20)})
+            guarded("learner_predict", "Learner.predict per tile (the reference's loop, predict.py:191-193)",
+                    lambda: {"f32": learner_predict_bench("f32", dev), "bf16": learner_predict_bench("bf16", dev)})
             guarded("cfg1", "cfg1 (BASELINE configs[0]: xresnet18 3->2, 256x256, batch 2)", cfg1_line)
             guarded("cfg4", "cfg4 (BASELINE configs[3]: xresnet50 8->10, 1024x1024, batch 2, fp32)", cfg4_line)
             guarded("sa_on", "cfg2 with self-attention on (the reference's shipped default), fp32 + bf16",

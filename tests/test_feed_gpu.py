@@ -84,6 +84,24 @@ def test_device_feed_reads_tile_files_like_the_host_path(tmp_path):
     assert all(yb is None for _, yb in out) and torch.equal(torch.cat([xb for xb, _ in out]).cpu(), x0)
 
 
+def test_single_batch_loaders_stage_directly_and_equal_the_host_path():
+    """feed="auto" with ONE batch (Learner.predict on a tile, a tiny validation set): no thread pool, no staging ring -- the integers go up in
+    one copy and the same kernels scale / widen / flip them: bit-equal to the host path, for uint16 data (/ 255 twice), flips, float targets"""
+    from unet_amd.learner import DataLoader, FlipAugment, TileDataset
+    imgs, masks = _tiles(3, 4, (40, 56), np.uint16, 8)
+    for regression in (False, True):
+        mk = [m.astype(np.float32) * 0.37 for m in masks] if regression else masks
+        ds = TileDataset(imgs, mk, "int16", regression=regression)
+        host = DataLoader(ds, 4, False, "cuda", batch_tfm=FlipAugment(n_transform_imgs=0.3, seed=5), feed="host")
+        auto = DataLoader(ds, 4, False, "cuda", batch_tfm=FlipAugment(n_transform_imgs=0.3, seed=5))
+        (xa, ya), = list(host)
+        (xb, yb), = list(auto)
+        assert auto._feeder is None                         # the direct path: no pool was built
+        assert torch.equal(xa, xb) and torch.equal(ya, yb) and yb.dtype == (torch.float32 if regression else torch.int64)
+    x1, y1 = next(iter(DataLoader(TileDataset(imgs[:1], None, "int16"), 16, False, "cuda")))
+    assert y1 is None and torch.equal(x1.cpu(), torch.from_numpy(imgs[0].astype(np.int32).astype(np.float32) / 255.0 / 255.0)[None])
+
+
 def test_regression_targets_and_generic_pipelines_go_through_the_device_feed():
     """float mask tiles (RegressionBlock, data.py:98-99) arrive as float32 targets; a pipeline that is not made of flips only
     (RandomBrightnessContrast) runs as torch ops on the staged batch, with the same draws as on the host path; a flips-only

@@ -359,8 +359,13 @@ class DataLoader:
 
     def __iter__(self):
         batches = self._batches()
-        if self.feed == "device" or (self.feed == "auto" and self.device.type == "cuda"):
+        # "auto": the device feed where there is something to run ahead of -- a loader of ONE batch (Learner.predict on a single tile,
+        # predict.py:193; a tiny validation set) takes the direct path instead of spinning up a thread pool and a pinned staging ring
+        if self.feed == "device" or (self.feed == "auto" and self.device.type == "cuda" and len(batches) > 1):
             yield from self._iter_device(batches)
+            return
+        if self.feed == "auto" and self.device.type == "cuda":
+            yield from self._iter_direct(batches)
             return
         for items in batches:
             items = [self.ds[int(i)] for i in items]
@@ -369,6 +374,35 @@ class DataLoader:
             if self.batch_tfm is not None and yb is not None:
                 xb, yb = self.batch_tfm(xb, yb)
             yield xb, yb
+
+    def _iter_direct(self, batches):
+        """one batch, nothing to run ahead of: the items' INTEGER samples go up in one copy and are scaled / widened / flipped by the same
+        kernels as the device feed (same bits as the host path), without threads or a staging ring"""
+        from .feed import _SAMPLE_TYPES, as_samples
+        has_y = self.ds.masks is not None
+        tfm = self.batch_tfm if has_y else None
+
+        def up(arrs):
+            a = np.ascontiguousarray(np.stack([as_samples(v) for v in arrs]))      # (tiles read as band-interleaved views stack into one C-ordered block)
+            t = torch.from_numpy(a.view(np.int16)).view(torch.uint16) if a.dtype == np.uint16 else torch.from_numpy(a)
+            assert t.dtype == _SAMPLE_TYPES[a.dtype]
+            return t.to(self.device)
+        with torch.cuda.device(self.device):
+            for items in batches:
+                raws = [self.ds.raw(int(i)) for i in items]
+                n = len(raws)
+                flips = tfm.flip_flags(n) if hasattr(tfm, "flip_flags") else None
+                src = up([r[0] for r in raws])
+                xb = torch.empty(src.shape, dtype=torch.float32, device=self.device)
+                ops.tiles_stage(src, self.ds.dtype == "int16", xb, flips)
+                yb = None
+                if has_y:
+                    msk = up([r[1] for r in raws])
+                    yb = torch.empty(msk.shape, dtype=torch.float32 if self.ds.regression else torch.int64, device=self.device)
+                    ops.mask_stage(msk, yb, flips)
+                if tfm is not None and flips is None:
+                    xb, yb = tfm(xb, yb)
+                yield xb, yb
 
     def _iter_device(self, batches):
         from .feed import BatchFeeder
@@ -782,6 +816,20 @@ class Learner:
         return [num / max(den, 1e-30)] + [m.value for m in self.metrics]
 
     # -- inference (predict.py:193)
+    @staticmethod
+    def _to_host(parts: list) -> Optional[torch.Tensor]:
+        """device batches -> ONE host tensor: concatenated on the device, copied into a pinned buffer of torch's caching host allocator
+        (a fresh pageable tensor of a few MB costs several ms of page faults on a memory-capped box: 50 of the 53 ms Learner.predict took
+        per tile before round 5 were such allocations and three pageable copies)"""
+        if not parts:
+            return None
+        t = parts[0] if len(parts) == 1 else torch.cat(parts)
+        if not t.is_cuda:
+            return t
+        out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        out.copy_(t)                      # (blocking on the stream: the tensor is complete when it is handed out)
+        return out
+
     @torch.no_grad()
     def get_preds(self, dl=None, with_input=False, with_decoded=False):
         dl = dl or self.dls.valid
@@ -790,26 +838,28 @@ class Learner:
         for xb, yb in dl:
             if self.regression:
                 vals = self.model.predict_values(xb)      # decoded == preds: no activation (train.py:90-95)
-                ps.append(vals.cpu()); ds.append(vals.cpu())
+                ps.append(vals)
             else:
                 probs, amax = self.model.predict_probs(xb)
-                ps.append(probs.cpu()); ds.append(amax.cpu())
+                ps.append(probs); ds.append(amax)
             if with_input:
-                xs.append(xb.cpu())
+                xs.append(xb)
             if yb is not None:
-                ys.append(yb.cpu())
-        res = (torch.cat(ps), torch.cat(ys) if ys else None)
+                ys.append(yb)
+        preds = self._to_host(ps)
+        res = (preds, self._to_host(ys))
         if with_decoded:
-            res = res + (torch.cat(ds),)
+            res = res + (preds if self.regression else self._to_host(ds),)
         if with_input:
-            res = (torch.cat(xs),) + res
+            res = (self._to_host(xs),) + res
         return res
 
     def predict(self, item, rm_type_tfms=None, with_input=False):
         """(decoded mask, argmax [H,W], per-class probabilities [C,H,W]) for one tile (path or [C,H,W] array); in regression
-        mode the 2-tuple (decoded, preds) of ``Learner_adjust.predict`` (train.py:87-95), both [1,H,W]."""
+        mode the 2-tuple (decoded, preds) of ``Learner_adjust.predict`` (train.py:87-95), both [1,H,W].  The reference's per-tile loop
+        (predict.py:191-193); predict.save_predictions batches 16 tiles instead."""
         dl = self.dls.test_dl([item])
-        _, preds, _, dec = self.get_preds(dl=dl, with_input=True, with_decoded=True)
+        preds, _, dec = self.get_preds(dl=dl, with_decoded=True)
         if self.regression:
             return dec[0], preds[0]
         res = dec[0], dec[0], preds[0]
