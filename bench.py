@@ -12,8 +12,8 @@ events on the launch stream inside the timed region; `roofline.traffic` comes fr
 bounded sample (rank 0, N=1 only).  The N=1 run also carries `secondary`, every entry in its own try: the bf16-storage variant of configs[1]
 (value un-probed, roofline from a second, probed run), predict at batch 16 / 1, `Learner.predict` per tile, configs[0] (cfg1), configs[3] (cfg4: xresnet50 8 -> 10,
 1024 x 1024, fp32), the step with self-attention on (the reference's shipped default), configs[4] (cfg5: predict.predict_raster over a
-20000 x 20000 raster) in fp32 and bf16 storage, and `fit_files`: Learner.fit_one_cycle over tile FILES through the product loader next to
-the resident-batch rate.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
+20000 x 20000 raster) in fp32 and bf16 storage, `predict_files`: predict.save_predictions(merge=True) over 400 tile files, and `fit_files`: Learner.fit_one_cycle over tile FILES
+through the product loader next to the resident-batch rate.  N > 1 runs add cfg5 over all ranks behind a watchdog that prints the headline with the failure
 recorded and exits non-zero.  Every rank reports its own clock and the time its compute stream waited for the gradient all-reduce in `devices`.
 """
 from __future__ import annotations
@@ -391,6 +391,56 @@ def fit_files_bench(dev, log, resident: dict, n_tiles: int = 512, batch: int = 1
     return out
 
 
+def predict_files_bench(dev, log, side: int = 8000):
+    """The reference's prediction entry point on tile FILES (predict.py:146-355): an 8000 x 8000 uint8 scene is cut by
+    create_tiles_unet.split_raster into 400 GeoTIFF tiles of 512 with overlap 0.2, an exported model is loaded by
+    predict.save_predictions(merge=True), which reads, predicts, overlap-merges and writes the mask.  Timed end to end (model load to mask on
+    disk) and inside the engine (first tile read to merged mask), fp32 and bf16 storage; the mask must equal predict_raster's on the scene."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import create_tiles_unet as T
+    import predict as P
+    from unet_amd.learner import CrossEntropyLossFlat, DataLoaders, Learner, TileDataset
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.tiffio import read_tiff, write_tiff
+    root = Path(tempfile.mkdtemp(prefix="unet_predict_files_"))
+    out = {"what": "create_tiles_unet.split_raster -> 400 tile files -> predict.save_predictions(merge=True), end to end incl. load_learner and the "
+                   "mask GeoTIFF; engine = first tile read to merged mask", "raster": [N_IN, side, side], "batch": 16}
+    try:
+        g = np.random.default_rng(0)
+        img = g.integers(1, 256, (N_IN, side, side), dtype=np.uint8)
+        write_tiff(root / "scene.tif", img, geotransform=(400000.0, 0.5, 0.0, 5700000.0, 0.0, -0.5))
+        n = T.split_raster(str(root / "scene.tif"), None, str(root / "cut"), patch_size=SIZE, patch_overlap=0.2, split=[1])["tiles"]
+        tiles_dir = root / "cut" / "img_tiles"
+        for dtype in ("f32", "bf16"):
+            torch.manual_seed(0)
+            model = HipDynamicUnet(ARCH, N_IN, N_CLS, (SIZE, SIZE), device=dev, act_dtype=dtype)
+            dls = DataLoaders(TileDataset([np.zeros((N_IN, SIZE, SIZE), np.uint8)], None, "int8"), None, 1, device=dev, vocab=list("abcde"))
+            pkl = root / f"m_{dtype}.pkl"
+            Learner(dls, model, loss_func=CrossEntropyLossFlat(axis=1), path=root).export(pkl)
+            model.eval()
+            ref = P.predict_raster(model, img, SIZE, 0.2, batch_size=16)
+            del model
+            torch.cuda.empty_cache()
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):          # (save_predictions prints progress lines: the bench prints ONE JSON line)
+                P.save_predictions(str(pkl), str(tiles_dir), False, merge=True, AOI="warm", validation_vision=False, batch_size=16)
+                tm = {}
+                t0 = time.perf_counter()
+                f = P.save_predictions(str(pkl), str(tiles_dir), False, merge=True, AOI=f"timed_{dtype}", validation_vision=False, batch_size=16, timing=tm)
+                dt = time.perf_counter() - t0
+            same = bool(np.array_equal(read_tiff(f)[0], ref))
+            out[dtype] = {"value": round(n / dt, 1), "unit": "tiles/s", "seconds": round(dt, 3), "tiles": n,
+                          "engine_tiles_per_s": round(n / tm["seconds"], 1), "mask_equals_predict_raster": same}
+            log(f"predict_files {dtype}: {n / dt:.1f} tiles/s end to end, engine {n / tm['seconds']:.1f}, mask equal {same}")
+            torch.cuda.empty_cache()
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def cfg5_multi(dtype, dev, rank, world, side=int(os.environ.get("UNET_CFG5_SIDE", "20000")), size=512, overlap=0.2, batch=16):
     """BASELINE configs[4] as worded: the 20000 x 20000 raster predicted by ALL ranks -- predict.predict_raster partitions the windows into
     contiguous row blocks (one per rank), every rank keeps its strip of the mosaic, overlap rows travel as slabs to the neighbouring rank
@@ -575,6 +625,8 @@ def main():
                     lambda: {"f32": sa_line("f32"), "bf16": sa_line("bf16")})
             guarded("cfg5", "cfg5 (BASELINE configs[4]: 20000x20000 sliding-window predict) fp32 + bf16",
                     lambda: {"f32": cfg5_bench("f32", dev), "bf16": cfg5_bench("bf16", dev)})
+            guarded("predict_files", "save_predictions(merge=True) over 400 tile files (split_raster -> files -> merged mask), fp32 + bf16",
+                    lambda: predict_files_bench(dev, log))
             guarded("fit_files", "fit_one_cycle from tile files through the product loader (uncompressed + LZW, fp32 + bf16)",
                     lambda: fit_files_bench(dev, log, {"f32": round(value, 3), "bf16": (sec.get("bf16") or {}).get("value")}))
             out["secondary"] = sec

@@ -407,6 +407,43 @@ class _TilePrefetcher:
         return d
 
 
+class _FeedPrefetcher:
+    """The same interface on the training feed's machinery (unet_amd/feed.py): every pool task reads ONE tile file and copies it straight into
+    its slot of a pinned staging buffer (the producer thread above copies the 16 tiles of a batch one after the other), uploads go out on a
+    copy stream one batch ahead.  For tile sets of one height x width -- what split_raster writes (a tile with other bands or another sample
+    type makes the feeder raise); sets of mixed sizes keep _TilePrefetcher.
+    Yields (first, n, slot); `upload(slot, device)` returns the device buffer [n_pad, C, h, w] (rows beyond n: leftovers of an earlier batch,
+    their windows are dropped); `done(slot)` after the forward that reads it has been issued."""
+
+    def __init__(self, tiles: Sequence[Path], batches: List[Tuple[int, int]], device, depth: int = 3):
+        from unet_amd.feed import BatchFeeder
+        self.tiles, self.batches = tiles, batches
+        self.n_pad = max((n for _, n in batches), default=0)
+        self.feeder = BatchFeeder(lambda i: (_as_samples(open_tile(self.tiles[i])),), self.n_pad, device, depth=depth)
+
+    def __iter__(self):
+        for (first, n), slot in zip(self.batches, self.feeder.run([range(first, first + n) for first, n in self.batches])):
+            yield first, n, slot
+
+    @staticmethod
+    def upload(slot, device) -> torch.Tensor:
+        return slot.dev[0]
+
+    @staticmethod
+    def done(slot):
+        slot.release()
+
+    def close(self):
+        self.feeder.close()
+
+
+def _prefetcher(tiles, batches, sizes, device):
+    """_FeedPrefetcher when every tile has the same height x width, else the general one"""
+    if len(set(sizes)) == 1 and device.type == "cuda":
+        return _FeedPrefetcher(tiles, batches, device)
+    return _TilePrefetcher(tiles, batches)
+
+
 def save_predictions(predict_model, predict_path, regression, merge=False, all_classes=False, specific_class=None, large_file=False,
                      AOI=None, year=None, validation_vision=True, class_zero=False, batch_size=16, timing: Optional[dict] = None,
                      batch_invariant: bool = False):
@@ -452,18 +489,29 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
         order = merge_order(places)
         places, tiles_o = places[order], [tiles[i] for i in order]
         plan = MergePlan(places, MH, MW, world)
-        pf = _TilePrefetcher(tiles_o, plan.batches(rank, batch_size))
+        pf = _prefetcher(tiles_o, plan.batches(rank, batch_size), [(int(p_[2]), int(p_[3])) for p_ in places], dev)
         feed = iter(pf)
         ztab = ops.window_table([[0, 0, j, 0] for j in range(batch_size)], dev)
+        held = []          # staging slot of the batch in flight: released once the NEXT batch is asked for (its gather has been issued by then)
 
         def make_input(first, n, n_pad):
+            while held:
+                pf.done(held.pop())
             f, nn, buf = next(feed)
-            assert (f, nn) == (first, n) and buf.shape[0] == n_pad, ((f, nn, buf.shape[0]), (first, n, n_pad))
-            return ops.WindowBatch(ops.WindowSource(pf.upload(buf, dev), div255_twice=div2), ztab, 0, n_pad, buf.shape[2], buf.shape[3])
+            d = pf.upload(buf, dev)
+            assert (f, nn) == (first, n) and d.shape[0] == n_pad, ((f, nn, d.shape[0]), (first, n, n_pad))
+            if hasattr(pf, "done"):
+                held.append(buf)
+            return ops.WindowBatch(ops.WindowSource(d, div255_twice=div2), ztab, 0, n_pad, d.shape[2], d.shape[3])
 
         want = _want(regression, all_classes, specific_class)
-        with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):          # (see predict_raster)
-            out = _run_merge(model, places, MH, MW, regression, int8_merge, rank, world, batch_size, make_input, want, timing)
+        try:
+            with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):          # (see predict_raster)
+                out = _run_merge(model, places, MH, MW, regression, int8_merge, rank, world, batch_size, make_input, want, timing)
+        finally:
+            feed.close()
+            if hasattr(pf, "close"):
+                pf.close()              # (the decode pool and its pinned ring live for one call)
         if timing is not None:
             timing["tiles_per_s_end_to_end"] = len(tiles) / (time.perf_counter() - t_start)
         if rank != 0:
@@ -485,12 +533,15 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
         batches.append((i, n))
         i += n
     mtiles = [tiles[i] for i in mine]
-    pf = _TilePrefetcher(mtiles, batches)
+    pf = _prefetcher(mtiles, batches, sizes, dev)
     ztab = ops.window_table([[0, 0, j, 0] for j in range(batch_size)], dev)
     for first, n, buf in pf:
-        wb = ops.WindowBatch(ops.WindowSource(pf.upload(buf, dev), div255_twice=div2), ztab, 0, buf.shape[0], buf.shape[2], buf.shape[3])
+        d = pf.upload(buf, dev)
+        wb = ops.WindowBatch(ops.WindowSource(d, div255_twice=div2), ztab, 0, d.shape[0], d.shape[2], d.shape[3])
         with (ops.tuning(plan_batch=1) if batch_invariant else contextlib.nullcontext()):
             z = model.forward_windows(wb)
+        if hasattr(pf, "done"):
+            pf.done(buf)               # (the gather that reads the staging buffer has been issued)
         zs = ops.TS(z.buf[:n], z.co, z.C)
         if regression:       # predict.py:195-197: tile_preds[1] = raw outputs [1,H,W]
             probs, amax = torch.empty((n, C, z.H, z.W), dtype=torch.float32, device=dev), None
@@ -514,6 +565,8 @@ def save_predictions(predict_model, predict_path, regression, merge=False, all_c
                 out = np.around(out * LARGE_FILE_SCALE).astype(np.int8)
             name = t.name if t.suffix != ".npy" else t.stem + ".tif"
             store_tif(output_folder / name, out, gt, tags, None, class_zero)
+    if hasattr(pf, "close"):
+        pf.close()
     if validation_vision:
         pass  # per-tile majority-class confusion plots (predict.py:56-143) are reporting, out of scope
     if world > 1:

@@ -993,9 +993,11 @@ def load_learner(fname, device="cuda", act_dtype: Optional[str] = None) -> Learn
     sa = meta.get("self_attention")
     if sa is None:
         sa = any(".query." in k for k in d["model"])
-    model = HipDynamicUnet(meta["arch"], meta["n_in"], meta["n_out"], tuple(meta["img_size"]), self_attention=bool(sa), device=device,
-                           act_dtype=act_dtype or meta.get("act_dtype", "f32"))
-    model.load_state_dict(d["model"])
+    from .model import skip_weight_init
+    with skip_weight_init():          # every parameter and buffer comes from the file (strict load below)
+        model = HipDynamicUnet(meta["arch"], meta["n_in"], meta["n_out"], tuple(meta["img_size"]), self_attention=bool(sa), device=device,
+                               act_dtype=act_dtype or meta.get("act_dtype", "f32"))
+    model.load_state_dict(d["model"], strict=True)
     empty = TileDataset([], None, meta.get("dtype", "int8"))
     dls = DataLoaders(empty, None, 1, device=device, vocab=meta.get("vocab"))
     w = meta.get("class_weights")

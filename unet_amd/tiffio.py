@@ -157,8 +157,12 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     an uncompressed native-endian file with contiguous strips comes back as a VIEW of the mapping (no copy at all: the training feed's one
     copy is the one into its pinned staging buffer); everything else is decoded strip by strip into one output array."""
     import mmap
+    import os
     with open(path, "rb") as f:
-        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)
+        if os.environ.get("UNET_TIFF_MMAP", "1") == "0":      # (A/B switch: read the file instead of mapping it)
+            mm = bytearray(f.read())
+        else:
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)
     b = np.frombuffer(mm, dtype=np.uint8)           # (keeps the mapping alive for as long as a view of it exists)
     tags, bo = _parse_tags(mm, path)
     W, H = tags[256][0], tags[257][0]
