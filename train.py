@@ -41,9 +41,17 @@ def get_datatype(data_path: Path) -> str:
 
 def get_class_weights(ds: TileDataset, n_cls: int, max_tiles: int = 1200) -> np.ndarray:
     """utils.py:106-117: total / count per class over (up to 1200) training masks."""
+    # only the MASK tiles are opened (ds[i] would also read and scale the image: 5 MB of float work per tile for nothing), by a few threads
+    from concurrent.futures import ThreadPoolExecutor
+
+    def count(i):
+        mk = ds.masks[i]
+        y = np.asarray(mk if isinstance(mk, np.ndarray) else open_tile(mk)[0]).astype(np.int64).ravel()
+        return np.bincount(y, minlength=n_cls)[:n_cls]
     cnt = np.zeros(n_cls, dtype=np.float64)
-    for i in range(min(len(ds), max_tiles)):
-        cnt += np.bincount(ds[i][1].numpy().ravel(), minlength=n_cls)[:n_cls]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for c in ex.map(count, range(min(len(ds), max_tiles))):
+            cnt += c
     return cnt.sum() / np.maximum(cnt, 1)
 
 
