@@ -167,7 +167,20 @@ def _ce_worker(rank, world, port, q):
     l0 = O.CrossEntropyLossFlat(weight=w0.cpu().double())(torch.cat(zs0).cpu().double(), torch.cat(ys0).cpu())
     ok_zero = bool(torch.isfinite(loss0).all().item()) and abs(loss0.item() - l0.item()) <= 2e-6 * abs(l0.item())
     ok_zero = ok_zero and bool(torch.isfinite(model.flat_grad).all().item())
-    q.put((rank, bool(ok_loss), bool(ok_dz), bool(ok_dice and ok_zero)))
+    # FocalLossFlat over the ranks (params_and_main.py:87-89): a plain mean over equally many pixels per rank -- loss averaged over the ranks,
+    # every rank's logit gradient that of ONE focal loss over the global batch
+    lossf = model.forward_loss_backward(x, y, w, world=world, focal_gamma=2.0)
+    torch.cuda.synchronize()
+    zf = model.logits_ts().view().permute(0, 3, 1, 2).contiguous()
+    dzf = model.ctx.act(model, "dlogits", 2, 64, 64, 5, zero=True).view().permute(0, 3, 1, 2).contiguous()
+    zsf = [torch.empty_like(zf) for _ in range(world)]
+    dist.all_gather(zsf, zf)
+    zcf = torch.cat(zsf).cpu().double().requires_grad_(True)
+    lf_ref = O.FocalLossFlat(gamma=2.0, weight=w.cpu().double())(zcf, torch.cat(ys).cpu())
+    lf_ref.backward()
+    ok_focal = abs(lossf.item() - lf_ref.item()) <= 2e-6 * abs(lf_ref.item())
+    ok_focal = ok_focal and (dzf.cpu().double() - zcf.grad[2 * rank:2 * rank + 2]).abs().max().item() <= 2e-6 * zcf.grad.abs().max().item()
+    q.put((rank, bool(ok_loss), bool(ok_dz), bool(ok_dice and ok_zero and ok_focal)))
     dist.destroy_process_group()
 
 

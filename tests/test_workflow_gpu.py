@@ -62,6 +62,21 @@ def test_train_export_predict_merge(tmp_path):
     assert np.array_equal((acc / cnt).argmax(0).astype(np.uint8), mm)
     # non-overlapped columns of the merge equal the per-tile masks
     assert np.array_equal(mm[:, :32], m0[:, :32])
+    # tiles of MIXED sizes in one folder (per-tile outputs): the feeder-backed prefetcher needs one shape, such a set keeps the general one;
+    # every tile's mask equals the mask of the tile predicted alone
+    mixed = tmp_path / "pred" / "mixed"
+    mixed.mkdir()
+    shapes = [(64, 64), (64, 64), (96, 64), (64, 64), (96, 64)]
+    for i, (h, w) in enumerate(shapes):
+        write_tiff(mixed / f"q{i}.tif", g.integers(0, 255, (4, h, w)).astype(np.uint8), geotransform=(3000.0 + 100 * i, 0.5, 0.0, 2000.0, 0.0, -0.5))
+    assert isinstance(P._prefetcher([mixed / f"q{i}.tif" for i in range(5)], [(0, 2), (2, 1)], shapes[:3], torch.device("cuda")), P._TilePrefetcher)
+    assert isinstance(P._prefetcher([mixed / f"q{i}.tif" for i in range(2)], [(0, 2)], shapes[:2], torch.device("cuda")), P._FeedPrefetcher)
+    out_mixed = P.save_predictions(pkl, mixed, False, merge=False, validation_vision=False, batch_size=2)
+    for i, (h, w) in enumerate(shapes):
+        mi, _ = read_tiff(out_mixed / f"q{i}.tif")
+        assert mi.shape == (h, w)
+        dec, _, _ = lr.predict(mixed / f"q{i}.tif")
+        assert np.array_equal(mi, dec.numpy().astype(np.uint8)), i
 
 
 def _make_regression_dataset(root, n_train=6, n_val=2, size=64, seed=0):
