@@ -81,6 +81,8 @@ typedef struct {
     int wgrad_wgs;          /* workgroups a weight-gradient launch is split into (split-K over pixel tiles).  0 (default): ~512 (two per CU); bf16
                                storage, 3x3 layers up to ~175 GFLOP: ~256 (one per CU: half the partial filter images to write and read back,
                                measured faster).  n > 0: ~n workgroups (A/B) */
+    int conv_smallcin;      /* 1 (default): forward 3x3 convs of <= 8 input channels (the stem's first conv) on the direct HBM-bound kernel; 0: the
+                               implicit-GEMM kernels (A/B, cross-check) */
 } unet_tuning;
 void unet_tuning_default(unet_tuning* t);
 

@@ -14,6 +14,6 @@ if which == "cfg1":
     for _ in range(20): st(x, y)
 else:
     m = HipDynamicUnet("xresnet34", 4, 5, (512, 512), act_dtype=os.environ.get("UNET_DTYPE", "f32")); m.eval()
-    x = torch.rand(1, 4, 512, 512, device="cuda")
+    x = torch.rand(16 if which == "b16" else 1, 4, 512, 512, device="cuda")
     for _ in range(20): m.predict_probs(x)
 torch.cuda.synchronize()

@@ -322,6 +322,42 @@ def test_conv1x1_small_reduction_kernel_bf16(K, Cout):
     assert (_back(yt).double() - ref2).abs().max().item() <= 2.0 ** -8 * ref2.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 4, 32, 2), (1, 37, 29, 3, 32, 2), (2, 18, 22, 7, 24, 1), (1, 33, 31, 8, 32, 1), (5, 512, 512, 4, 32, 2)])
+def test_conv3x3_small_cin_kernel_bf16(case):
+    """conv3x3_smallcin_kernel with bf16 storage (variant id 10; the stem's first conv): exact products, fp32 accumulation, one rounding of
+    the output; and the implicit-GEMM kernel on the same operands (unet_tuning.conv_smallcin = 0) within two output roundings"""
+    from unet_amd import ops
+    N, H, W, Cin, Cout, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), _bf(w).double(), b.double(), stride=stride, padding=1))
+    OH, OW = ref.shape[2:]
+    xt = _ts(x, cs=24, co=8)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    outs = []
+    big = N * OH * OW >= 1 << 18
+    if not big:                       # bf16 takes the kernel from 2^18 output pixels on (a single tile is faster on MFMA) ...
+        yt = _empty(N, OH, OW, Cout, cs=Cout + 24, co=16)
+        assert ops.conv2d_variant(xt, wp, yt, 3, stride) != 10
+    else:                             # ... counted with the PLANNED batch: a batch-invariant plan (plan_batch = 1) never takes it
+        with _knobs.tuning(plan_batch=1):
+            assert ops.conv2d_variant(xt, wp, _empty(N, OH, OW, Cout), 3, stride) != 10
+    for on in (1, 0):
+        with _knobs.tuning(conv_smallcin=on, plan_batch=0 if big else 4096):
+            yt = _empty(N, OH, OW, Cout, cs=Cout + 24, co=16)
+            assert (ops.conv2d_variant(xt, wp, yt, 3, stride) == 10) == bool(on)
+            ops.conv2d(xt, wp, yt, 3, stride, bias=b.cuda(), relu=True)
+            torch.cuda.synchronize()
+        full = yt.buf.float().cpu()
+        assert bool((full[..., :16] == 7.25).all()) and bool((full[..., 16 + Cout:] == 7.25).all()), "wrote outside the slice"
+        outs.append(_back(yt).double())
+    scale = ref.abs().max().item()
+    assert (outs[0] - ref).abs().max().item() <= 2.0 ** -8 * scale + 1e-6
+    assert (outs[0] - outs[1]).abs().max().item() <= 2.0 ** -7 * scale + 1e-6
+
+
 def test_conv_epilogue_slices_residual_relu_mask_bf16():
     """channel-sliced operands (concat elimination), bias + residual + ReLU forward epilogue, residual + ReLU-mask dgrad epilogue"""
     from unet_amd import ops

@@ -284,6 +284,47 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, stride: conv3x3_smallcin_kernel (variant id 10) -- the stem's first conv and its neighbours
+    (2, 64, 64, 4, 32, 2),      # the headline stem conv0 (RGBI tile)
+    (1, 37, 29, 3, 32, 2),      # RGB, odd image edges (stride-2 output ceil(H / 2))
+    (2, 18, 22, 7, 24, 1),      # stride 1, two input vectors, 24 outputs = 3 groups of 8 (85 pixels per block, last lane idle)
+    (1, 33, 31, 8, 32, 1),      # widest form: 8 inputs (two vectors), 32 outputs
+    (2, 512, 512, 4, 32, 2),    # two headline tiles: the four-pixels-per-thread form (>= 1024 workgroups), ragged last workgroup never
+    (3, 16, 16, 1, 20, 2),      # one band; 20 outputs: the last group stores its lower 4 channels only
+])
+def test_conv3x3_small_cin_kernel(ops, case):
+    """the direct 3x3 kernel for <= 8 input channels: bias + ReLU into a channel slice, against torch on the CPU and against the
+    implicit-GEMM kernel on the same operands (unet_tuning.conv_smallcin = 0)"""
+    N, H, W, Cin, Cout, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=stride, padding=1))
+    OH, OW = ref.shape[2:]
+    xt = to_ts(x, cs=ops.rup4(Cin) + 8, co=4)
+    wp = ops.pack_weights(w.cuda(), 0)
+    outs = []
+    for on in (1, 0):
+        with _knobs.tuning(conv_smallcin=on):
+            yt = empty_ts(N, OH, OW, Cout, cs=ops.rup4(Cout) + 12, co=8)
+            assert (ops.conv2d_variant(xt, wp, yt, 3, stride) == 10) == bool(on)
+            ops.conv2d(xt, wp, yt, 3, stride, bias=b.cuda(), relu=True)
+            torch.cuda.synchronize()
+        assert outside_untouched(yt)
+        outs.append(from_ts(yt))
+    assert_close(outs[0], ref, rtol=1e-5, what=f"small-Cin 3x3 {case}")
+    assert_close(outs[0], outs[1], rtol=2e-4, what=f"small-Cin 3x3 vs implicit GEMM {case}")
+    # launches it must leave alone: a residual, column sums (BatchNorm statistics fused into the producer)
+    yt = empty_ts(N, OH, OW, Cout)
+    d = ops._conv_desc(xt, wp, yt, 3, stride, 0, None, to_ts(ref), None, False, None, None)
+    from unet_amd._lib import lib
+    import ctypes
+    assert int(lib.unet_conv2d_variant(ctypes.byref(d))) != 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
     # (Cin, Cout, H, W, N): the 256-pixel tile in its fp32 form (conv_bf16_t256_kernel<.., float>): no reduction tail, no 4-channel sliver
     (96, 96, 250, 270, 2),      # 6 channel tiles, ragged image edges
     (32, 128, 256, 256, 2),     # 8 tiles, two chunks

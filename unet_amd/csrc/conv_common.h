@@ -480,5 +480,8 @@ int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st);
 int conv_gemm1x1_ps_check(const unet_conv_desc* d);      // validation of a unet_conv_desc.pixel_shuffle descriptor (UNET_OK: conv_gemm1x1 takes it)
 bool conv_smallk_applies(const unet_conv_desc* d);
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
+// 3x3 forward convolutions of at most 8 input channels (the stem's first conv; conv_igemm.hip: conv3x3_smallcin_kernel), both storage types
+bool conv_smallcin_applies(const unet_conv_desc* d);
+int conv_smallcin_bf16(const unet_conv_desc* d, hipStream_t st);
 
 }  // namespace unetconv

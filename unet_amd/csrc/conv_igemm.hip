@@ -738,6 +738,7 @@ const unet_tuning& tuning_defaults() {
         v.wgrad_narrow = 1;
         v.plan_batch = 0;
         v.wgrad_wgs = env_int("UNET_WGRAD_WGS", 0);
+        v.conv_smallcin = env_int("UNET_CONV_SMALLCIN", 1);
         return v;
     }();
     return t;
@@ -834,6 +835,7 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     int rc = make_plan_ws(d, &p);
     if (rc != UNET_OK) return rc;
     if (unetconv::conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
+    if (unetconv::conv_smallcin_applies(d)) return 10;       // conv3x3_smallcin_kernel
     if (unetconv::conv_gemm1x1_applies(d)) return 8;         // conv1x1_gemm_kernel
     const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
     return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? (large ? 7 : 6) : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
@@ -1025,11 +1027,181 @@ int launch_smallk(const unet_conv_desc* d, hipStream_t st) {
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
+
+// ---- 3x3 convolution with at most 8 INPUT channels: the stem's first conv (train.py:131-135: Conv2d(n_in, 32, 3, stride 2) on the 3 / 4 / 8-band
+// tile) -- SURVEY 8a row A1: "conv0 is HBM-bound (C_in 4)".  On the MFMA kernels its 36-wide reduction pads to nine taps x a 16- / 32-channel
+// chunk (4 x / 8 x the products) in front of small 32-pixel tiles: 0.51 ms fp32 / 0.28 ms bf16 at 16 x 512^2 for 0.4 / 0.13 GB of traffic
+// (profiles/r05_z: 0.5-0.8 TB/s).  Here it is what it is, an HBM-bound stencil: a thread owns one output pixel x 8 output channels, reads the
+// nine input pixels as 16-byte vectors (zero outside the image), takes the filter from an fp32 LDS copy [tap][cin][cout] of the SAME packed
+// image the MFMA kernels read (BatchNorm fold included) and accumulates in ascending (tap, channel) order; consecutive threads own consecutive
+// channel groups of one pixel (one coalesced row per pixel).
+template <typename T> struct SmallCin;
+template <> struct SmallCin<float> {
+    static constexpr int VEC = 4;
+    // fp32 image, one (tail) chunk, channel-transposed: [tap][outPad][16], position (r >> 2) + 4 (r & 3) holds reduction channel r
+    __device__ static float w(const float* wp, int outPad, int tap, int o, int r) { return wp[((size_t)tap * outPad + o) * 16 + (r >> 2) + 4 * (r & 3)]; }
+};
+template <> struct SmallCin<unsigned short> {
+    static constexpr int VEC = 8;
+    // bf16 image, one chunk: [tap][outPad][32] (the folded-tail slabs behind it are not read)
+    __device__ static float w(const unsigned short* wp, int outPad, int tap, int o, int r) { return __uint_as_float((unsigned)wp[((size_t)tap * outPad + o) * 32 + r] << 16); }
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T, int PX, int NX>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const T* __restrict__ x, int x_cs, int x_co, const T* __restrict__ wp, int Cin, int outPad,
+                                                               const float* __restrict__ bias, T* __restrict__ y, int y_cs, int y_co, int IH, int IW,
+                                                               int OH, int OW, int stride, long long P, int Cout, int groups, int relu) {
+    // PX pixels per thread, 64 / groups apart... (ppb apart): every filter value read from LDS feeds PX FMAs -- at one pixel per thread the
+    // two 16-byte LDS reads per 8 FMAs bound the kernel (LDS 128 B / clk / CU), at four the VALU does.
+    constexpr int VEC = SmallK<T>::VEC;                        // NX 16-byte input vectors per pixel (fp32 with 5..8 input channels: two)
+    __shared__ float wl[9 * 8 * 64];                           // [tap][cin][cout padded to groups * 8]
+    const int cp = groups * 8;
+    for (int i = threadIdx.x; i < 9 * 8 * cp; i += 256) {
+        const int o = i % cp, r = (i / cp) & 7, t = i / (8 * cp);
+        wl[i] = (r < Cin && o < Cout) ? SmallCin<T>::w(wp, outPad, t, o, r) : 0.f;
+    }
+    __syncthreads();
+    const int ppb = 256 / groups;
+    const int pl = (int)threadIdx.x / groups, gi = (int)threadIdx.x - pl * groups;
+    if (pl >= ppb) return;
+    // fp32: a thread owns channels [4 gi, 4 gi + 4) and [4 groups + 4 gi, ...): each of its two 16-byte stores continues its neighbour's
+    const int c0 = VEC == 8 ? gi * 8 : gi * 4, c1 = VEC == 8 ? gi * 8 + 4 : groups * 4 + gi * 4;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bv[j] = (bias != nullptr && c0 + j < Cout) ? bias[c0 + j] : 0.f;
+        bv[4 + j] = (bias != nullptr && c1 + j < Cout) ? bias[c1 + j] : 0.f;
+    }
+    // 32-bit pixel arithmetic (the launcher checks the sizes): 64-bit divisions cost more instructions than the nine taps
+    for (unsigned pb = blockIdx.x * (unsigned)(ppb * PX); pb < (unsigned)P; pb += gridDim.x * (unsigned)(ppb * PX)) {
+        f32x2 o[PX][4];
+        const T* xp[PX];
+        int iy0[PX], ix0[PX];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            unsigned p = pb + (unsigned)(q * ppb + pl);
+            if (p >= (unsigned)P) p = (unsigned)P - 1;         // computed, not stored
+            const unsigned row = p / (unsigned)OW, img = row / (unsigned)OH;
+            const int ox = (int)(p - row * (unsigned)OW), oy = (int)(row - img * (unsigned)OH);
+            iy0[q] = oy * stride - 1;
+            ix0[q] = ox * stride - 1;
+            xp[q] = x + (size_t)img * IH * IW * x_cs + x_co + (iy0[q] * IW + ix0[q]) * x_cs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[q][j] = f32x2{0.f, 0.f};
+        }
+        // one tap at a time, the next tap's pixels in flight while this one is multiplied (a fully unrolled tap loop keeps 9 x PX vectors and
+        // 72 filter vectors live: 256 VGPRs, one wave per SIMD)
+        float cur[PX][NX * VEC], nxt[PX][NX * VEC];
+        auto load = [&](int t, float (&d)[PX][NX * VEC]) {
+            const int ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+                const bool in = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+#pragma unroll
+                for (int h = 0; h < NX; ++h) {
+                    float v[VEC];
+                    SmallK<T>::ld(in ? xp[q] + (ky * IW + kx) * x_cs + h * VEC : x + x_co, v);      // branch-free: a padding tap reads pixel 0 and drops it
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) d[q][h * VEC + j] = in ? v[j] : 0.f;
+                }
+            }
+        };
+        load(0, cur);
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            if (t < 8) load(t + 1, nxt);
+            const float* wt = wl + t * 8 * cp;
+#pragma unroll
+            for (int r = 0; r < NX * VEC; ++r) {
+                if (r < Cin) {
+                    // v_pk_fma_f32: two channels per lane and instruction (each half is the same fused multiply-add the scalar form does)
+                    const f32x2 wa = *reinterpret_cast<const f32x2*>(wt + r * cp + c0), wb = *reinterpret_cast<const f32x2*>(wt + r * cp + c0 + 2);
+                    const f32x2 wc = *reinterpret_cast<const f32x2*>(wt + r * cp + c1), wd = *reinterpret_cast<const f32x2*>(wt + r * cp + c1 + 2);
+#pragma unroll
+                    for (int q = 0; q < PX; ++q) {
+                        const f32x2 a = {cur[q][r], cur[q][r]};
+                        o[q][0] = __builtin_elementwise_fma(a, wa, o[q][0]);
+                        o[q][1] = __builtin_elementwise_fma(a, wb, o[q][1]);
+                        o[q][2] = __builtin_elementwise_fma(a, wc, o[q][2]);
+                        o[q][3] = __builtin_elementwise_fma(a, wd, o[q][3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PX; ++q)
+#pragma unroll
+                for (int r = 0; r < NX * VEC; ++r) cur[q][r] = nxt[q][r];
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const unsigned p = pb + (unsigned)(q * ppb + pl);
+            if (p >= (unsigned)P) break;
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                e[j] = o[q][j >> 1][j & 1] + bv[j];
+                if (relu) e[j] = fmaxf(e[j], 0.f);
+                if ((j < 4 ? c0 + j : c1 + j - 4) >= Cout) e[j] = 0.f;
+            }
+            T* yo = y + (size_t)p * y_cs + y_co;
+            if constexpr (VEC == 8) SmallK<T>::st(yo + c0, e);
+            else {
+                const float lo[4] = {e[0], e[1], e[2], e[3]}, hi[4] = {e[4], e[5], e[6], e[7]};
+                if (c0 < Cout) SmallK<T>::st(yo + c0, lo);
+                if (c1 < Cout) SmallK<T>::st(yo + c1, hi);
+            }
+        }
+    }
+}
+
+// the launches it takes: a plain forward 3x3 conv (stride 1 | 2, padding 1) of <= 8 input channels held in ONE chunk of the packed image,
+// 16..32 output channels in whole vectors, no residual / mask / column sums / channel range.  Measured alone at 16 x 4 x 512^2 -> 32, stride 2
+// (scripts/ab_conv_smallcin.py): fp32 86 us against 271 us on conv_igemm16_kernel (bit-identical results: the same ascending (tap, channel)
+// chain of fused multiply-adds per output), bf16 93 against 180 us.  64 outputs lose to the MFMA kernels (8 -> 64: 273 / 219 us against
+// 150 / 55 us), and so does a single bf16 tile (17 against 13 us): bf16 launches below 2^18 output pixels stay where they were -- counted with
+// unet_tuning.plan_batch when that is set, so that a batch-invariant plan picks ONE kernel for every batch size.
+bool smallcin_applies(const unet_conv_desc* d) {
+    const int vec = d->dtype == UNET_BF16 ? 8 : 4;
+    const int plan_n = unetconv::tuning_of(d->tuning).plan_batch > 0 ? unetconv::tuning_of(d->tuning).plan_batch : d->N;
+    return d->ks == 3 && (d->stride == 1 || d->stride == 2) && d->kind == UNET_CONV_FWD && d->Cin <= 8 && d->Cout >= 16 && d->Cout <= 32 &&
+           d->Cout % vec == 0 && d->res == nullptr && !(d->flags & UNET_CONV_MASK) && d->colsum == nullptr && d->colsumsq == nullptr &&
+           d->cout_begin == 0 && (d->cout_count == 0 || d->cout_count == d->Cout) && d->wp_img_stride == 0 && !d->pixel_shuffle &&
+           !(d->dtype == UNET_BF16 && d->y_f32) && d->Cout <= d->y_cs - d->y_co && unet::roundup(d->Cin, vec) <= d->x_cs - d->x_co &&
+           (d->dtype != UNET_BF16 || (long long)plan_n * d->OH * d->OW >= (1ll << 18)) &&
+           (long long)d->N * d->OH * d->OW < (1ll << 31) - 256 * 12 * 1024 && (long long)d->IH * d->IW * d->x_cs < (1ll << 31);
+}
+
+template <typename T, int PX>
+int launch_smallcin_px(const unet_conv_desc* d, hipStream_t st) {
+    const long long P = (long long)d->N * d->OH * d->OW;
+    const int groups = unet::cdiv(d->Cout, 8), ppb = 256 / groups * PX;
+    long long blocks = (P + ppb - 1) / ppb;
+    if (blocks > 256 * 12) blocks = 256 * 12;
+    auto kern = conv3x3_smallcin_kernel<T, PX, 1>;
+    if (d->Cin > SmallK<T>::VEC) kern = conv3x3_smallcin_kernel<T, PX, 8 / SmallK<T>::VEC>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)d->x, d->x_cs, d->x_co, (const T*)d->wp, d->Cin,
+                       unet::roundup(d->Cout, 128), d->bias, (T*)d->y, d->y_cs, d->y_co, d->IH, d->IW, d->OH, d->OW, d->stride, P, d->Cout, groups,
+                       (d->flags & UNET_CONV_RELU) ? 1 : 0);
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+// four pixels per thread once that still leaves >= 4 workgroups per CU, else one (a single 512^2 tile: 256 workgroups instead of 64)
+template <typename T>
+int launch_smallcin(const unet_conv_desc* d, hipStream_t st) {
+    const long long P = (long long)d->N * d->OH * d->OW;
+    const int ppb4 = 256 / unet::cdiv(d->Cout, 8) * 4;
+    return (P + ppb4 - 1) / ppb4 >= 1024 ? launch_smallcin_px<T, 4>(d, st) : launch_smallcin_px<T, 1>(d, st);
+}
 }  // namespace
 
 namespace unetconv {
 bool conv_smallk_applies(const unet_conv_desc* d) { return smallk_applies(d); }
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st) { return launch_smallk<unsigned short>(d, st); }
+bool conv_smallcin_applies(const unet_conv_desc* d) { return tuning_of(d->tuning).conv_smallcin != 0 && smallcin_applies(d); }
+int conv_smallcin_bf16(const unet_conv_desc* d, hipStream_t st) { return launch_smallcin<unsigned short>(d, st); }
 }
 
 // plan with split-K when the caller brought a workspace for it, else the plain plan
@@ -1052,6 +1224,7 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     if (rc != UNET_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (smallk_applies(d)) return launch_smallk<float>(d, st);
+    if (unetconv::conv_smallcin_applies(d)) return launch_smallcin<float>(d, st);
     if (unetconv::conv_gemm1x1_applies(d)) return unetconv::conv_gemm1x1(d, st);
     if (p.hit == 6) rc = unetconv::conv2d_t256_f32(p, st);          // the 256-pixel tile (conv_bf16.hip: conv_bf16_t256_kernel<.., float>)
     else rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
