@@ -83,6 +83,8 @@ typedef struct {
                                measured faster).  n > 0: ~n workgroups (A/B) */
     int conv_smallcin;      /* 1 (default): forward 3x3 convs of <= 8 input channels (the stem's first conv) on the direct HBM-bound kernel; 0: the
                                implicit-GEMM kernels (A/B, cross-check) */
+    int conv_head1x1;       /* 1 (default): 1x1 forward convs with <= 16 produced channels (the segmentation head) on the streaming kernel that keeps
+                               the filter in registers; 0: the implicit-GEMM kernels (A/B, cross-check: same bits); 2: the other pixel-tile count per trip (A/B) */
 } unet_tuning;
 void unet_tuning_default(unet_tuning* t);
 

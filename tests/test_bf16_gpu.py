@@ -322,6 +322,36 @@ def test_conv1x1_small_reduction_kernel_bf16(K, Cout):
     assert (_back(yt).double() - ref2).abs().max().item() <= 2.0 ** -8 * ref2.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("case", [(2, 37, 29, 100, 5), (1, 64, 64, 96, 2), (2, 16, 16, 128, 16), (1, 20, 20, 36, 3), (3, 5, 5, 9, 7)])
+@pytest.mark.parametrize("f32_out", [True, False])
+def test_conv1x1_head_kernel_bf16(case, f32_out):
+    """conv1x1_head_kernel with bf16 storage (variant id 11): fp32 logits (the head's own form: unet_conv_desc.y_f32) and bf16 output; exact
+    products, fp32 accumulation; the same bits as the implicit-GEMM kernel (unet_tuning.conv_head1x1 = 0)"""
+    from unet_amd import ops
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), _bf(w).double(), b.double())
+    xt = _ts(x, cs=ops.rupv(Cin, torch.bfloat16) + 16, co=8)
+    wp = ops.pack_weights(w.cuda(), 0, dtype=torch.bfloat16)
+    odt = torch.float32 if f32_out else torch.bfloat16
+    outs = []
+    for on in (1, 2, 0):                      # 2: the other pixel-tile count per trip
+        with _knobs.tuning(conv_head1x1=on, conv_splitk=0):       # (a split reduction is another chain: the planner cuts 128 channels on a small grid)
+            yt = _empty(N, H, W, Cout, cs=ops.rupv(Cout, odt) + 16, co=8, dtype=odt)
+            assert (ops.conv2d_variant(xt, wp, yt, 1, 1) == 11) == bool(on)
+            ops.conv2d(xt, wp, yt, 1, 1, bias=b.cuda())
+            torch.cuda.synchronize()
+        full = yt.buf.float().cpu()
+        assert bool((full[..., :8] == 7.25).all()) and bool((full[..., 8 + ops.rupv(Cout, odt):] == 7.25).all()), "wrote outside the slice"
+        outs.append(_back(yt).double())
+    scale = ref.abs().max().item()
+    assert (outs[0] - ref).abs().max().item() <= (1e-5 if f32_out else 2.0 ** -8) * scale + 1e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "not the bits of the implicit-GEMM kernel"
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 4, 32, 2), (1, 37, 29, 3, 32, 2), (2, 18, 22, 7, 24, 1), (1, 33, 31, 8, 32, 1), (5, 512, 512, 4, 32, 2)])
 def test_conv3x3_small_cin_kernel_bf16(case):
     """conv3x3_smallcin_kernel with bf16 storage (variant id 10; the stem's first conv): exact products, fp32 accumulation, one rounding of

@@ -284,6 +284,42 @@ def test_conv1x1_small_reduction_kernel(ops, K, Cout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout: conv1x1_head_kernel (variant id 11) -- the segmentation head and its neighbours
+    (2, 37, 29, 100, 5),        # the headline head: six full chunks + a tail of 4 (ONE transposed MFMA step), ragged last wave
+    (1, 64, 64, 96, 2),         # BASELINE configs[0]'s two classes, whole chunks only
+    (2, 16, 16, 128, 16),       # the widest form
+    (1, 20, 20, 36, 3),         # tail of 4 behind two chunks
+    (1, 9, 7, 22, 1),           # regression head (one output), tail of 6: two transposed steps
+    (3, 5, 5, 9, 7),            # narrowest reduction the kernel takes: a tail only (three steps)
+])
+def test_conv1x1_head_kernel(ops, case):
+    """the streaming 1x1 kernel for <= 16 produced channels: bias (+ ReLU) into a channel slice; against torch on the CPU, and the SAME BITS as
+    the implicit-GEMM kernel (unet_tuning.conv_head1x1 = 0): one accumulation chain per logit, so masks and mosaic checksums do not move"""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xt = to_ts(x, cs=ops.rup4(Cin) + 8, co=4)
+    wp = ops.pack_weights(w.cuda(), 0)
+    for relu in (False, True):
+        ref = F.conv2d(x, w, b)
+        ref = F.relu(ref) if relu else ref
+        outs = []
+        for on in (1, 2, 0):                      # 2: the other pixel-tile count per trip
+            with _knobs.tuning(conv_head1x1=on, conv_splitk=0):       # (a split reduction is another chain: the planner cuts 128 channels on a small grid)
+                yt = empty_ts(N, H, W, Cout, cs=ops.rup4(Cout) + 12, co=8)
+                assert (ops.conv2d_variant(xt, wp, yt, 1, 1) == 11) == bool(on)
+                ops.conv2d(xt, wp, yt, 1, 1, bias=b.cuda(), relu=relu)
+                torch.cuda.synchronize()
+            assert outside_untouched(yt)
+            outs.append(from_ts(yt))
+        assert_close(outs[0], ref, rtol=1e-5, what=f"head 1x1 {case}")
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"head 1x1 {case}: not the bits of the implicit-GEMM kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
     # N, H, W, Cin, Cout, stride: conv3x3_smallcin_kernel (variant id 10) -- the stem's first conv and its neighbours
     (2, 64, 64, 4, 32, 2),      # the headline stem conv0 (RGBI tile)
     (1, 37, 29, 3, 32, 2),      # RGB, odd image edges (stride-2 output ceil(H / 2))

@@ -29,7 +29,7 @@ vp = C.c_void_p
 class Tuning(C.Structure):
     """unet_tuning: the kernel-selection switches of one launch (include/unet_hip.h).  Start from Tuning.default()."""
     _fields_ = [(n, C.c_int) for n in ("conv_splitk", "mfma_shape", "f32_big_tile", "bf16_big_tile", "t256_tiles_per_wg", "t256_sliver",
-                                       "conv1x1_gemm", "wgrad_mfma_shape", "wgrad_bf16_k4", "wgrad_1x1", "wgrad_narrow", "plan_batch", "wgrad_wgs", "conv_smallcin")]
+                                       "conv1x1_gemm", "wgrad_mfma_shape", "wgrad_bf16_k4", "wgrad_1x1", "wgrad_narrow", "plan_batch", "wgrad_wgs", "conv_smallcin", "conv_head1x1")]
 
     @classmethod
     def default(cls, **over) -> "Tuning":

@@ -225,6 +225,118 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
     }
 }
 
+
+// ---- conv1x1_head_kernel: a 1x1 convolution with at most 16 OUTPUT channels -- the segmentation head (reference train.py:141-144: the last layer
+// of DynamicUnet, ConvLayer(100, n_classes, ks=1, act_cls=None)) --, forward.  SURVEY 8a: 2 x 100 x 5 FLOP against 400 B (fp32) per pixel: a
+// stream over the widest activation of the network (16 x 512^2 x 100: 1.7 GB fp32, 0.87 GB bf16) that the tiled implicit-GEMM kernels read at
+// 3.3-3.4 TB/s through their LDS halo (conv_igemm16_kernel<32,1,1,4,1,4> 508 us, conv_bf16_kernel<32,1,1,4,1,4> 262 us in the step; this
+// kernel alone: 432 / 203 us = 4.2 / 5.0 TB/s).  Here a
+// wave owns 64 consecutive pixels and nothing else: the MFMA B operand of lane (l15, kq) IS the 16-byte piece [16 kq, 16 kq + 16) of chunk c of
+// pixel l15 (global -> VGPR, every load of a trip issued before the first MFMA), the filter (<= 16 x 128 values) lives in registers for the whole
+// kernel, no LDS, no barrier.  Accumulation per output element = the chain of the implicit-GEMM kernels (chunks ascending; fp32: the four
+// k-steps of a chunk ascending, a reduction tail as ONE transposed step), so the logits are the same bits.
+struct HeadArgs {
+    const char* x; const char* wp; const float* bias; char* y;
+    int x_cs, x_co, y_cs, y_co;
+    long long P;
+    int Cin, Cout, coutPad, relu, y_f32;
+};
+
+template <typename T, int NCH, int MT>
+__global__ __launch_bounds__(256) void conv1x1_head_kernel(const HeadArgs a) {
+    constexpr int EB = (int)sizeof(T), KC = 64 / EB, VEC = 16 / EB;               // 64-byte chunks of KC channels; MT pixel tiles of 16 per wave and trip
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int nch = (a.Cin + KC - 1) / KC, tail = a.Cin % KC;                       // (tail: fp32 only -- bf16 tails are zero padded chunks)
+    const int cin_v = (a.Cin + VEC - 1) / VEC * VEC;                                // channels that exist in the slice (pad lanes are zeros)
+    // filter: lane (cout l15, kq) keeps its 16 bytes of every chunk
+    f32x4 w[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        w[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < nch) w[c] = *reinterpret_cast<const f32x4*>(a.wp + ((size_t)(c * a.coutPad + l15) * KC) * EB + 16 * kq);
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (a.bias != nullptr && 4 * kq + r < a.Cout) ? a.bias[4 * kq + r] : 0.f;
+    const long long nwaves = (long long)gridDim.x * 4, wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int WP = 16 * MT;
+    auto ldx = [](const char* q) { return *reinterpret_cast<const f32x4*>(q); };
+    for (long long g = wave0; g * WP < a.P; g += nwaves) {
+        f32x4 xs[MT][NCH];
+        const char* xp[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            long long p = g * WP + m * 16 + l15;
+            p = p < a.P ? p : a.P - 1;                       // computed, not stored
+            xp[m] = a.x + ((size_t)p * a.x_cs + a.x_co) * EB;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                xs[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (EB == 4) {
+                    if (c < nch && !(tail != 0 && c == nch - 1)) xs[m][c] = ldx(xp[m] + (size_t)(c * KC + 4 * kq) * EB);
+                    else if (c == nch - 1 && tail != 0) {   // transposed tail: k-slot kq of step kk = channel kq + 4 kk of the chunk
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (kq + 4 * kk < tail) xs[m][c][kk] = *reinterpret_cast<const float*>(xp[m] + (size_t)(c * KC + kq + 4 * kk) * EB);
+                    }
+                } else {
+                    if (c < nch && c * KC + VEC * kq < cin_v) xs[m][c] = ldx(xp[m] + (size_t)(c * KC + VEC * kq) * EB);
+                }
+            }
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c < nch) {
+                if constexpr (EB == 2) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[c]), __builtin_bit_cast(bf16x8, xs[m][c]), acc[m], 0, 0, 0);
+                } else {
+                    const int steps = (tail != 0 && c == nch - 1) ? (tail + 3) / 4 : 4;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        if (kk < steps) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][kk], xs[m][c][kk], acc[m], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        // lane (pixel l15, kq): channels 4 kq .. 4 kq + 3 (only produced channels are written: pad lanes of a slice belong to its owner)
+        if (4 * kq < a.Cout) {
+            const int nr = a.Cout - 4 * kq;                  // valid channels of this lane's quad (>= 4: the whole vector)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const long long p = g * WP + m * 16 + l15;
+                if (p >= a.P) continue;
+                f32x4 v = acc[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += bv[r];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (EB == 4 || a.y_f32) {
+                    float* yo = reinterpret_cast<float*>(a.y) + (size_t)p * a.y_cs + a.y_co + 4 * kq;
+                    if (nr >= 4) *reinterpret_cast<f32x4*>(yo) = v;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) if (r < nr) yo[r] = v[r];
+                    }
+                } else {
+                    __bf16* yo = reinterpret_cast<__bf16*>(a.y) + (size_t)p * a.y_cs + a.y_co + 4 * kq;
+                    if (nr >= 4) *reinterpret_cast<bf16x4*>(yo) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) if (r < nr) yo[r] = (__bf16)v[r];
+                    }
+                }
+            }
+        }
+    }
+}
 }  // namespace
 
 namespace unetconv {
@@ -312,6 +424,41 @@ int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
         if (bf) hipLaunchKernelGGL((conv1x1_gemm_kernel<unsigned short, false>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv1x1_gemm_kernel<float, false>), dim3(grid), dim3(256), 0, st, a);
     }
+    UNET_CHECK_LAUNCH();
+    return UNET_OK;
+}
+
+
+// the head kernel's launches: 1x1 / stride 1, 9..128 reduction channels in ONE filter image, at most 16 produced channels, bias / ReLU only
+bool conv_head1x1_applies(const unet_conv_desc* d) {
+    if (tuning_of(d->tuning).conv_head1x1 == 0) return false;
+    const int vec = d->dtype == UNET_BF16 ? 8 : 4;
+    return d->ks == 1 && d->stride == 1 && d->Cin > 8 && d->Cin <= 128 && d->Cout <= 16 && d->res == nullptr && !(d->flags & UNET_CONV_MASK) &&
+           d->colsum == nullptr && d->colsumsq == nullptr && d->cout_begin == 0 && (d->cout_count == 0 || d->cout_count == d->Cout) &&
+           d->wp_img_stride == 0 && !d->pixel_shuffle && unet::roundup(d->Cin, vec) <= d->x_cs - d->x_co && d->Cout <= d->y_cs - d->y_co &&
+           d->y_co % 4 == 0 && d->y_cs % 4 == 0 && d->x_co % vec == 0 && d->x_cs % vec == 0;
+}
+
+int conv_head1x1(const unet_conv_desc* d, hipStream_t st) {
+    HeadArgs a;
+    const bool bf = d->dtype == UNET_BF16;
+    a.x = (const char*)d->x; a.wp = (const char*)d->wp; a.bias = d->bias; a.y = (char*)d->y;
+    a.x_cs = d->x_cs; a.x_co = d->x_co; a.y_cs = d->y_cs; a.y_co = d->y_co;
+    a.P = (long long)d->N * d->OH * d->OW;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.coutPad = unet::roundup(d->Cout, 128);
+    a.relu = (d->flags & UNET_CONV_RELU) ? 1 : 0;
+    a.y_f32 = bf ? d->y_f32 : 1;
+    // pixel tiles per wave and trip: 4 with bf16 storage (16 loads in flight per lane), 2 in fp32 (14 loads; 28 cost half the occupancy) --
+    // measured at 16 x 512^2 x 100 -> 5 (scripts/ab_conv_head.py): bf16 203 us (4) / 217 (2) against 257 on conv_bf16_kernel, fp32 475 (4) /
+    // 432 (2) against 485 on conv_igemm16_kernel; nontemporal loads cost 20 % in every form.  unet_tuning.conv_head1x1 = 2 swaps the two (A/B).
+    const bool swap = tuning_of(d->tuning).conv_head1x1 == 2;
+    const int mt = (bf != swap) ? 4 : 2;
+    long long blocks = (a.P + 64 * mt - 1) / (64 * mt);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    void (*kern)(const HeadArgs);
+    if (bf) kern = mt == 4 ? conv1x1_head_kernel<u16, 4, 4> : conv1x1_head_kernel<u16, 4, 2>;
+    else kern = mt == 4 ? conv1x1_head_kernel<float, 8, 4> : conv1x1_head_kernel<float, 8, 2>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }

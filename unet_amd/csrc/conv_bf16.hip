@@ -1098,6 +1098,7 @@ int conv2d_bf16(const unet_conv_desc* d, hipStream_t st) {
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return conv_smallk_bf16(d, st);
     if (conv_smallcin_applies(d)) return conv_smallcin_bf16(d, st);
+    if (conv_head1x1_applies(d)) return conv_head1x1(d, st);
     if (conv_gemm1x1_applies(d)) return conv_gemm1x1(d, st);
     const int y_f32 = p.splits > 1 ? 1 : d->y_f32;        // partial sums are fp32 slabs
     if (p.hit == 6) rc = launch_t256<unsigned short>(p, y_f32, st);
@@ -1120,6 +1121,7 @@ int conv2d_bf16_variant(const unet_conv_desc* d) {
     if (rc != UNET_OK) return rc;
     if (conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
     if (conv_smallcin_applies(d)) return 10;       // conv3x3_smallcin_kernel
+    if (conv_head1x1_applies(d)) return 11;        // conv1x1_head_kernel
     if (conv_gemm1x1_applies(d)) return 8;         // conv1x1_gemm_kernel
     // 256-pixel tile: ...7 = the large layers (128-wide blocks, 32-pixel patches, >= 512 blocks: the launches bench.py's roofline follows), ...6 = its
     // narrow-block / 16-pixel-patch / small-grid launches

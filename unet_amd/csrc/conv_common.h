@@ -481,6 +481,9 @@ int conv_gemm1x1_ps_check(const unet_conv_desc* d);      // validation of a unet
 bool conv_smallk_applies(const unet_conv_desc* d);
 int conv_smallk_bf16(const unet_conv_desc* d, hipStream_t st);
 // 3x3 forward convolutions of at most 8 input channels (the stem's first conv; conv_igemm.hip: conv3x3_smallcin_kernel), both storage types
+// 1x1 forward convolutions with at most 16 produced channels (the segmentation head; conv1x1.hip: conv1x1_head_kernel), both storage types
+bool conv_head1x1_applies(const unet_conv_desc* d);
+int conv_head1x1(const unet_conv_desc* d, hipStream_t st);
 bool conv_smallcin_applies(const unet_conv_desc* d);
 int conv_smallcin_bf16(const unet_conv_desc* d, hipStream_t st);
 

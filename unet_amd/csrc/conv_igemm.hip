@@ -739,6 +739,7 @@ const unet_tuning& tuning_defaults() {
         v.plan_batch = 0;
         v.wgrad_wgs = env_int("UNET_WGRAD_WGS", 0);
         v.conv_smallcin = env_int("UNET_CONV_SMALLCIN", 1);
+        v.conv_head1x1 = env_int("UNET_CONV_HEAD1X1", 1);
         return v;
     }();
     return t;
@@ -836,6 +837,7 @@ extern "C" int unet_conv2d_variant(const unet_conv_desc* d) {
     if (rc != UNET_OK) return rc;
     if (unetconv::conv_smallk_applies(d)) return 9;          // conv1x1_smallk_kernel
     if (unetconv::conv_smallcin_applies(d)) return 10;       // conv3x3_smallcin_kernel
+    if (unetconv::conv_head1x1_applies(d)) return 11;        // conv1x1_head_kernel
     if (unetconv::conv_gemm1x1_applies(d)) return 8;         // conv1x1_gemm_kernel
     const bool large = p.bm == 256 && p.bn == 128 && p.tw == 32 && (long long)p.k.mtiles * p.k.ntn >= 512;
     return p.tw * 10000 + p.bn * 10 + (p.hit == 10 ? 1 : 0) + (p.bm == 64 ? 5 : 0) + (p.bm == 256 ? (large ? 7 : 6) : 0) + (p.splits > 1 ? 1000000 * p.splits : 0);
@@ -1225,6 +1227,7 @@ extern "C" int unet_conv2d(const unet_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (smallk_applies(d)) return launch_smallk<float>(d, st);
     if (unetconv::conv_smallcin_applies(d)) return launch_smallcin<float>(d, st);
+    if (unetconv::conv_head1x1_applies(d)) return unetconv::conv_head1x1(d, st);
     if (unetconv::conv_gemm1x1_applies(d)) return unetconv::conv_gemm1x1(d, st);
     if (p.hit == 6) rc = unetconv::conv2d_t256_f32(p, st);          // the 256-pixel tile (conv_bf16.hip: conv_bf16_t256_kernel<.., float>)
     else rc = (p.hit == 10) ? launch_tw<10>(p, st) : launch_tw<4>(p, st);
