@@ -137,6 +137,16 @@ typedef struct {
                                             order.  The PixelShuffle_ICNR without blur in front of the dense merge (reference train.py:141: blur_final applies
                                             to the LAST UnetBlock, the final upsample has none) then needs no un-shuffled copy of the conv output at all.
                                             Only descriptors unet_conv2d_variant answers 8 for are taken (UNET_E_UNSUPPORTED otherwise) */
+    /* pixel_shuffle only, optional (ps_tail = NULL: none): an NHWC tensor [N, 2 OH, 2 OW] of y's storage type whose channels [ps_tail_co,
+       ps_tail_co + ps_tail_c) are copied to channels [ps_tail_at, ..) of y's BUFFER (counted from the buffer, not from y_co) by the lane that
+       stores the last four shuffled channels of the same pixel: the network-input half of DynamicUnet's final concat (reference train.py:141,
+       last_cross: cat([up, x])) without a second pass of 8-byte writes at 208-byte stride over the buffer (158 us alone at 16 x 512^2; measured
+       with bf16 storage: 490 + 158 us -> 598 us in one launch; with fp32 storage the appended stores cost more than the pass: 1021 + 155 -> 1229,
+       so the model uses it for bf16 only).  Whole quads are copied (ps_tail_c rounded up to 4: pad lanes of the source are zeros);
+       ps_tail_cs, ps_tail_co and ps_tail_at are multiples of 4, ps_tail_at + roundup(ps_tail_c, 4) <= y_cs */
+    const void* ps_tail;
+    int ps_tail_cs, ps_tail_co;
+    int ps_tail_c, ps_tail_at;
 } unet_conv_desc;
 
 /* number of partial rows the colsum buffers must hold for this desc */

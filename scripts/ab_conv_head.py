@@ -45,3 +45,20 @@ for dt in (torch.float32, torch.bfloat16):
     y1 = TS(torch.zeros((16, 512, 512, ops.rupv(100, dt)), device="cuda", dtype=dt), 0, 100)
     print(f"nchw_to_nhwc {str(dt)[6:]}: own buffer {timeit(lambda: ops.nchw_to_nhwc(x, y0)):6.1f} us, channels 96..99 of the concat {timeit(lambda: ops.nchw_to_nhwc(x, y1, at=96)):6.1f} us")
     assert torch.equal(y0.buf[..., :4].float(), x.permute(0, 2, 3, 1).to(dt).float()) and torch.equal(y1.buf[..., 96:100].float(), x.permute(0, 2, 3, 1).to(dt).float())
+# the final upsample (96 -> 4 x 96 at 16 x 256^2, stored pixel-shuffled into the 100-wide concat buffer) with the network input appended by the
+# same launch (unet_conv_desc.ps_tail) against the launch + a second pass
+for dt in (torch.float32, torch.bfloat16):
+    N, H, Cin, nf = 16, 256, 96, 96
+    x = TS(torch.randn((N, H, H, Cin), device="cuda", generator=g).to(dt), 0, Cin)
+    w = torch.randn((4 * nf, Cin, 1, 1), device="cuda", generator=g) / Cin ** 0.5
+    b = torch.randn(4 * nf, device="cuda", generator=g)
+    wp = ops.pack_weights(w, 2, dtype=dt)
+    img = torch.rand(N, 4, 2 * H, 2 * H, device="cuda")
+    x0 = TS(torch.zeros((N, 2 * H, 2 * H, ops.rupv(4, dt)), device="cuda", dtype=dt), 0, 4)
+    ops.nchw_to_nhwc(img, x0)
+    Xa = TS(torch.zeros((N, 2 * H, 2 * H, ops.rupv(100, dt)), device="cuda", dtype=dt), 0, nf)
+    Xb = TS(torch.zeros((N, 2 * H, 2 * H, ops.rupv(100, dt)), device="cuda", dtype=dt), 0, nf)
+    t_plain = timeit(lambda: ops.conv1x1_shuffle(x, wp, Xa, bias=b, relu=True))
+    t_put = timeit(lambda: ops.nchw_to_nhwc(img, TS(Xa.buf, 0, Xa.buf.shape[3]), at=96))
+    t_tail = timeit(lambda: ops.conv1x1_shuffle(x, wp, Xb, bias=b, relu=True, tail=x0, tail_at=96))
+    print(f"upsample {str(dt)[6:]}: launch {t_plain:6.1f} us + second pass {t_put:6.1f} us = {t_plain + t_put:6.1f}; with ps_tail {t_tail:6.1f} us; same buffer: {torch.equal(Xa.buf, Xb.buf)}")

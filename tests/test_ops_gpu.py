@@ -505,6 +505,24 @@ def _conv1x1_shuffle_case(ops, case, bf16):
     tol = (2.0 ** -8 if bf16 else 2e-5) * ref.abs().max().item()
     assert (got.double() - ref.detach()).abs().max().item() <= tol
     assert bool((Xt.buf[..., :v] == 7.25).all()) and bool((Xt.buf[..., v + nf:] == 7.25).all())          # the neighbouring slices are untouched
+    # unet_conv_desc.ps_tail: the same launch appends another NHWC slice (the network input of the final concat) behind the shuffled channels
+    for tc in (4, 3, 8):
+        tsrc = torch.full((N, 2 * H, 2 * W, v + 16), 3.5)
+        tsrc[..., v:v + tc] = rnd(torch.randn(N, 2 * H, 2 * W, tc, generator=g))
+        tsrc[..., v + tc:v + (tc + 3) // 4 * 4] = 0.0                       # pad lanes of the source slice are zeros
+        tail = ops.TS(tsrc.to(dt).cuda(), v, tc)
+        X2 = ops.TS(torch.full((N, 2 * H, 2 * W, nf + 2 * v + 16), 7.25, dtype=dt, device="cuda"), v, nf)
+        at = v + nf + 4                                                     # a quad-aligned place behind the slice (with a gap)
+        assert ops.conv1x1_shuffle_tail_ok(X2, tail, at) and not ops.conv1x1_shuffle_tail_ok(X2, tail, at + 2)
+        ops.conv1x1_shuffle(xt, wp, X2, bias=b.cuda(), relu=True, tail=tail, tail_at=at)
+        torch.cuda.synchronize()
+        tq = (tc + 3) // 4 * 4
+        assert torch.equal(X2.view(), Xt.view()), "the shuffled channels changed with a tail"
+        assert torch.equal(X2.buf[..., at:at + tq], tail.buf[..., v:v + tq]), "tail channels"
+        rest = torch.ones(X2.buf.shape[-1], dtype=torch.bool)
+        rest[v:v + nf] = False
+        rest[at:at + tq] = False
+        assert bool((X2.buf[..., rest] == 7.25).all()), "wrote outside the slice and the tail"
     # adjoint: dL/d(yc) from dL/dX, masked by the ReLU -- the mask read from X itself
     dX = rnd(torch.randn(N, nf, 2 * H, 2 * W, generator=g))
     ref.backward(dX.double())

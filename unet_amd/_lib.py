@@ -62,6 +62,7 @@ class ConvDesc(C.Structure):
         ("splitk_ws", vp), ("splitk_ws_floats", C.c_size_t),
         ("tuning", C.POINTER(Tuning)),
         ("pixel_shuffle", C.c_int),
+        ("ps_tail", vp), ("ps_tail_cs", C.c_int), ("ps_tail_co", C.c_int), ("ps_tail_c", C.c_int), ("ps_tail_at", C.c_int),
     ]
 
 

@@ -32,6 +32,8 @@ struct G1Args {
     // pixel-shuffle store (unet_conv_desc.pixel_shuffle): produced channel q = ij * nf + c of input pixel (img, h, w) goes to channel c of
     // output pixel (img, 2 h + (ij >> 1), 2 w + (ij & 1)) of a [N, 2 H, 2 W] tensor; bias is indexed in the filter's own order 4 c + ij
     int ps, nf, H, W;
+    // unet_conv_desc.ps_tail: quads [0, tail_q) of tail + pixel * tail_cs + tail_co go to channel tail_at of the same OUTPUT pixel of y's buffer
+    const char* tail; int tail_cs, tail_co, tail_q, tail_at;
 };
 
 // STAGED = false: the pixel operand of a wave goes global -> VGPR directly (128-pixel workgroup tile, 4 x 4 tiles per wave).
@@ -221,6 +223,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const G1Args a) {
                 const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.y) + yo) = __builtin_bit_cast(uint2, o);
             }
+            if (a.ps && a.tail != nullptr && c4 % a.nf == a.nf - 4) {      // the last quad of this output pixel's shuffled channels: append the tail
+                const size_t op = (yo - (size_t)a.y_co - (size_t)(a.nf - 4)) / (size_t)a.y_cs;
+                const char* src = a.tail + ((size_t)op * a.tail_cs + a.tail_co) * EB;
+                char* dst = a.y + ((size_t)op * a.y_cs + a.tail_at) * EB;
+                for (int t = 0; t < a.tail_q; ++t) {
+                    if constexpr (EB == 4) *reinterpret_cast<f32x4*>(dst + 16 * t) = *reinterpret_cast<const f32x4*>(src + 16 * t);
+                    else *reinterpret_cast<uint2*>(dst + 8 * t) = *reinterpret_cast<const uint2*>(src + 8 * t);
+                }
+            }
         }
     }
 }
@@ -386,6 +397,13 @@ int conv_gemm1x1_ps_check(const unet_conv_desc* d) {
     UNET_CHECK_ARG(d->res == nullptr && !(d->flags & UNET_CONV_MASK) && d->colsum == nullptr && d->colsumsq == nullptr && d->cout_begin == 0 &&
                    d->cout_count == 0 && d->wp_img_stride == 0, "conv pixel_shuffle: no residual / mask / column sums / channel range / per-image filters");
     UNET_CHECK_ARG((long long)d->N * d->OH * d->OW * 4 < (1ll << 31), "conv pixel_shuffle: more than 2^31 output pixels");
+    if (d->ps_tail != nullptr) {
+        const int tq = unet::roundup(d->ps_tail_c, 4);
+        UNET_CHECK_ARG(unet::aligned16(d->ps_tail) && d->ps_tail_c > 0 && d->ps_tail_cs > 0 && d->ps_tail_cs % 4 == 0 && d->ps_tail_co >= 0 && d->ps_tail_co % 4 == 0 &&
+                       d->ps_tail_co + tq <= d->ps_tail_cs, "conv pixel_shuffle: bad ps_tail slice (whole quads: cs, co multiples of 4, co + roundup(c, 4) <= cs)");
+        UNET_CHECK_ARG(d->ps_tail_at % 4 == 0 && d->ps_tail_at >= d->y_co + d->Cout / 4 && d->ps_tail_at + tq <= d->y_cs && !(d->dtype == UNET_BF16 && d->y_f32),
+                       "conv pixel_shuffle: ps_tail_at must be a multiple of 4 behind the shuffled channels with ps_tail_at + roundup(ps_tail_c, 4) <= y_cs");
+    }
     if (!shape_ok(d)) {
         unet::set_error("conv pixel_shuffle: only conv1x1_gemm_kernel stores pixel-shuffled (whole reduction chunks, >= 256 blocks of 128 x 128); "
                         "ask unet_conv2d_variant first and keep conv + unet_shuffle_blur otherwise");
@@ -410,6 +428,8 @@ int conv_gemm1x1(const unet_conv_desc* d, hipStream_t st) {
     a.Cout = d->Cout;
     a.relu = (d->flags & UNET_CONV_RELU) ? 1 : 0;
     a.y_f32 = bf ? d->y_f32 : 1;
+    a.tail = d->pixel_shuffle ? (const char*)d->ps_tail : nullptr;
+    a.tail_cs = d->ps_tail_cs; a.tail_co = d->ps_tail_co; a.tail_q = unet::roundup(d->ps_tail_c, 4) / 4; a.tail_at = d->ps_tail_at;
     const bool staged = form_of(d) == 2;
     const int tpix = staged ? 256 : 128;
     a.ntn = unet::cdiv(a.n_end - a.n_base, 128);

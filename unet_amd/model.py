@@ -315,8 +315,10 @@ class HipDynamicUnet(nn.Module):
             h = L[4 + k].hip_fwd(ctx, h, skips[idx])
         nb = 4 + len(self.sz_chg_idxs)
         X = ctx.act(self, "xcat", N, H, W, self.cat_p, zero=True)
-        L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W))
-        put(X.buf, self.up_off)                     # after the shuffle: the up slice owns its padding lanes (a gap: zeros) in front of these channels
+        # the network input behind the up-sampled channels: appended by the fused upsample launch from x0 (the same values, already NHWC) where
+        # it takes that; else a second pass -- after the shuffle: the up slice owns its padding lanes (a gap: zeros) in front of these channels
+        if not L[nb].hip_fwd(ctx, h, X.sub(0, self.up_c), (H, W), tail=(x0, self.up_off)):
+            put(X.buf, self.up_off)
         o = L[nb + 3].hip_fwd(ctx, X)
         z = ctx.act(self, "logits", N, H, W, self.n_out, zero=True, dtype=torch.float32)      # logits are fp32 in both modes
         head: ConvLayer = L[nb + 4]

@@ -226,6 +226,9 @@ def _no_forward(self, *a, **k):
 FUSE_BN_STATS = False
 # conv1x1 + bias + ReLU + PixelShuffle(2) as one launch where there is no blur behind it (UNET_FUSE_SHUFFLE=0: the two-pass form, A/B)
 FUSE_SHUFFLE = os.environ.get("UNET_FUSE_SHUFFLE", "1") != "0"
+# ... and, with bf16 storage, the network-input half of the final concat appended by that launch (unet_conv_desc.ps_tail;
+# UNET_FUSE_CONCAT_TAIL=0: a second pass, A/B)
+FUSE_CONCAT_TAIL = os.environ.get("UNET_FUSE_CONCAT_TAIL", "1") != "0"
 
 
 class _ConvExec:
@@ -698,9 +701,11 @@ class PixelShuffle_ICNR(nn.Sequential):
         super().__init__(*layers)
         self.blur, self.nf = blur, nf
 
-    def hip_fwd(self, ctx: Ctx, up_in: TS, dst: TS, out_hw: Tuple[int, int]):
+    def hip_fwd(self, ctx: Ctx, up_in: TS, dst: TS, out_hw: Tuple[int, int], tail: Optional[Tuple[TS, int]] = None) -> bool:
         """writes [blur](shuffle(relu(conv1x1(up_in)))) into `dst` (a channel slice of the concat buffer),
-        nearest-resized to out_hw when the skip / input size differs (non-/32 tiles)."""
+        nearest-resized to out_hw when the skip / input size differs (non-/32 tiles).
+        tail = (slice, channel): the other half of the concat, to be copied behind dst's channels at `channel` of dst's buffer; returns True when
+        this call wrote it (the fused launch appends it to its own stores), False when the caller still has to."""
         cl: ConvLayer = self[0]
         ctx.saved[(id(cl), "x")] = up_in
         # no blur (the final upsample in front of the dense merge) and no resize: conv + bias + ReLU + PixelShuffle is ONE launch that stores
@@ -710,8 +715,12 @@ class PixelShuffle_ICNR(nn.Sequential):
                  and FUSE_SHUFFLE and ops.conv1x1_shuffle_applies(up_in, dst))
         ctx.saved[(id(self), "fused")] = dst if fused else None
         if fused:
-            ops.conv1x1_shuffle(up_in, cl.cx.packed(2), dst, bias=cl.cx.bsrc(), relu=True)
-            return
+            # (bf16 storage only: at 16 x 256^2 x 96 -> 4 x 96 the launch + the second pass are 490 + 158 us against 598 us in one launch; in
+            #  fp32 1021 + 155 against 1229 -- the appended 16-byte stores cost the launch more than the pass they replace: scripts/ab_conv_head.py)
+            with_tail = (tail is not None and FUSE_CONCAT_TAIL and dst.bf16 and ops.conv1x1_shuffle_tail_ok(dst, tail[0], tail[1]))
+            ops.conv1x1_shuffle(up_in, cl.cx.packed(2), dst, bias=cl.cx.bsrc(), relu=True, tail=tail[0] if with_tail else None,
+                                tail_at=tail[1] if with_tail else 0)
+            return with_tail
         yc = ctx.act(cl, "a", up_in.N, up_in.H, up_in.W, 4 * self.nf)
         cl.cx.fwd(up_in, yc, relu=True)
         if (2 * up_in.H, 2 * up_in.W) == tuple(out_hw):
@@ -720,6 +729,7 @@ class PixelShuffle_ICNR(nn.Sequential):
             tmp = ctx.act(self, "up", up_in.N, 2 * up_in.H, 2 * up_in.W, self.nf)
             ops.shuffle_blur(yc, tmp, self.blur)
             ops.resize_nearest(tmp, dst)
+        return False
 
     def hip_bwd(self, ctx: Ctx, d_dst: TS, mask_input: bool = True) -> TS:
         """d_dst = dL/d(dst slice).  Returns dL/d(pre-activation of the producer of up_in) (masked by up_in > 0 when up_in is

@@ -422,9 +422,20 @@ def conv1x1_shuffle_applies(x: TS, X: TS) -> bool:
     return int(lib.unet_conv2d_variant(C.byref(d))) == 8
 
 
-def conv1x1_shuffle(x: TS, wp_ps: torch.Tensor, X: TS, bias=None, relu=True):
-    """X = PixelShuffle(2)(act(conv1x1(x) + bias)); wp_ps is the mode-2 packed image (columns in pixel-shuffle order)"""
+def conv1x1_shuffle_tail_ok(X: TS, tail: TS, at: int) -> bool:
+    """can conv1x1_shuffle append `tail`'s channels at channel `at` of X's buffer (unet_conv_desc.ps_tail: whole quads at quad-aligned places)?"""
+    return (tail.bf16 == X.bf16 and (tail.N, tail.H, tail.W) == (X.N, X.H, X.W) and tail.cs % 4 == 0 and tail.co % 4 == 0 and at % 4 == 0
+            and tail.co + rup4(tail.C) <= tail.cs and at >= X.co + X.C and at + rup4(tail.C) <= X.cs)
+
+
+def conv1x1_shuffle(x: TS, wp_ps: torch.Tensor, X: TS, bias=None, relu=True, tail: Optional[TS] = None, tail_at: int = 0):
+    """X = PixelShuffle(2)(act(conv1x1(x) + bias)); wp_ps is the mode-2 packed image (columns in pixel-shuffle order).
+    tail: an NHWC slice of X's geometry copied to channels [tail_at, tail_at + C) of X's BUFFER by the same launch (the network input behind
+    the up-sampled channels of the final concat)"""
     d = _ps_desc(x, wp_ps, X, bias, relu)
+    if tail is not None:
+        assert conv1x1_shuffle_tail_ok(X, tail, tail_at)
+        d.ps_tail, d.ps_tail_cs, d.ps_tail_co, d.ps_tail_c, d.ps_tail_at = tail.ptr, tail.cs, tail.co, tail.C, tail_at
     check(lib.unet_conv2d(C.byref(d), _stream()), "conv1x1_shuffle")
 
 
