@@ -35,7 +35,7 @@ extern "C" {
 #define UNET_E_UNSUPPORTED (-2)
 #define UNET_E_HIP (-3)
 
-#define UNET_ABI_VERSION 7
+#define UNET_ABI_VERSION 8
 
 int unet_abi_version(void);
 const char* unet_last_error(void);
@@ -442,6 +442,23 @@ int unet_focal_bwd_bf16(const float* z, int z_cs, int z_co, const int64_t* targe
 int unet_pack_weights_strided_bf16(const unet_bf16* w, long long so, long long sr, unet_bf16* wp, int O, int R, void* stream);
 int unet_row_softmax_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
 int unet_row_softmax_bwd_bf16(const unet_bf16* y, int y_cs, int y_co, const float* dy, int dy_cs, int dy_co, unet_bf16* dx, int dx_cs, int dx_co, long long P, int C, void* stream);
+/* Fused SelfAttention for bf16 storage (round 5; csrc/attention.hip): beta = softmax(f^T g, dim=1), o = h beta of fastai layers.py
+ * SelfAttention (params_and_main.py:81-83, train.py:141-144) without the N x N matrix in HBM.  qkv: [B][N][cq] rows with F (query conv) at
+ * channel 0, G (key conv) at dp, H (value conv) at 2 dp; dp <= 64, C <= 512, both multiples of 8 (unet_sa_fused_supported; other shapes run
+ * the blockwise products above).  Rows are positions h * W + w of the NHWC tensors.
+ *   unet_sa_pack_bf16   image of a channel slice blocked by 64 positions with positions innermost (unet_sa_pack_elems(N, cc) elements per
+ *                       image): the operand of the products that sum over positions (H for O = P H; dO, G, F in the backward pass)
+ *   unet_sa_fwd_bf16    O[j] = sum_i softmax_i(G_j . F_i) H_i (bf16) and lse[b][j] = log sum_i exp(G_j . F_i) (fp32), vpack = pack of H
+ *   unet_sa_rowdot_bf16 D[row] = sum_c a[row][c] o[row][c] (fp32): the softmax-adjoint term dO_j . O_j
+ *   unet_sa_bwd_bf16    dqkv (all three slices: dF, dG, dH) from dO, lse, D; dopack / gpack / fpack = packs of dO, G, F.  Weights are
+ *                       recomputed from lse; no atomics (run-to-run identical bits) */
+int unet_sa_fused_supported(int dp, int C);
+size_t unet_sa_pack_elems(int N, int cc);
+int unet_sa_pack_bf16(const unet_bf16* x, int x_cs, int x_co, int cc, int B, int N, unet_bf16* out, void* stream);
+int unet_sa_fwd_bf16(const unet_bf16* qkv, int cq, int dp, int C, int B, int N, const unet_bf16* vpack, unet_bf16* O, int o_cs, int o_co, float* lse, void* stream);
+int unet_sa_rowdot_bf16(const unet_bf16* a, int a_cs, int a_co, const unet_bf16* o, int o_cs, int o_co, long long rows, int C, float* D, void* stream);
+int unet_sa_bwd_bf16(const unet_bf16* qkv, int cq, int dp, int C, int B, int N, const unet_bf16* dO, int do_cs, int do_co, const unet_bf16* dopack,
+                     const unet_bf16* gpack, const unet_bf16* fpack, const float* lse, const float* D, unet_bf16* dqkv, void* stream);
 int unet_relu_mask_bf16(const unet_bf16* g, int g_cs, int g_co, const unet_bf16* ref, int r_cs, int r_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);
 int unet_dot_bf16(const unet_bf16* x, int x_cs, int x_co, const unet_bf16* y, int y_cs, int y_co, long long P, int C, float* out, float* workspace, void* stream);
 int unet_cast_slice_bf16(const float* x, int x_cs, int x_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(L.lib, s), s
-    assert L.lib.unet_abi_version() == 7
+    assert L.lib.unet_abi_version() == 8
     # version 6: no process-wide setters any more -- the kernel-selection switches travel with the descriptors (unet_tuning)
     assert not [s for s in syms if s.startswith("unet_set_")]
     t = L.Tuning.default()

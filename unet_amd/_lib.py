@@ -181,6 +181,12 @@ for _n in ("bn_stats", "affine_act", "bn_bwd_reduce", "bn_bwd_apply", "maxpool3x
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
 for _n in ("pack_weights_strided", "row_softmax", "row_softmax_bwd", "relu_mask", "dot"):
     _sig[f"unet_{_n}_bf16"] = _sig[f"unet_{_n}"]
+_sig["unet_sa_fused_supported"] = (i, [i, i])
+_sig["unet_sa_pack_elems"] = (sz, [i, i])
+_sig["unet_sa_pack_bf16"] = (i, [vp, i, i, i, i, i, vp, vp])
+_sig["unet_sa_fwd_bf16"] = (i, [vp, i, i, i, i, i, vp, vp, i, i, vp, vp])
+_sig["unet_sa_rowdot_bf16"] = (i, [vp, i, i, vp, i, i, ll, i, vp, vp])
+_sig["unet_sa_bwd_bf16"] = (i, [vp, i, i, i, i, i, vp, i, i, vp, vp, vp, vp, vp, vp, vp])
 _sig["unet_cast_slice_bf16"] = (i, [vp, i, i, vp, i, i, ll, i, vp])
 _sig["unet_pack_weights_size_bf16"] = _sig["unet_pack_weights_size"]
 _sig["unet_pack_weights_bf16"] = _sig["unet_pack_weights"]
@@ -194,7 +200,7 @@ _undeclared = [s for s in declared_symbols() if s not in _sig]
 if _undeclared:
     raise ImportError(f"ctypes signatures missing for: {_undeclared}")
 
-if lib.unet_abi_version() != 7:
+if lib.unet_abi_version() != 8:
     raise ImportError("libunet_hip.so ABI version mismatch; rebuild with `python -m unet_amd.build --force`")
 
 

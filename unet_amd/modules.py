@@ -786,6 +786,7 @@ class SelfAttention(nn.Module):
     tiny matrices and stays in torch; its backward is torch autograd on those matrices, fed with the HIP weight gradient."""
     forward = _no_forward
     budget_elems = 1 << 28          # floats per N x N scratch buffer (1 GiB); tests lower it to force row blocks
+    fused = True                    # bf16 storage, C <= 512: the fused kernels of csrc/attention.hip (no N x N tensor); False = blockwise products
 
     def __init__(self, n_channels):
         super().__init__()
@@ -878,11 +879,19 @@ class SelfAttention(nn.Module):
         ops.pack_weights(wq, 0, wp, dtype=dt)
         qkv = ctx.act(self, "qkv", B, H, W, CQ)
         ops.conv2d(x, wp, qkv, 1)
-        chunks = self._chunks(B, H, W)
-        nbmax = max(c[1] for c in chunks)
-        szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
-        wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
         O = ctx.act(self, "O", B, H, W, C_)
+        use_fused = bool(self.fused) and dt == torch.bfloat16 and ops.sa_fused_supported(c8p, C_)
+        ctx.saved[(id(self), "fused")] = use_fused
+        chunks = [] if use_fused else self._chunks(B, H, W)
+        if use_fused:
+            # QK^T -> softmax -> . V in one launch (csrc/attention.hip); lse kept for the backward pass, which recomputes the weights
+            pk = ctx.vec(self, "sa_pack", B * ops.sa_pack_elems(N, C_), dtype=dt)
+            ops.sa_pack(qkv.sub(2 * c8p, C_), pk)
+            ops.sa_fwd(qkv, c8p, C_, pk, O, ctx.vec(self, "sa_lse", B * N))
+        else:
+            nbmax = max(c[1] for c in chunks)
+            szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
+            wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
         img = N * CQ * es     # bytes per image of qkv
         for ch in chunks:
             b0, nb, j0, nj = ch
@@ -895,7 +904,7 @@ class SelfAttention(nn.Module):
         out = ctx.act(self, "out", B, H, W, C_)
         ops.affine_act(O, out, gvec, zvec, x2=x)
         ctx.saved[(id(self), "x")] = x
-        ctx.saved[(id(self), "P_kept")] = len(chunks) == 1      # a single chunk leaves its P in the scratch buffer for the backward
+        ctx.saved[(id(self), "P_kept")] = len(chunks) == 1 and not use_fused      # a single chunk leaves its P in the scratch buffer for the backward
         return out
 
     def hip_bwd(self, ctx: Ctx, dout: TS) -> TS:
@@ -910,13 +919,26 @@ class SelfAttention(nn.Module):
         dO = ctx.tmp(B, H, W, C_)
         ops.affine_act(dout, dO, gvec, zvec)
         dqkv = ctx.tmp(B, H, W, CQ)
-        chunks = self._chunks(B, H, W)
-        kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
-        nbmax = max(c[1] for c in chunks)
-        szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
-        wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
-        tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8p)              # weight-gradient results: fp32 in both modes
-        put = ops.cast_slice if bf else ops.copy_slice                                          # ... into the gradient of the QKV tensor
+        use_fused = bool(ctx.saved.get((id(self), "fused"), False))
+        chunks = [] if use_fused else self._chunks(B, H, W)
+        if use_fused:
+            # dH, dF per key block and dG per query block in two launches, weights recomputed from lse; the packed images are the
+            # operands of the products that sum over positions (dO for dH, G for dF, F for dG)
+            lse, D = ctx.vec(self, "sa_lse", B * N), ctx.vec(self, "sa_D", B * N)
+            ops.sa_rowdot(dO, O, D)
+            pk = ctx.vec(self, "sa_pack", B * ops.sa_pack_elems(N, C_), dtype=dt)               # the forward's image of H is not needed any more
+            gpk, fpk = (ctx.vec(self, t, B * ops.sa_pack_elems(N, c8p), dtype=dt) for t in ("sa_gpack", "sa_fpack"))
+            ops.sa_pack(dO, pk)
+            ops.sa_pack(qkv.sub(c8p, c8p), gpk)
+            ops.sa_pack(qkv.sub(0, c8p), fpk)
+            ops.sa_bwd(qkv, c8p, C_, dO, pk, gpk, fpk, lse, D, dqkv)
+        else:
+            kept = bool(ctx.saved.get((id(self), "P_kept"), False)) and len(chunks) == 1
+            nbmax = max(c[1] for c in chunks)
+            szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
+            wpa = ctx.vec(self, "wp_a", nbmax * max(szs), dtype=dt)
+            tmpH, tmpF = ctx.vec(self, "tmpH", N * C_), ctx.vec(self, "tmpF", N * c8p)          # weight-gradient results: fp32 in both modes
+            put = ops.cast_slice if bf else ops.copy_slice                                      # ... into the gradient of the QKV tensor
         img = N * CQ * es
         for ch in chunks:
             b0, nb, j0, nj = ch

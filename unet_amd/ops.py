@@ -277,6 +277,41 @@ def row_softmax_bwd(y: "TS", dy: "TS", dx: "TS"):
     check(fn(y.ptr, y.cs, y.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, y.P, y.C, _stream()), "row_softmax_bwd")
 
 
+# ---- fused SelfAttention for bf16 storage (csrc/attention.hip): the N x N matrix stays in registers
+def sa_fused_supported(dp: int, C: int) -> bool:
+    return bool(lib.unet_sa_fused_supported(int(dp), int(C)))
+
+
+def sa_pack_elems(N: int, cc: int) -> int:
+    return int(lib.unet_sa_pack_elems(int(N), int(cc)))
+
+
+def sa_pack(x: "TS", out: torch.Tensor):
+    """positions-innermost image of the channel slice x (rows = the H * W positions of each image): the operand of a product that sums over
+    positions"""
+    assert x.bf16 and out.dtype == torch.bfloat16 and out.numel() >= x.N * sa_pack_elems(x.H * x.W, x.C)
+    check(lib.unet_sa_pack_bf16(x.ptr, x.cs, x.co, x.C, x.N, x.H * x.W, out.data_ptr(), _stream()), "sa_pack")
+
+
+def sa_fwd(qkv: "TS", dp: int, C: int, vpack: torch.Tensor, O: "TS", lse: torch.Tensor):
+    """O_j = sum_i softmax_i(G_j . F_i) H_i and lse_j for every image of the fused QKV buffer (F at channel 0, G at dp, H at 2 dp)"""
+    assert qkv.bf16 and O.bf16 and qkv.co == 0 and lse.dtype == torch.float32 and lse.numel() >= qkv.P and O.C == C and O.P == qkv.P
+    check(lib.unet_sa_fwd_bf16(qkv.ptr, qkv.cs, dp, C, qkv.N, qkv.H * qkv.W, vpack.data_ptr(), O.ptr, O.cs, O.co, lse.data_ptr(), _stream()), "sa_fwd")
+
+
+def sa_rowdot(a: "TS", o: "TS", D: torch.Tensor):
+    assert a.bf16 and o.bf16 and a.C == o.C and a.P == o.P and D.dtype == torch.float32 and D.numel() >= a.P
+    check(lib.unet_sa_rowdot_bf16(a.ptr, a.cs, a.co, o.ptr, o.cs, o.co, a.P, a.C, D.data_ptr(), _stream()), "sa_rowdot")
+
+
+def sa_bwd(qkv: "TS", dp: int, C: int, dO: "TS", dopack: torch.Tensor, gpack: torch.Tensor, fpack: torch.Tensor, lse: torch.Tensor,
+           D: torch.Tensor, dqkv: "TS"):
+    """the gradient of the whole QKV buffer (dF | dG | dH slices) from dO = dL/dO, with the weights recomputed from lse"""
+    assert qkv.bf16 and dO.bf16 and dqkv.bf16 and qkv.co == 0 and dqkv.co == 0 and dqkv.cs == qkv.cs and dO.C == C and dO.P == qkv.P
+    check(lib.unet_sa_bwd_bf16(qkv.ptr, qkv.cs, dp, C, qkv.N, qkv.H * qkv.W, dO.ptr, dO.cs, dO.co, dopack.data_ptr(), gpack.data_ptr(),
+                               fpack.data_ptr(), lse.data_ptr(), D.data_ptr(), dqkv.ptr, _stream()), "sa_bwd")
+
+
 def cast_slice(x: "TS", y: "TS"):
     """fp32 slice -> bf16 slice (same geometry)"""
     assert not x.bf16 and y.bf16 and x.P == y.P and x.C == y.C
