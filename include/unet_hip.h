@@ -448,15 +448,16 @@ int unet_row_softmax_bwd_bf16(const unet_bf16* y, int y_cs, int y_co, const floa
  * the blockwise products above).  Rows are positions h * W + w of the NHWC tensors.
  *   unet_sa_pack_bf16   image of a channel slice blocked by 64 positions with positions innermost (unet_sa_pack_elems(N, cc) elements per
  *                       image): the operand of the products that sum over positions (H for O = P H; dO, G, F in the backward pass)
- *   unet_sa_fwd_bf16    O[j] = sum_i softmax_i(G_j . F_i) H_i (bf16) and lse[b][j] = log sum_i exp(G_j . F_i) (fp32), vpack = pack of H
- *   unet_sa_rowdot_bf16 D[row] = sum_c a[row][c] o[row][c] (fp32): the softmax-adjoint term dO_j . O_j
+ *   unet_sa_fwd_bf16    O[j] = sum_i softmax_i(G_j . F_i) H_i (bf16) and lse[b][j] = log sum_i exp(G_j . F_i) (fp32), vpack = pack of H.
+ *                       lse and D are [B][Np] with Np = 64 ceil(N / 64): the rows past N are written as 1e30 (their recomputed weight is 0)
+ *   unet_sa_rowdot_bf16 D[b][j] = sum_c a[b][j][c] o[b][j][c] (fp32): the softmax-adjoint term dO_j . O_j (rows past N untouched: keep them finite)
  *   unet_sa_bwd_bf16    dqkv (all three slices: dF, dG, dH) from dO, lse, D; dopack / gpack / fpack = packs of dO, G, F.  Weights are
  *                       recomputed from lse; no atomics (run-to-run identical bits) */
 int unet_sa_fused_supported(int dp, int C);
 size_t unet_sa_pack_elems(int N, int cc);
 int unet_sa_pack_bf16(const unet_bf16* x, int x_cs, int x_co, int cc, int B, int N, unet_bf16* out, void* stream);
 int unet_sa_fwd_bf16(const unet_bf16* qkv, int cq, int dp, int C, int B, int N, const unet_bf16* vpack, unet_bf16* O, int o_cs, int o_co, float* lse, void* stream);
-int unet_sa_rowdot_bf16(const unet_bf16* a, int a_cs, int a_co, const unet_bf16* o, int o_cs, int o_co, long long rows, int C, float* D, void* stream);
+int unet_sa_rowdot_bf16(const unet_bf16* a, int a_cs, int a_co, const unet_bf16* o, int o_cs, int o_co, int B, int N, int C, float* D, void* stream);
 int unet_sa_bwd_bf16(const unet_bf16* qkv, int cq, int dp, int C, int B, int N, const unet_bf16* dO, int do_cs, int do_co, const unet_bf16* dopack,
                      const unet_bf16* gpack, const unet_bf16* fpack, const float* lse, const float* D, unet_bf16* dqkv, void* stream);
 int unet_relu_mask_bf16(const unet_bf16* g, int g_cs, int g_co, const unet_bf16* ref, int r_cs, int r_co, unet_bf16* y, int y_cs, int y_co, long long P, int C, void* stream);

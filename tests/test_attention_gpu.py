@@ -82,7 +82,8 @@ def test_fused_forward_against_fp64(shape):
     qkv = _qkv(B, H, W, dp, d, C, seed=5, scale=0.6)
     O_ref, lse_ref, _ = _ref(qkv, dp, C)
     O = torch.full((B, H, W, C + 8), 9.0, dtype=torch.bfloat16, device="cuda")
-    lse = torch.zeros(B * N, device="cuda")
+    Np = ops.sa_rows(N)
+    lse = torch.zeros(B * Np, device="cuda")
     pk = torch.zeros(B * ops.sa_pack_elems(N, C), dtype=torch.bfloat16, device="cuda")
     q = TS(qkv, 0, 2 * dp + C)
     ops.sa_pack(q.sub(2 * dp, C), pk)
@@ -90,7 +91,8 @@ def test_fused_forward_against_fp64(shape):
     torch.cuda.synchronize()
     assert torch.all(O[..., :8] == 9.0), "channels outside the slice were written"
     rO = _rel(O[..., 8:].view(B, N, C), O_ref)
-    el = (lse.view(B, N).double() - lse_ref).abs().max().item()
+    el = (lse.view(B, Np)[:, :N].double() - lse_ref).abs().max().item()
+    assert torch.all(lse.view(B, Np)[:, N:] == 1e30), "lse of the rows past N"
     print(f"sa_fwd {shape}: O rel-L2 {rO:.3e}  lse max abs err {el:.3e} (max |lse| {lse_ref.abs().max().item():.2f})")
     assert rO <= 6e-3
     assert el <= 5e-5 * max(1.0, lse_ref.abs().max().item())
@@ -107,8 +109,10 @@ def test_fused_backward_against_fp64(shape):
     O_ref, lse_ref, g_ref = _ref(qkv, dp, C, dO)
     q = TS(qkv, 0, CQ)
     O = O_ref.to(torch.bfloat16).view(B, H, W, C).contiguous()
-    lse = lse_ref.float().view(-1).contiguous()
-    D = torch.zeros(B * N, device="cuda")
+    Np = ops.sa_rows(N)
+    lse = torch.full((B, Np), 1e30, device="cuda")
+    lse[:, :N] = lse_ref.float()
+    D = torch.zeros(B * Np, device="cuda")
     ops.sa_rowdot(TS(dO, 0, C), TS(O, 0, C), D)
     D_ref = (dO.double().view(B, N, C) * O.double().view(B, N, C)).sum(-1)
     pk, gpk, fpk = (torch.zeros(B * ops.sa_pack_elems(N, c), dtype=torch.bfloat16, device="cuda") for c in (C, dp, dp))
@@ -118,7 +122,7 @@ def test_fused_backward_against_fp64(shape):
     dqkv = torch.full((B, H, W, CQ), 5.0, dtype=torch.bfloat16, device="cuda")
     ops.sa_bwd(q, dp, C, TS(dO, 0, C), pk, gpk, fpk, lse, D, TS(dqkv, 0, CQ))
     torch.cuda.synchronize()
-    assert (D.view(B, N).double() - D_ref).abs().max().item() <= 1e-4 * D_ref.abs().max().item() + 1e-5
+    assert (D.view(B, Np)[:, :N].double() - D_ref).abs().max().item() <= 1e-4 * D_ref.abs().max().item() + 1e-5
     g = dqkv.view(B, N, CQ)
     rF, rG, rH = _rel(g[..., :d], g_ref[..., :d]), _rel(g[..., dp:dp + d], g_ref[..., dp:dp + d]), _rel(g[..., 2 * dp:], g_ref[..., 2 * dp:2 * dp + C])
     print(f"sa_bwd {shape}: rel-L2 dF {rF:.3e} dG {rG:.3e} dH {rH:.3e}")

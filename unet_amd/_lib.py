@@ -185,7 +185,7 @@ _sig["unet_sa_fused_supported"] = (i, [i, i])
 _sig["unet_sa_pack_elems"] = (sz, [i, i])
 _sig["unet_sa_pack_bf16"] = (i, [vp, i, i, i, i, i, vp, vp])
 _sig["unet_sa_fwd_bf16"] = (i, [vp, i, i, i, i, i, vp, vp, i, i, vp, vp])
-_sig["unet_sa_rowdot_bf16"] = (i, [vp, i, i, vp, i, i, ll, i, vp, vp])
+_sig["unet_sa_rowdot_bf16"] = (i, [vp, i, i, vp, i, i, i, i, i, vp, vp])
 _sig["unet_sa_bwd_bf16"] = (i, [vp, i, i, i, i, i, vp, i, i, vp, vp, vp, vp, vp, vp, vp])
 _sig["unet_cast_slice_bf16"] = (i, [vp, i, i, vp, i, i, ll, i, vp])
 _sig["unet_pack_weights_size_bf16"] = _sig["unet_pack_weights_size"]

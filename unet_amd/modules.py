@@ -887,7 +887,7 @@ class SelfAttention(nn.Module):
             # QK^T -> softmax -> . V in one launch (csrc/attention.hip); lse kept for the backward pass, which recomputes the weights
             pk = ctx.vec(self, "sa_pack", B * ops.sa_pack_elems(N, C_), dtype=dt)
             ops.sa_pack(qkv.sub(2 * c8p, C_), pk)
-            ops.sa_fwd(qkv, c8p, C_, pk, O, ctx.vec(self, "sa_lse", B * N))
+            ops.sa_fwd(qkv, c8p, C_, pk, O, ctx.vec(self, "sa_lse", B * ops.sa_rows(N)))
         else:
             nbmax = max(c[1] for c in chunks)
             szs = [ops.pack_size(N, c8, dt), ops.pack_size(C_, N, dt), ops.pack_size(N, C_, dt), ops.pack_size(c8p, N, dt)]
@@ -924,7 +924,7 @@ class SelfAttention(nn.Module):
         if use_fused:
             # dH, dF per key block and dG per query block in two launches, weights recomputed from lse; the packed images are the
             # operands of the products that sum over positions (dO for dH, G for dF, F for dG)
-            lse, D = ctx.vec(self, "sa_lse", B * N), ctx.vec(self, "sa_D", B * N)
+            lse, D = ctx.vec(self, "sa_lse", B * ops.sa_rows(N)), ctx.vec(self, "sa_D", B * ops.sa_rows(N))
             ops.sa_rowdot(dO, O, D)
             pk = ctx.vec(self, "sa_pack", B * ops.sa_pack_elems(N, C_), dtype=dt)               # the forward's image of H is not needed any more
             gpk, fpk = (ctx.vec(self, t, B * ops.sa_pack_elems(N, c8p), dtype=dt) for t in ("sa_gpack", "sa_fpack"))

@@ -293,15 +293,21 @@ def sa_pack(x: "TS", out: torch.Tensor):
     check(lib.unet_sa_pack_bf16(x.ptr, x.cs, x.co, x.C, x.N, x.H * x.W, out.data_ptr(), _stream()), "sa_pack")
 
 
+def sa_rows(N: int) -> int:
+    """row count per image of the lse / D vectors of the fused attention kernels (whole 64-position blocks)"""
+    return (N + 63) // 64 * 64
+
+
 def sa_fwd(qkv: "TS", dp: int, C: int, vpack: torch.Tensor, O: "TS", lse: torch.Tensor):
     """O_j = sum_i softmax_i(G_j . F_i) H_i and lse_j for every image of the fused QKV buffer (F at channel 0, G at dp, H at 2 dp)"""
-    assert qkv.bf16 and O.bf16 and qkv.co == 0 and lse.dtype == torch.float32 and lse.numel() >= qkv.P and O.C == C and O.P == qkv.P
+    assert qkv.bf16 and O.bf16 and qkv.co == 0 and lse.dtype == torch.float32 and O.C == C and O.P == qkv.P
+    assert lse.numel() >= qkv.N * sa_rows(qkv.H * qkv.W)
     check(lib.unet_sa_fwd_bf16(qkv.ptr, qkv.cs, dp, C, qkv.N, qkv.H * qkv.W, vpack.data_ptr(), O.ptr, O.cs, O.co, lse.data_ptr(), _stream()), "sa_fwd")
 
 
 def sa_rowdot(a: "TS", o: "TS", D: torch.Tensor):
-    assert a.bf16 and o.bf16 and a.C == o.C and a.P == o.P and D.dtype == torch.float32 and D.numel() >= a.P
-    check(lib.unet_sa_rowdot_bf16(a.ptr, a.cs, a.co, o.ptr, o.cs, o.co, a.P, a.C, D.data_ptr(), _stream()), "sa_rowdot")
+    assert a.bf16 and o.bf16 and a.C == o.C and a.P == o.P and D.dtype == torch.float32 and D.numel() >= a.N * sa_rows(a.H * a.W)
+    check(lib.unet_sa_rowdot_bf16(a.ptr, a.cs, a.co, o.ptr, o.cs, o.co, a.N, a.H * a.W, a.C, D.data_ptr(), _stream()), "sa_rowdot")
 
 
 def sa_bwd(qkv: "TS", dp: int, C: int, dO: "TS", dopack: torch.Tensor, gpack: torch.Tensor, fpack: torch.Tensor, lse: torch.Tensor,
