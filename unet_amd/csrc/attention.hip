@@ -42,6 +42,26 @@ __device__ __forceinline__ void st_bf(u16* p, float v) { *p = __builtin_bit_cast
 // position (inside a 32-position step) of row m of logits tile h: lane group g = m / 4 ends up with positions 8 g .. 8 g + 7
 __device__ __forceinline__ int perm_pos(int m, int h) { return 8 * (m >> 2) + 4 * h + (m & 3); }
 
+// Accumulator tiles -> whole rows.  a[ct][r] is row 4 (lane / 16) + r, channel 16 ct + lane % 16 of a 16-row block: per-lane stores would be
+// 2-byte writes scattered over four rows (measured: ~250 us for the 50 MB of O at the cfg2 geometry); the wave instead writes its block into
+// its own LDS region and reads it back as 16-byte pieces of whole rows (wave-local: LDS operations of one wave complete in order).
+// dst = row 0 of the block, stride in elements; rows [0, nrows) and channels [0, cvalid) are stored.
+template <int NT_, int PAD>
+__device__ __forceinline__ void rows_out(u16* wl, const f32x4 (&a)[NT_], const float (&sc)[4], int lane, u16* dst, size_t stride, int nrows, int cvalid) {
+    constexpr int PITCH = NT_ * 16 + PAD, VPR = NT_ * 2;
+    const int jl = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < NT_; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_bf(wl + (4 * g + r) * PITCH + ct * 16 + jl, a[ct][r] * sc[r]);
+#pragma unroll
+    for (int k = 0; k < (16 * VPR + 63) / 64; ++k) {
+        const int v = lane + 64 * k, row = v / VPR, cv = v % VPR;
+        if (row < 16 && row < nrows && cv * 8 < cvalid)
+            *reinterpret_cast<u32x4*>(dst + (size_t)row * stride + cv * 8) = *reinterpret_cast<const u32x4*>(wl + row * PITCH + cv * 8);
+    }
+}
+
 // Workgroups of one image run next to each other on ONE XCD (its L2 then holds the image's operands once): linear workgroup id L is
 // dispatched to XCD L % 8; when the batch is a multiple of 8, XCD x takes images x, x + 8, ...
 __device__ __forceinline__ void wg_image_block(int per_image, int B, int& b, int& blk) {
@@ -113,21 +133,21 @@ __global__ __launch_bounds__(256) void sa_rowdot_kernel(const u16* __restrict__ 
 #define SA_ONE_BF 0x3F80u
 #define SA_LSE_PAD 1e30f        /* lse of the query rows past N (lse is [B][64 NKB]): their recomputed weights are exp(t - 1e30) = 0 */
 
-// Forward.  Workgroup = 4 waves, wave = QT tiles of 16 query rows, all of [ct0, ct0 + ntc) value-channel tiles in accumulators.
+// Forward.  Workgroup = NW waves, wave = QT tiles of 16 query rows, all of [ct0, ct0 + ntc) value-channel tiles in accumulators.
 // grid.x = B * ceil(N / (64 QT)), grid.z = ceil(NT / NTM); LDS: 2 x NTM x 2 KB (the packed H image of one 64-key block, double buffered).
 // EXACT: NT == NTM (C = 16 NTM) and dp <= 56 -- no per-tile guards, so the loop body is ONE basic block and the compiler interleaves the
 // LDS reads with the MFMAs; the logits / exp of block kb + 1 are issued in front of the P H products of block kb (independent work for the
 // scheduler to put into the MFMA shadow).
-template <int QT, int NTM, bool EXACT>
-__global__ __launch_bounds__(256) void sa_fwd_kernel(const u16* __restrict__ qkv, int cq, int dp, int C, int N, int NKB, int NT, int B,
+template <int QT, int NTM, bool EXACT, int NW>
+__global__ __launch_bounds__(64 * NW) void sa_fwd_kernel(const u16* __restrict__ qkv, int cq, int dp, int C, int N, int NKB, int NT, int B,
                                                      const u32x4* __restrict__ vpack, u16* __restrict__ O, int o_cs, int o_co,
                                                      float* __restrict__ lse) {
     extern __shared__ u32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, g = lane >> 4;
     int b, qblk;
-    wg_image_block((N + 64 * QT - 1) / (64 * QT), B, b, qblk);
+    wg_image_block((N + 16 * NW * QT - 1) / (16 * NW * QT), B, b, qblk);
     const int ct0 = EXACT ? 0 : blockIdx.z * NTM, ntc = EXACT ? NTM : min(NTM, NT - ct0);
-    const int qw = (qblk * 4 + w) * (16 * QT);
+    const int qw = (qblk * NW + w) * (16 * QT);
     const u16* qb = qkv + (size_t)b * N * cq;
     const u32x4* vb = vpack + (size_t)b * NKB * NT * 128;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -195,22 +215,22 @@ __global__ __launch_bounds__(256) void sa_fwd_kernel(const u16* __restrict__ qkv
     }
 
     // ---- pass 2
-    constexpr int NS = NTM / 2;
+    constexpr int NTHR = 64 * NW, NS = (NTM * 128 + NTHR - 1) / NTHR;
     u32x4 stg[NS];
     auto stage_ld = [&](int kb) {
         const u32x4* src = vb + ((size_t)kb * NT + ct0) * 128;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int idx = tid + i * 256;
-            stg[i] = (EXACT || idx < ntc * 128) ? src[idx] : zero4;
+            const int idx = tid + i * NTHR;
+            stg[i] = ((EXACT && NTM * 128 % NTHR == 0) || idx < ntc * 128) ? src[idx] : zero4;
         }
     };
     auto stage_st = [&](int bi) {
         u32x4* d = lds + bi * (NTM * 128);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int idx = tid + i * 256;
-            if (EXACT || idx < ntc * 128) d[idx] = stg[i];
+            const int idx = tid + i * NTHR;
+            if ((EXACT && NTM * 128 % NTHR == 0) || idx < ntc * 128) d[idx] = stg[i];
         }
     };
     f32x4 acc[QT][NTM];
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(256) void sa_fwd_kernel(const u16* __restrict__ qkv
 
     // ---- epilogue: O = acc / l, lse = m + log l.  acc[qt][ct][r] belongs to query 4 g + r, channel 16 ct + jl; l of query q sits in lane q
     const int Np = NKB * 64;
+    if (EXACT) __syncthreads();                              // the staging buffers become the row-store regions of the waves
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l = lsum[qt];
@@ -311,16 +332,23 @@ __global__ __launch_bounds__(256) void sa_fwd_kernel(const u16* __restrict__ qkv
         float li[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) li[r] = __shfl(linv, 4 * g + r);
+        if constexpr (EXACT) {
+            constexpr int PAD = NW * (NTM * 16 + 8) * 32 <= 2 * NTM * 2048 ? 8 : 0;
+            const int j0 = qw + qt * 16;
+            rows_out<NTM, PAD>(reinterpret_cast<u16*>(lds) + w * 16 * (NTM * 16 + PAD), acc[qt], li, lane, O + ((size_t)b * N + j0) * o_cs + o_co, (size_t)o_cs,
+                               N - j0, NTM * 16);
+        } else {
 #pragma unroll
-        for (int ct = 0; ct < NTM; ++ct)
-            if (EXACT || ct < ntc) {
-                const int c = (ct0 + ct) * 16 + jl;
+            for (int ct = 0; ct < NTM; ++ct)
+                if (ct < ntc) {
+                    const int c = (ct0 + ct) * 16 + jl;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = qw + qt * 16 + 4 * g + r;
-                    if (j < N && (EXACT || c < C)) st_bf(O + ((size_t)b * N + j) * o_cs + o_co + c, acc[qt][ct][r] * li[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = qw + qt * 16 + 4 * g + r;
+                        if (j < N && c < C) st_bf(O + ((size_t)b * N + j) * o_cs + o_co + c, acc[qt][ct][r] * li[r]);
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -496,19 +524,26 @@ __global__ __launch_bounds__(256) void sa_bwd_kv_kernel(const u16* __restrict__ 
     }
     // acc[ct][r]: key key0 + 4 g + r, channel 16 ct + il
     u16* db = dqkv + (size_t)b * N * cq;
+    if constexpr (EXACT) {                                   // (the loop ended on a barrier: nobody reads the step images any more)
+        const float one[4] = {1.f, 1.f, 1.f, 1.f};
+        u16* wl = reinterpret_cast<u16*>(lds) + w * 16 * (NTM * 16 + 8);
+        rows_out<NTM, 8>(wl, accH, one, lane, db + (size_t)key0 * cq + 2 * dp, (size_t)cq, N - key0, NTM * 16);
+        rows_out<4, 8>(wl, accF, one, lane, db + (size_t)key0 * cq, (size_t)cq, N - key0, dp);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int key = key0 + 4 * g + r;
-        if (key >= N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 4 * g + r;
+            if (key >= N) continue;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int c = ct * 16 + il;
-            if (c < dp) st_bf(db + (size_t)key * cq + c, accF[ct][r]);
-        }
+            for (int ct = 0; ct < 4; ++ct) {
+                const int c = ct * 16 + il;
+                if (c < dp) st_bf(db + (size_t)key * cq + c, accF[ct][r]);
+            }
 #pragma unroll
-        for (int ct = 0; ct < NTM; ++ct) {
-            const int c = ct * 16 + il;
-            if (EXACT || (ct < NTr && c < C)) st_bf(db + (size_t)key * cq + 2 * dp + c, accH[ct][r]);
+            for (int ct = 0; ct < NTM; ++ct) {
+                const int c = ct * 16 + il;
+                if (ct < NTr && c < C) st_bf(db + (size_t)key * cq + 2 * dp + c, accH[ct][r]);
+            }
         }
     }
 }
@@ -651,14 +686,19 @@ __global__ __launch_bounds__(256) void sa_bwd_q_kernel(const u16* __restrict__ q
         __syncthreads();
     }
     u16* db = dqkv + (size_t)b * N * cq;
+    if constexpr (EXACT) {
+        const float one[4] = {1.f, 1.f, 1.f, 1.f};
+        rows_out<4, 8>(reinterpret_cast<u16*>(lds) + w * 16 * (4 * 16 + 8), accG, one, lane, db + (size_t)q0 * cq + dp, (size_t)cq, N - q0, dp);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = q0 + 4 * g + r;
-        if (j >= N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int j = q0 + 4 * g + r;
+            if (j >= N) continue;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int c = ct * 16 + jl;
-            if (c < dp) st_bf(db + (size_t)j * cq + dp + c, accG[ct][r]);
+            for (int ct = 0; ct < 4; ++ct) {
+                const int c = ct * 16 + jl;
+                if (c < dp) st_bf(db + (size_t)j * cq + dp + c, accG[ct][r]);
+            }
         }
     }
 }
@@ -695,15 +735,15 @@ extern "C" int unet_sa_rowdot_bf16(const unet_bf16* a, int a_cs, int a_co, const
     return UNET_OK;
 }
 
-template <int QT, int NTM, bool EXACT>
+template <int QT, int NTM, bool EXACT, int NW>
 static int launch_sa_fwd(const u16* qkv, int cq, int dp, int C, int B, int N, const u32x4* vpack, u16* O, int o_cs, int o_co, float* lse, hipStream_t st) {
-    auto kern = sa_fwd_kernel<QT, NTM, EXACT>;
+    auto kern = sa_fwd_kernel<QT, NTM, EXACT, NW>;
     static unsigned long long configured = 0;
     if (unet::first_use_on_device(&configured))
         UNET_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const int NT = (C + 15) / 16, per = unet::cdiv(N, 64 * QT);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * per), 1, EXACT ? 1 : unet::cdiv(NT, NTM)), dim3(256), (size_t)2 * NTM * 2048, st, qkv, cq, dp, C, N, nkb_of(N), NT,
-                       B, vpack, O, o_cs, o_co, lse);
+    const int NT = (C + 15) / 16, per = unet::cdiv(N, 16 * NW * QT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * per), 1, EXACT ? 1 : unet::cdiv(NT, NTM)), dim3(64 * NW), (size_t)2 * NTM * 2048, st, qkv, cq, dp, C, N, nkb_of(N),
+                       NT, B, vpack, O, o_cs, o_co, lse);
     UNET_CHECK_LAUNCH();
     return UNET_OK;
 }
@@ -713,9 +753,11 @@ extern "C" int unet_sa_fwd_bf16(const unet_bf16* qkv, int cq, int dp, int C, int
     UNET_CHECK_ARG(qkv && vpack && O && lse && sa_shape_ok(cq, dp, C, B, N) && unet::slice_ok_v(o_cs, o_co, C, 8) && unet::aligned16(qkv) &&
                        unet::aligned16(vpack),
                    "sa_fwd_bf16: bad args (dp <= 64, C <= 512, channel counts multiples of 8)");
-    if (C == 384 && dp <= 56) return launch_sa_fwd<2, 24, true>((const u16*)qkv, cq, dp, C, B, N, (const u32x4*)vpack, (u16*)O, o_cs, o_co, lse, ST);
-    if (C <= 384) return launch_sa_fwd<2, 24, false>((const u16*)qkv, cq, dp, C, B, N, (const u32x4*)vpack, (u16*)O, o_cs, o_co, lse, ST);
-    return launch_sa_fwd<1, 32, false>((const u16*)qkv, cq, dp, C, B, N, (const u32x4*)vpack, (u16*)O, o_cs, o_co, lse, ST);
+#define SA_FWD(QT_, NTM_, EX_, NW_) launch_sa_fwd<QT_, NTM_, EX_, NW_>((const u16*)qkv, cq, dp, C, B, N, (const u32x4*)vpack, (u16*)O, o_cs, o_co, lse, ST)
+    if (C == 384 && dp <= 56) return SA_FWD(2, 24, true, 4);     // (8 waves x 1 query tile, two waves per SIMD: measured level, 510 vs 505 us)
+    if (C <= 384) return SA_FWD(2, 24, false, 4);
+    return SA_FWD(1, 32, false, 4);
+#undef SA_FWD
 }
 
 template <int NTM, bool EXACT>
