@@ -48,6 +48,7 @@ SHAPES = [
     (1, 10, 13, 48, 48, 384),       # 130 positions: ragged key block and ragged query tiles
     (3, 25, 25, 54, 56, 432),       # xresnet34_deep: 54 -> 56 query lanes, 27 channel tiles (the 32-tile instantiation), 625 positions
     (1, 8, 8, 16, 16, 128),         # narrow: one channel-tile group, unused steps of the reduction guarded off
+    (1, 96, 96, 48, 48, 384),       # 9216 positions (a 768 x 768 tile): 144 key blocks, nothing of size N x N anywhere but in this test's reference
 ]
 
 
