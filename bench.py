@@ -595,9 +595,12 @@ def main():
             def sa_line(dtype):
                 # the reference's SHIPPED default is self_attention=True (params_and_main.py:81-83); SURVEY 8(d): report it separately
                 r = step_bench(ARCH, N_IN, N_CLS, SIZE, args.batch, dtype, 5, 2, 0, 1, dev, log, probe=False, self_attention=True)
-                return step_line(r, args.batch, 5, GFLOP_PER_TILE_FWD_BWD + 3 * 16.0, PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS,
-                                 "cfg2 with DynamicUnet(self_attention=True): SelfAttention(384) at 64x64 positions behind UnetBlock 1 "
-                                 "(+ ~16 GFLOP fwd per tile)", dtype)
+                o = step_line(r, args.batch, 5, GFLOP_PER_TILE_FWD_BWD + 3 * 16.0, PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS,
+                              "cfg2 with DynamicUnet(self_attention=True): SelfAttention(384) at 64x64 positions behind UnetBlock 1 "
+                              "(+ ~16 GFLOP fwd per tile)", dtype)
+                o["attention"] = ("fused kernels (csrc/attention.hip: no N x N tensor in HBM)" if dtype == "bf16"
+                                  else "blockwise products on the conv / weight-gradient kernels (fp32 parity path)")
+                return o
 
             def cfg4_line():
                 # BASELINE configs[3]: 8-ch 1024x1024 tiles, xresnet50 encoder, 10 classes, fp32

@@ -122,6 +122,44 @@ def test_tiff_decoders_against_libtiff_on_random_images(tmp_path):
     assert n == 120
 
 
+def test_float_predictor_3_against_libtiff(tmp_path):
+    """Predictor 3 (floating-point horizontal differencing: what GDAL writes for float rasters with PREDICTOR=3, e.g. the probability rasters of
+    reference predict.py:19-52 re-compressed): files written by Pillow's libtiff binding with LZW / Deflate read back bit for bit (Pillow writes
+    one float band; the multi-sample stride is the next test's)"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    n = 0
+    for trial in range(10):
+        H, W = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        a = (rng.normal(size=(H, W)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+        if trial % 3 == 0:
+            a[rng.integers(0, H), rng.integers(0, W)] = np.float32("inf")
+        for comp in ("tiff_lzw", "tiff_adobe_deflate"):
+            Image.fromarray(a).save(tmp_path / "f.tif", format="TIFF", compression=comp, tiffinfo={317: 3})
+            got, meta = read_tiff(tmp_path / "f.tif")
+            assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), a.view(np.uint32)), (trial, comp, a.shape)
+            n += 1
+    assert n == 20
+
+
+def test_float_predictor_3_multi_sample_rows():
+    """the byte differencing of Predictor 3 runs with a stride of samples-per-pixel bytes over the byte-plane row: checked against the encoder
+    of the specification (Adobe TIFF Technical Note 3) restated here, float32 and float64, 1 / 3 / 4 samples per pixel"""
+    from unet_amd.tiffio import _unpredict_float
+    rng = np.random.default_rng(11)
+    for dt in (np.dtype("<f4"), np.dtype("<f8")):
+        for pix in (1, 3, 4):
+            rows, cols = 5, 9
+            a = rng.normal(size=(rows, cols, pix)).astype(dt)
+            be = a.astype(dt.newbyteorder(">")).view(np.uint8).reshape(rows, cols * pix, dt.itemsize)
+            planes = np.moveaxis(be, 2, 1).reshape(rows, -1).astype(np.int16)                # byte 0 of every sample, then byte 1, ...
+            enc = planes.copy()
+            enc[:, pix:] = planes[:, pix:] - planes[:, :-pix]
+            raw = (enc % 256).astype(np.uint8).reshape(-1)
+            got = _unpredict_float(raw, rows, cols, pix, dt)
+            assert np.array_equal(got, a), (dt, pix)
+
+
 def test_write_tiff_switches_to_bigtiff_and_both_forms_are_read_by_libtiff(tmp_path):
     """write_tiff emits BigTIFF when the data would not fit 32-bit offsets (GDAL's BIGTIFF=IF_NEEDED: the all-classes probabilities of a
     20000 x 20000 scene are 8 GB); both header forms are read back by this reader and by Pillow's libtiff (single-band files: Pillow has

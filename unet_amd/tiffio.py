@@ -5,7 +5,7 @@ writes them with GDAL; ``create_tiles_unet.py:252-434`` opens whole scenes with 
 strips or tiles, chunky or planar, 8/16/32/64-bit unsigned / signed / float samples, the compressions GDAL writes by default or
 on request -- none, LZW (5), Deflate (8 / 32946), PackBits (32773) -- with horizontal differencing (Predictor 2), plus the GeoTIFF
 georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922, GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams
-34737, GDAL_NODATA 42113) which are passed through verbatim.  Anything else (JPEG, floating-point predictor 3, ...) raises loudly.
+34737, GDAL_NODATA 42113) which are passed through verbatim.  Floating-point differencing (Predictor 3) is undone on float samples.  Anything else (JPEG, ...) raises loudly.
 The byte-oriented decoders are C functions (csrc/tiff_codecs.hip: in libunet_hip.so, and linked by g++ alone into the host-only
 libunet_tiff.so); files are memory-mapped for reading and written uncompressed.
 """
@@ -125,6 +125,17 @@ def _unpredict(block: np.ndarray, predictor: int, path) -> np.ndarray:
     return np.cumsum(block, axis=1, dtype=block.dtype)
 
 
+def _unpredict_float(raw: np.ndarray, rows: int, cols: int, pix: int, dt: np.dtype) -> np.ndarray:
+    """undo Predictor 3 (floating-point horizontal differencing, Adobe Photoshop TIFF Technical Note 3; what GDAL writes with PREDICTOR=3):
+    every row is stored as byte planes -- byte 0 (the most significant) of all its samples, then byte 1, ... -- independent of the file's byte
+    order, and that byte row is differenced with a stride of `pix` bytes.  Returns [rows, cols, pix] in native byte order."""
+    bps, n = dt.itemsize, cols * pix
+    acc = np.cumsum(raw[:rows * n * bps].reshape(rows, n * bps // pix, pix), axis=1, dtype=np.uint8)          # (wraps modulo 256, as the bytes do)
+    planes = acc.reshape(rows, bps, n)
+    be = np.ascontiguousarray(np.moveaxis(planes, 1, 2))                                                          # [rows, n, bps] big-endian samples
+    return be.view(np.dtype(f">f{bps}")).reshape(rows, cols, pix).astype(dt.newbyteorder("="))
+
+
 def _geo_meta(tags) -> Dict:
     meta = {"tags": {t: tags[t] for t in GEO_TAGS if t in tags}, "geotransform": None}
     if 33550 in tags and 33922 in tags:
@@ -201,6 +212,9 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
         raw = decode(b[off:off + nbytes], need) if comp != 1 else b[off:off + need]
         if len(raw) < need:
             raise ValueError(f"{path}: strip / tile holds {len(raw)} bytes, {need} expected")
+        if predictor == 3 and dt.kind == "f":
+            return _unpredict_float(np.frombuffer(raw, dtype=np.uint8, count=need) if not isinstance(raw, np.ndarray) else raw[:need].view(np.uint8),
+                                    rows, cols, pix, dt)
         t = raw[:need].view(dt).reshape(rows, cols, pix)
         return _unpredict(t.astype(native, copy=False), predictor, path)
 
