@@ -13,11 +13,14 @@ def short(n):
 
 
 def window(first_pat, last_pat):
-    idx = [i for i, r in enumerate(rows) if first_pat in r["Kernel_Name"]]
     jdx = [i for i, r in enumerate(rows) if last_pat in r["Kernel_Name"]]
-    if not idx or not jdx:
+    if not jdx:
         return
-    i0, i1 = idx[-1], jdx[-1]
+    i1 = jdx[-1]
+    idx = [i for i, r in enumerate(rows[:i1]) if first_pat in r["Kernel_Name"]]          # the last `first` in front of the last `last`
+    if not idx:
+        return
+    i0 = idx[-1]
     t0 = int(rows[max(0, i0 - before)]["Start_Timestamp"])
     last_end = {}
     for r in rows[max(0, i0 - before):i1 + after]:

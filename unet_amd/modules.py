@@ -915,17 +915,23 @@ class SelfAttention(nn.Module):
         N, CQ = H * W, 2 * c8p + C_
         qkv, O = ctx.act(self, "qkv", B, H, W, CQ), ctx.act(self, "O", B, H, W, C_)
         gvec, zvec = ctx.vec(self, "gvec", C_), ctx.vec(self, "zvec", C_)
-        ops.dot(O, dout, self.gamma.grad, ctx.workspace(ops.colsum_workspace(O.P, C_)))        # dL/dgamma = sum O * dout
+        use_fused = bool(ctx.saved.get((id(self), "fused"), False))
+        if use_fused:
+            # one pass over dout and O gives both the per-row term of the softmax adjoint and dL/dgamma: Dp_j = dout_j . O_j,
+            # dgamma = sum_j Dp_j, D_j = dO_j . O_j = gamma Dp_j (two torch launches on B x N floats instead of a 50 MB dot + its reduction)
+            lse, D = ctx.vec(self, "sa_lse", B * ops.sa_rows(N)), ctx.vec(self, "sa_D", B * ops.sa_rows(N))
+            ops.sa_rowdot(dout, O, D)                                                         # (rows past N stay 0)
+            torch.sum(D.view(1, -1), dim=1, out=self.gamma.grad)
+            D.mul_(self.gamma.data)
+        else:
+            ops.dot(O, dout, self.gamma.grad, ctx.workspace(ops.colsum_workspace(O.P, C_)))    # dL/dgamma = sum O * dout
         dO = ctx.tmp(B, H, W, C_)
         ops.affine_act(dout, dO, gvec, zvec)
         dqkv = ctx.tmp(B, H, W, CQ)
-        use_fused = bool(ctx.saved.get((id(self), "fused"), False))
         chunks = [] if use_fused else self._chunks(B, H, W)
         if use_fused:
             # dH, dF per key block and dG per query block in two launches, weights recomputed from lse; the packed images are the
             # operands of the products that sum over positions (dO for dH, G for dF, F for dG)
-            lse, D = ctx.vec(self, "sa_lse", B * ops.sa_rows(N)), ctx.vec(self, "sa_D", B * ops.sa_rows(N))
-            ops.sa_rowdot(dO, O, D)
             pk = ctx.vec(self, "sa_pack", B * ops.sa_pack_elems(N, C_), dtype=dt)               # the forward's image of H is not needed any more
             gpk, fpk = (ctx.vec(self, t, B * ops.sa_pack_elems(N, c8p), dtype=dt) for t in ("sa_gpack", "sa_fpack"))
             ops.sa_pack(dO, pk)
