@@ -175,3 +175,42 @@ def test_fused_module_against_the_blockwise_path(size, arch):
     print(f"fused vs blockwise {arch} {size}: logits rel-L2 {rel:.3e}, loss {l1:.6f} vs {l0:.6f}, gradient cos {cos:.6f}, attention parameters {sa}")
     assert rel <= 5e-3 and abs(l1 - l0) <= 2e-3 * abs(l0)
     assert cos >= 0.999 and len(sa) == 4 and all(v >= 0.99 for v in sa.values()), sa
+
+
+def test_fused_attention_step_repeats_bit_for_bit():
+    """No atomics in the fused backward: two models built from the same state give the same gradient BITS after one training step.
+    TrainStep(use_graph=True) on a model with SelfAttention falls back to the eager launch stream with a warning (capturing the spectral-norm
+    autograd ends in a segmentation fault of hipStreamEndCapture on this stack: scripts/graph_sa_probe.py) and trains."""
+    import warnings
+    from oracle import unet_oracle as O
+    from unet_amd.model import HipDynamicUnet
+    from unet_amd.optimizer import FlatAdam
+    from unet_amd.trainer import TrainStep
+    torch.manual_seed(5)
+    size = (128, 160)                                      # SelfAttention(384) on 16 x 20 = 320 positions
+    sd = O.DynamicUnet("xresnet34", 3, 4, size, self_attention=True).state_dict()
+    for k in sd:
+        if k.endswith("gamma"):
+            sd[k] = torch.tensor([0.7])                    # (fastai initialises gamma to 0: the attention branch would carry no signal)
+    x, y = O.synthetic_batch(2, 3, size[0], size[1], 4)
+    w = torch.tensor([0.1, 0.4, 0.3, 0.2])
+    grads = []
+    for _ in range(2):
+        m = HipDynamicUnet("xresnet34", 3, 4, size, self_attention=True, act_dtype="bf16")
+        m.load_state_dict(sd)
+        m.train()
+        m.forward_loss_backward(x.cuda(), y.cuda(), w.cuda())
+        torch.cuda.synchronize()
+        grads.append(torch.cat([p.grad.detach().flatten() for p in m.parameters()]).cpu())
+    assert torch.equal(grads[0], grads[1])
+    assert grads[0].abs().max().item() > 0
+    m = HipDynamicUnet("xresnet34", 3, 4, size, self_attention=True, act_dtype="bf16")
+    m.load_state_dict(sd)
+    m.train()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        step = TrainStep(m, FlatAdam(m, [1e-5, 3e-5, 1e-4]), None, 1, use_graph=True)
+    assert not step.use_graph and any("SelfAttention" in str(r.message) for r in rec)
+    losses = [float(step(x.cuda(), y.cuda()).item()) for _ in range(4)]
+    print("SA model, TrainStep(use_graph=True) -> eager:", losses)
+    assert step._graph is None and all(l == l for l in losses) and losses[-1] < losses[0]

@@ -994,9 +994,13 @@ class SelfAttention(nn.Module):
         ops.conv2d_dgrad(dqkv, wpd, dx, 1, 1, res=dout)                                           # + identity branch
         ctx.free(dO)
         ctx.free(dqkv)
-        for seq in (self.query, self.key, self.value):
-            seq[0].weight_orig.grad.zero_()
-        wcat.backward(dw)                                                                         # spectral-norm backward (torch, tiny)
+        # spectral-norm backward (torch, tiny).  torch.autograd.grad, not .backward(): no AccumulateGrad nodes (they remember the stream of their
+        # first use and warn about it on any other stream).  A hipGraph capture of a step with this module still dies inside hipStreamEndCapture on
+        # ROCm 7.2 / torch 2.10 (with .backward(), with .grad(), with the engine single-threaded; blockwise and fused, fp32 and bf16):
+        # TrainStep(use_graph=True) therefore runs models with SelfAttention eagerly (trainer.py)
+        leaves = [seq[0].weight_orig for seq in (self.query, self.key, self.value)]
+        for p, g in zip(leaves, torch.autograd.grad(wcat, leaves, dw)):
+            p.grad.copy_(g)
         return dx
 
 # --------------------------------------------------------------------------

@@ -29,6 +29,15 @@ class TrainStep:
         self.focal_gamma: Optional[float] = None    # FocalLossFlat(gamma) instead of the weighted cross-entropy (params_and_main.py:87-89)
         self.use_graph = use_graph and world == 1
         if self.use_graph:
+            from .modules import SelfAttention
+            if any(isinstance(mod, SelfAttention) for mod in model.modules()):
+                # the spectral-norm power iteration and its adjoint are torch autograd inside the step: capturing them ends in a segmentation
+                # fault of hipStreamEndCapture on this stack (scripts/graph_sa_probe.py).  Eager is what the measurements use anyway
+                # (a replayed graph is not faster: DESIGN 6)
+                import warnings
+                warnings.warn("TrainStep(use_graph=True): models with SelfAttention run eagerly (torch autograd inside the step is not capturable here)")
+                self.use_graph = False
+        if self.use_graph:
             # a replayed graph has no host in the loop: the second stream of the weight gradients buys nothing there and its
             # fork / join nodes cost (cfg1 fp32: 7.51 ms per replay without, 7.69 with; bf16: 4.00 / 4.33)
             model.ctx.wgrad_overlap = False
