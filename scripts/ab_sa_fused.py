@@ -13,9 +13,10 @@ quiet = lambda m: None
 
 def run(dt, sa, fused):
     SelfAttention.fused = fused
-    r = B.step_bench("xresnet34", 4, 5, 512, 16, dt, steps, 3, 0, 1, dev, quiet, probe=False, self_attention=sa)
+    r = B.step_bench(os.environ.get("UNET_AB_ARCH", "xresnet34"), 4, 5, 512, int(os.environ.get("UNET_AB_BATCH", "16")), dt, steps, 3, 0, 1, dev, quiet,
+                     probe=False, self_attention=sa)
     torch.cuda.empty_cache()
-    return 16 * steps / r["dt"], r["dt"] / steps * 1e3, r["loss"]
+    return int(os.environ.get("UNET_AB_BATCH", "16")) * steps / r["dt"], r["dt"] / steps * 1e3, r["loss"]
 
 
 for dt in (sys.argv[2:] or ["bf16"]):

@@ -786,7 +786,7 @@ class SelfAttention(nn.Module):
     tiny matrices and stays in torch; its backward is torch autograd on those matrices, fed with the HIP weight gradient."""
     forward = _no_forward
     budget_elems = 1 << 28          # floats per N x N scratch buffer (1 GiB); tests lower it to force row blocks
-    fused = True                    # bf16 storage, C <= 512: the fused kernels of csrc/attention.hip (no N x N tensor); False = blockwise products
+    fused = True                    # bf16 storage, C = 384: the fused kernels of csrc/attention.hip (no N x N tensor); False = blockwise products; "always" = every width the library takes
 
     def __init__(self, n_channels):
         super().__init__()
@@ -880,7 +880,10 @@ class SelfAttention(nn.Module):
         qkv = ctx.act(self, "qkv", B, H, W, CQ)
         ops.conv2d(x, wp, qkv, 1)
         O = ctx.act(self, "O", B, H, W, C_)
-        use_fused = bool(self.fused) and dt == torch.bfloat16 and ops.sa_fused_supported(c8p, C_)
+        # the fused kernels where they are faster: the instantiations without per-tile guards (C = 384, the width of every xresnet18 / 34 network).
+        # Other widths the library accepts (C <= 512: xresnet34_deep's 432) run its guarded instantiations 5 % SLOWER than the blockwise products
+        # (361 vs 378 tiles/s at cfg2 geometry, batch 8): they stay blockwise unless fused == "always" (the kernel tests call the library directly)
+        use_fused = bool(self.fused) and dt == torch.bfloat16 and ops.sa_fused_supported(c8p, C_) and ((C_ == 384 and c8p <= 56) or self.fused == "always")
         ctx.saved[(id(self), "fused")] = use_fused
         chunks = [] if use_fused else self._chunks(B, H, W)
         if use_fused:
