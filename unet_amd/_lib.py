@@ -10,6 +10,9 @@ import os
 import re
 from pathlib import Path
 
+import torch  # noqa: F401  -- FIRST: torch ships its own libamdhip64; loading libunet_hip.so before it binds /opt/rocm's copy and the process ends
+#                    up with two HIP runtimes (the second one reports "no ROCm-capable device": seen with build() + smoke() in one process)
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libunet_hip.so"
 HEADER = _HERE.parent / "include" / "unet_hip.h"
