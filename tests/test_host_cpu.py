@@ -287,3 +287,38 @@ def test_deep_encoder_with_self_attention_builds():
     sa = [b.sa for b in m.layers[4:10] if b.sa is not None]
     assert len(sa) == 1 and (sa[0].C, sa[0].c8, sa[0].c8p) == (432, 54, 56)
     HipDynamicUnet("xresnet34", 3, 3, (64, 64), self_attention=True, device="cpu")        # the shipped configuration
+
+
+def test_fused_attention_entry_points_validate_on_the_host():
+    """unet_sa_* (csrc/attention.hip): the shape rule (query / key lanes <= 64, value channels <= 512, multiples of 8), the size of the packed
+    image, and rejection of null pointers / channel slices that leave their buffer / unsupported widths before any launch"""
+    import unet_amd._lib as L
+    lib, fake = L.lib, 0x100000
+    assert lib.unet_sa_fused_supported(48, 384) == 1 and lib.unet_sa_fused_supported(56, 432) == 1 and lib.unet_sa_fused_supported(64, 512) == 1
+    assert lib.unet_sa_fused_supported(192, 1536) == 0 and lib.unet_sa_fused_supported(48, 380) == 0 and lib.unet_sa_fused_supported(52, 384) == 0
+    assert lib.unet_sa_fused_supported(0, 384) == 0 and lib.unet_sa_fused_supported(72, 384) == 0
+    # blocks of 64 positions x tiles of 16 channels x (2 steps x 64 lanes x 8 positions)
+    assert lib.unet_sa_pack_elems(4096, 384) == 64 * 24 * 1024 and lib.unet_sa_pack_elems(2500, 48) == 40 * 3 * 1024 and lib.unet_sa_pack_elems(1, 8) == 1024
+    ok = dict(qkv=fake, cq=480, dp=48, C=384, B=2, N=256)
+
+    def fwd(**kw):
+        a = dict(ok, vpack=fake, O=fake, o_cs=384, o_co=0, lse=fake)
+        a.update(kw)
+        return lib.unet_sa_fwd_bf16(a["qkv"], a["cq"], a["dp"], a["C"], a["B"], a["N"], a["vpack"], a["O"], a["o_cs"], a["o_co"], a["lse"], None)
+
+    for kw in (dict(qkv=None), dict(vpack=None), dict(lse=None), dict(B=0), dict(N=0), dict(dp=72), dict(dp=44), dict(C=520), dict(C=380),
+               dict(cq=400), dict(o_cs=380), dict(o_co=8), dict(qkv=fake + 2)):
+        assert fwd(**kw) == -1 and lib.unet_last_error(), kw
+
+    def bwd(**kw):
+        a = dict(ok, dO=fake, do_cs=384, do_co=0, dopack=fake, gpack=fake, fpack=fake, lse=fake, D=fake, dqkv=fake)
+        a.update(kw)
+        return lib.unet_sa_bwd_bf16(a["qkv"], a["cq"], a["dp"], a["C"], a["B"], a["N"], a["dO"], a["do_cs"], a["do_co"], a["dopack"], a["gpack"],
+                                    a["fpack"], a["lse"], a["D"], a["dqkv"], None)
+
+    for kw in (dict(dO=None), dict(gpack=None), dict(D=None), dict(dqkv=None), dict(dp=80), dict(C=1536), dict(do_cs=300), dict(lse=fake + 4)):
+        assert bwd(**kw) == -1 and lib.unet_last_error(), kw
+    assert lib.unet_sa_pack_bf16(None, 480, 0, 48, 2, 256, fake, None) == -1
+    assert lib.unet_sa_pack_bf16(fake, 480, 440, 48, 2, 256, fake, None) == -1          # the slice leaves the buffer
+    assert lib.unet_sa_pack_bf16(fake, 480, 0, 44, 2, 256, fake, None) == -1           # not whole 8-channel vectors
+    assert lib.unet_sa_rowdot_bf16(fake, 384, 0, fake, 384, 0, 2, 0, 384, fake, None) == -1
