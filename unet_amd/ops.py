@@ -301,7 +301,7 @@ def sa_rows(N: int) -> int:
 def sa_fwd(qkv: "TS", dp: int, C: int, vpack: torch.Tensor, O: "TS", lse: torch.Tensor):
     """O_j = sum_i softmax_i(G_j . F_i) H_i and lse_j for every image of the fused QKV buffer (F at channel 0, G at dp, H at 2 dp)"""
     assert qkv.bf16 and O.bf16 and qkv.co == 0 and lse.dtype == torch.float32 and O.C == C and O.P == qkv.P
-    assert lse.numel() >= qkv.N * sa_rows(qkv.H * qkv.W)
+    assert lse.numel() >= qkv.N * sa_rows(qkv.H * qkv.W) and vpack.numel() >= qkv.N * sa_pack_elems(qkv.H * qkv.W, C)
     check(lib.unet_sa_fwd_bf16(qkv.ptr, qkv.cs, dp, C, qkv.N, qkv.H * qkv.W, vpack.data_ptr(), O.ptr, O.cs, O.co, lse.data_ptr(), _stream()), "sa_fwd")
 
 
@@ -314,6 +314,9 @@ def sa_bwd(qkv: "TS", dp: int, C: int, dO: "TS", dopack: torch.Tensor, gpack: to
            D: torch.Tensor, dqkv: "TS"):
     """the gradient of the whole QKV buffer (dF | dG | dH slices) from dO = dL/dO, with the weights recomputed from lse"""
     assert qkv.bf16 and dO.bf16 and dqkv.bf16 and qkv.co == 0 and dqkv.co == 0 and dqkv.cs == qkv.cs and dO.C == C and dO.P == qkv.P
+    rows, N = qkv.N * sa_rows(qkv.H * qkv.W), qkv.H * qkv.W
+    assert lse.dtype == torch.float32 and D.dtype == torch.float32 and lse.numel() >= rows and D.numel() >= rows        # [B][64 ceil(N / 64)]
+    assert dopack.numel() >= qkv.N * sa_pack_elems(N, C) and min(gpack.numel(), fpack.numel()) >= qkv.N * sa_pack_elems(N, dp)
     check(lib.unet_sa_bwd_bf16(qkv.ptr, qkv.cs, dp, C, qkv.N, qkv.H * qkv.W, dO.ptr, dO.cs, dO.co, dopack.data_ptr(), gpack.data_ptr(),
                                fpack.data_ptr(), lse.data_ptr(), D.data_ptr(), dqkv.ptr, _stream()), "sa_bwd")
 
