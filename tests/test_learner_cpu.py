@@ -86,9 +86,12 @@ def test_geotiff_reads_foreign_writer(tmp_path):
     Image.fromarray(a).save(tmp_path / "z.tif", compression="tiff_lzw")          # (round 4: LZW / Deflate / PackBits strips are read)
     z, _ = read_tiff(tmp_path / "z.tif")
     assert np.array_equal(a, z)
-    Image.fromarray(rgb).save(tmp_path / "j.tif", compression="jpeg")            # what the reader does not decode raises, loudly
+    Image.fromarray(rgb).save(tmp_path / "j.tif", compression="jpeg")            # (round 5: JPEG-in-TIFF is read, to libtiff's own bytes)
+    j, _ = read_tiff(tmp_path / "j.tif")
+    assert np.array_equal(j, np.moveaxis(np.asarray(Image.open(tmp_path / "j.tif")), -1, 0))
+    Image.fromarray(a > 127).save(tmp_path / "g4.tif", compression="group4")     # what the reader does not decode raises, loudly
     with pytest.raises(NotImplementedError):
-        read_tiff(tmp_path / "j.tif")
+        read_tiff(tmp_path / "g4.tif")
 
 
 def test_dataloaders_batches(tmp_path):

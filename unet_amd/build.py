@@ -72,12 +72,15 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
 def build_host_codecs(force: bool = False) -> Path:
     """libunet_tiff.so: the TIFF strip decoders (csrc/tiff_codecs.hip is plain C++) linked by g++ alone -- unet_amd/tiffio.py loads it without
     the HIP runtime (tile preparation on a box without a GPU stack)."""
-    src, out = CSRC / "tiff_codecs.hip", LIBDIR / "libunet_tiff.so"
-    if force or _stale(out, [src, REPO / "include" / "unet_hip.h"]):
-        r = subprocess.run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "c++", str(src), "-I", str(REPO / "include"),
-                            "-o", str(out)], capture_output=True, text=True)
+    # csrc/host/tiff_jpeg.cpp (JPEG-in-TIFF, include/unet_tiff.h) exists in this library only: it is not device-path code and stays out of
+    # libunet_hip.so and of source_hash()
+    src, jpg, out = CSRC / "tiff_codecs.hip", CSRC / "host" / "tiff_jpeg.cpp", LIBDIR / "libunet_tiff.so"
+    LIBDIR.mkdir(exist_ok=True)
+    if force or _stale(out, [src, jpg, REPO / "include" / "unet_hip.h", REPO / "include" / "unet_tiff.h"]):
+        r = subprocess.run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-shared", "-fPIC", "-x", "c++", str(src), str(jpg),
+                            "-I", str(REPO / "include"), "-o", str(out)], capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"g++ failed for {src.name}:\n{r.stderr[-4000:]}")
+            raise RuntimeError(f"g++ failed for {src.name} / {jpg.name}:\n{r.stderr[-4000:]}")
     return out
 
 

@@ -5,9 +5,12 @@ writes them with GDAL; ``create_tiles_unet.py:252-434`` opens whole scenes with 
 strips or tiles, chunky or planar, 8/16/32/64-bit unsigned / signed / float samples, the compressions GDAL writes by default or
 on request -- none, LZW (5), Deflate (8 / 32946), PackBits (32773) -- with horizontal differencing (Predictor 2), plus the GeoTIFF
 georeferencing tags (ModelPixelScale 33550, ModelTiepoint 33922, GeoKeyDirectory 34735, GeoDoubleParams 34736, GeoAsciiParams
-34737, GDAL_NODATA 42113) which are passed through verbatim.  Floating-point differencing (Predictor 3) is undone on float samples.  Anything else (JPEG, ...) raises loudly.
-The byte-oriented decoders are C functions (csrc/tiff_codecs.hip: in libunet_hip.so, and linked by g++ alone into the host-only
-libunet_tiff.so); files are memory-mapped for reading and written uncompressed.
+34737, GDAL_NODATA 42113) which are passed through verbatim.  Floating-point differencing (Predictor 3) is undone on float samples.
+JPEG-in-TIFF (Compression 7 with the JPEGTables tag: baseline 8-bit, what GDAL's COMPRESS=JPEG writes; PhotometricInterpretation 6 comes back
+as RGB, as it does from GDAL) is decoded to the bytes libtiff + libjpeg produce (csrc/host/tiff_jpeg.cpp).  Anything else (old-style JPEG 6,
+12-bit / progressive JPEG, CCITT, ...) raises loudly.
+The byte-oriented decoders are C functions (csrc/tiff_codecs.hip: in libunet_hip.so, and linked by g++ alone -- together with the JPEG
+decoder -- into the host-only libunet_tiff.so); files are memory-mapped for reading and written uncompressed.
 """
 from __future__ import annotations
 
@@ -83,6 +86,12 @@ def _codecs():
             from ._lib import lib
         for fn in (lib.unet_tiff_lzw_decode, lib.unet_tiff_packbits_decode):
             fn.restype, fn.argtypes = C.c_longlong, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+        try:                       # include/unet_tiff.h: the JPEG decoder lives in the host-only library alone
+            lib.unet_tiff_jpeg_decode.restype = C.c_longlong
+            lib.unet_tiff_jpeg_decode.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+            lib.has_jpeg = True
+        except AttributeError:     # libunet_hip.so, or a libunet_tiff.so built before the decoder existed
+            lib.has_jpeg = False
         _codec_lib = lib
     return _codec_lib
 
@@ -113,7 +122,40 @@ def _decoder(comp: int, path):
                 raise ValueError(f"{path}: corrupt {'LZW' if comp == 5 else 'PackBits'} data")
             return dst[:got]
         return dec
-    raise NotImplementedError(f"{path}: TIFF compression {comp} is not supported (none, LZW, Deflate and PackBits are)")
+    raise NotImplementedError(f"{path}: TIFF compression {comp} is not supported (none, LZW, Deflate, PackBits and new-style JPEG (7) are)")
+
+
+def _jpeg_decoder(tags, path):
+    """(compressed strip / tile, rows, cols, samples per pixel) -> uint8 [rows', cols', samples] with the frame size the JPEG stream itself states
+    (libtiff writes a short last strip as a short frame, tiles always whole).  TIFF Technical Note 2: tag 347 holds the shared tables."""
+    import ctypes as C
+    lib = _codecs()
+    if not lib.has_jpeg:
+        raise RuntimeError(f"{path}: JPEG-in-TIFF needs unet_amd/lib/libunet_tiff.so (python -m unet_amd.build)")
+    tables = np.array(tags[347], dtype=np.uint8) if 347 in tags else None
+    ycc = 1 if tags.get(262, (1,))[0] == 6 else 0
+
+    import threading
+    tl = threading.local()          # one output buffer per decoding thread (a fresh >= 128 KB array per strip is an mmap + its page faults, and
+                                    # those serialise the threads of a large scene); the caller copies the block out before its next call
+
+    def dec(raw, rows, cols, pix):
+        src = np.ascontiguousarray(raw)
+        cap = rows * cols * pix
+        dst = getattr(tl, "buf", None)
+        if dst is None or dst.size < cap:
+            dst = tl.buf = np.empty(cap, dtype=np.uint8)
+        dims = (C.c_int * 3)()
+        got = lib.unet_tiff_jpeg_decode(None if tables is None else tables.ctypes.data, 0 if tables is None else tables.size, src.ctypes.data,
+                                        src.size, ycc, dst.ctypes.data, cap, dims)
+        if got == -2:
+            raise NotImplementedError(f"{path}: this JPEG process is not supported (baseline / extended sequential Huffman, 8 bit, "
+                                      f"chroma at 1:1, 2:1 horizontally or 2:1 in both directions are)")
+        h, w, c = dims
+        if got < 0 or c != pix or h > rows or w > cols:
+            raise ValueError(f"{path}: corrupt JPEG strip / tile (decoder returned {got}, frame {h} x {w} x {c} for a {rows} x {cols} x {pix} block)")
+        return dst[:got].reshape(h, w, c)
+    return dec
 
 
 def _unpredict(block: np.ndarray, predictor: int, path) -> np.ndarray:
@@ -182,6 +224,8 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     fmt = tags.get(339, (1,))[0]
     comp, predictor = tags.get(259, (1,))[0], tags.get(317, (1,))[0]
     planar = tags.get(284, (1,))[0]
+    if bits not in (8, 16, 32, 64) or len(set(tags.get(258, (bits,)))) != 1:
+        raise NotImplementedError(f"{path}: {tags.get(258)}-bit samples are not supported (8 / 16 / 32 / 64, the same for every band, are)")
     dt = _dtype(bits, fmt, bo)
     native = dt.newbyteorder("=")
     planes = spp if planar == 2 else 1
@@ -203,11 +247,17 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
         if contiguous and offs[0] + total <= b.size:
             return finish(b[offs[0]:offs[0] + total].view(dt).reshape(planes, H, W, pix))
 
-    decode = _decoder(comp, path)
+    if comp == 7:
+        if bits != 8 or predictor != 1:
+            raise NotImplementedError(f"{path}: JPEG-in-TIFF with {bits}-bit samples / predictor {predictor} is not supported")
+        jpeg = _jpeg_decoder(tags, path)
+    decode = _decoder(comp, path) if comp != 7 else None
     out = np.zeros((planes, H, W, pix), dtype=native)
 
     def block(off, nbytes, rows, cols):
         """one strip / tile as [rows, cols, pix] in native byte order, decompressed and un-differenced"""
+        if comp == 7:
+            return jpeg(b[off:off + nbytes], rows, cols, pix)
         need = rows * cols * pix * dt.itemsize
         raw = decode(b[off:off + nbytes], need) if comp != 1 else b[off:off + need]
         if len(raw) < need:
@@ -245,7 +295,10 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
 
     def run(chunk):
         for off, nbytes, brows, bcols, p, r0, h, c0, w in chunk:
-            out[p, r0:r0 + h, c0:c0 + w] = block(off, nbytes, brows, bcols)[:h, :w]
+            t = block(off, nbytes, brows, bcols)
+            if t.shape[0] < h or t.shape[1] < w:
+                raise ValueError(f"{path}: strip / tile decodes to {t.shape[0]} x {t.shape[1]} samples, {h} x {w} needed")
+            out[p, r0:r0 + h, c0:c0 + w] = t[:h, :w]
 
     total = planes * H * W * pix * dt.itemsize
     try:
