@@ -84,6 +84,26 @@ def test_device_feed_reads_tile_files_like_the_host_path(tmp_path):
     assert all(yb is None for _, yb in out) and torch.equal(torch.cat([xb for xb, _ in out]).cpu(), x0)
 
 
+def test_jpeg_compressed_tile_files_through_either_feed(tmp_path):
+    """COMPRESS=JPEG tiles (4 bands, what GDAL writes for orthophoto tiles; masks stay lossless): the device feed and the host path stage the
+    same integers -- the ones libtiff decodes (tests/test_tiff_jpeg_cpu.py has the decoder's own bars)"""
+    Image = pytest.importorskip("PIL.Image")
+    from unet_amd.learner import TileDataset
+    from unet_amd.tiffio import write_tiff
+    imgs, masks = _tiles(6, 4, (64, 48), np.uint8, 2)
+    pi, pm, ref = [], [], []
+    for i, (a, m) in enumerate(zip(imgs, masks)):
+        Image.fromarray(np.moveaxis(a, 0, -1), "RGBA").save(tmp_path / f"i{i}.tif", compression="jpeg", quality=90)
+        ref.append(np.moveaxis(np.asarray(Image.open(tmp_path / f"i{i}.tif")), -1, 0))
+        write_tiff(tmp_path / f"m{i}.tif", m)
+        pi.append(tmp_path / f"i{i}.tif"); pm.append(tmp_path / f"m{i}.tif")
+    host, dev = _pair(TileDataset(pi, pm, "int8"), 3, None, None, shuffle=False, workers=4, depth=2)
+    for (xa, ya), (xb, yb) in zip(list(host), list(dev)):
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    x0 = torch.cat([xb for xb, _ in dev]).cpu()
+    assert torch.equal(x0, torch.from_numpy(np.stack(ref).astype(np.int32).astype(np.float32) / 255.0))
+
+
 def test_single_batch_loaders_stage_directly_and_equal_the_host_path():
     """feed="auto" with ONE batch (Learner.predict on a tile, a tiny validation set): no thread pool, no staging ring -- the integers go up in
     one copy and the same kernels scale / widen / flip them: bit-equal to the host path, for uint16 data (/ 255 twice), flips, float targets"""
