@@ -299,8 +299,8 @@ def cfg5_bench(dtype, dev, side=20000, size=512, overlap=0.2, batch=16):
 
 def _write_tile_files(root: Path, n: int, log):
     """n uint8 4x512x512 image tiles + uint8 masks as GeoTIFFs, once uncompressed (unet_amd.tiffio.write_tiff: what the reference's
-    create_tiles_unet.save_crop writes through GDAL's default creation options) and once LZW-compressed by libtiff (Pillow; skipped when
-    Pillow is missing).  Content: a ramp + low-amplitude noise, so that LZW compresses to ~2/3 like imagery does (uniform noise would make
+    create_tiles_unet.save_crop writes through GDAL's default creation options), once LZW-compressed and once JPEG-compressed (quality 90,
+    masks LZW) by libtiff (Pillow; both skipped when Pillow is missing).  Content: a ramp + low-amplitude noise, so that LZW compresses to ~2/3 like imagery does (uniform noise would make
     every code a literal)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
@@ -309,7 +309,7 @@ def _write_tile_files(root: Path, n: int, log):
         from PIL import Image
     except Exception:      # noqa: BLE001
         Image = None
-    sets = {"none": root / "none", "lzw": root / "lzw"} if Image is not None else {"none": root / "none"}
+    sets = {"none": root / "none", "lzw": root / "lzw", "jpeg": root / "jpeg"} if Image is not None else {"none": root / "none"}
     for d in sets.values():
         (d / "img").mkdir(parents=True)
         (d / "mask").mkdir(parents=True)
@@ -326,6 +326,9 @@ def _write_tile_files(root: Path, n: int, log):
         if "lzw" in sets:
             Image.fromarray(np.moveaxis(img, 0, -1), "RGBA").save(sets["lzw"] / "img" / f"t{i:04d}.tif", compression="tiff_lzw")
             Image.fromarray(mask, "L").save(sets["lzw"] / "mask" / f"t{i:04d}.tif", compression="tiff_lzw")
+        if "jpeg" in sets:          # COMPRESS=JPEG image tiles (lossy: quality 90), masks lossless (LZW) as they have to be
+            Image.fromarray(np.moveaxis(img, 0, -1), "RGBA").save(sets["jpeg"] / "img" / f"t{i:04d}.tif", compression="jpeg", quality=90)
+            Image.fromarray(mask, "L").save(sets["jpeg"] / "mask" / f"t{i:04d}.tif", compression="tiff_lzw")
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=8) as ex:
@@ -630,7 +633,7 @@ def main():
                     lambda: {"f32": cfg5_bench("f32", dev), "bf16": cfg5_bench("bf16", dev)})
             guarded("predict_files", "save_predictions(merge=True) over 400 tile files (split_raster -> files -> merged mask), fp32 + bf16",
                     lambda: predict_files_bench(dev, log))
-            guarded("fit_files", "fit_one_cycle from tile files through the product loader (uncompressed + LZW, fp32 + bf16)",
+            guarded("fit_files", "fit_one_cycle from tile files through the product loader (uncompressed + LZW + JPEG, fp32 + bf16)",
                     lambda: fit_files_bench(dev, log, {"f32": round(value, 3), "bf16": (sec.get("bf16") or {}).get("value")}))
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
