@@ -56,11 +56,11 @@ bool build_huff(Huff& h, const uint8_t* bits /* [16] */, const uint8_t* vals, in
 struct Bits {                       // MSB-first reader over an entropy-coded segment: FF00 -> FF, any other FFxx ends the segment (zeros follow)
     const uint8_t* p;
     const uint8_t* end;
-    uint32_t acc = 0;
+    uint64_t acc = 0;
     int cnt = 0;
     void fill() {
-        while (cnt <= 24) {
-            uint32_t b = 0;
+        while (cnt <= 56) {
+            uint64_t b = 0;
             if (p < end) {
                 b = *p;
                 if (b == 0xFF) {
@@ -70,14 +70,14 @@ struct Bits {                       // MSB-first reader over an entropy-coded se
                     ++p;
                 }
             }
-            acc |= b << (24 - cnt);
+            acc |= b << (56 - cnt);
             cnt += 8;
         }
     }
     int get(int n) {                // n in [0, 16]
         if (n == 0) return 0;
-        fill();
-        const int v = (int)(acc >> (32 - n));
+        if (cnt < n) fill();
+        const int v = (int)(acc >> (64 - n));
         acc <<= n;
         cnt -= n;
         return v;
@@ -86,8 +86,8 @@ struct Bits {                       // MSB-first reader over an entropy-coded se
 };
 
 inline int decode_sym(Bits& b, const Huff& h) {
-    b.fill();
-    const uint32_t top = b.acc >> 23;
+    if (b.cnt < 16) b.fill();
+    const uint32_t top = (uint32_t)(b.acc >> 55);
     int l = h.look_len[top];
     if (l) {
         b.acc <<= l;
@@ -95,7 +95,7 @@ inline int decode_sym(Bits& b, const Huff& h) {
         return h.look_val[top];
     }
     for (l = 10; l <= 16; ++l) {
-        const int32_t code = (int32_t)(b.acc >> (32 - l));
+        const int32_t code = (int32_t)(b.acc >> (64 - l));
         if (code <= h.maxcode[l]) {
             b.acc <<= l;
             b.cnt -= l;
@@ -107,58 +107,64 @@ inline int decode_sym(Bits& b, const Huff& h) {
 
 inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v + (int)((~0u) << s) + 1 : v; }
 
-inline uint8_t range_limit(int32_t x) {     // jdmaster.c prepare_range_limit_table, indexed with (x & RANGE_MASK) past the +128 centre
-    x &= 1023;
-    if (x < 128) return (uint8_t)(x + 128);
-    if (x < 512) return 255;
-    if (x < 896) return 0;
-    return (uint8_t)(x - 896);
-}
+struct RangeTable {                 // jdmaster.c prepare_range_limit_table as the inverse DCT indexes it: (x & RANGE_MASK) past the +128 centre
+    uint8_t t[1024];
+    RangeTable() {
+        for (int x = 0; x < 1024; ++x) t[x] = (uint8_t)(x < 128 ? x + 128 : x < 512 ? 255 : x < 896 ? 0 : x - 896);
+    }
+};
+const RangeTable RANGE;
+inline uint8_t range_limit(int32_t x) { return RANGE.t[x & 1023]; }
 
-// jidctint.c jpeg_idct_islow: coefficients (natural order) times the quantisation table -> 8 x 8 samples at out (row stride `stride`)
-void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride) {
-    enum { CB = 13, P1 = 2 };
+// One 1-D pass of jidctint.c jpeg_idct_islow over EIGHT independent lanes at once (v[i][l]: input i of lane l), so that the compiler turns every
+// statement into vector instructions; the integer arithmetic per lane is the library's, statement by statement.
+__attribute__((always_inline)) inline void idct_pass8(const int32_t (*v)[8], int32_t (*o)[8], const int sh) {
+    enum { CB = 13 };
     const int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
                   F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    int32_t ws[64];
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int k = 0; k < 8; ++k) {
-            int32_t in[8];
-            if (pass == 0) {                                                                                           // column k
-                if ((coef[8 + k] | coef[16 + k] | coef[24 + k] | coef[32 + k] | coef[40 + k] | coef[48 + k] | coef[56 + k]) == 0) {
-                    // no AC term in this column: the arithmetic below reduces to DC << 2 exactly (the library takes the same shortcut)
-                    const int32_t dcv = (int32_t)coef[k] * (int32_t)q[k] * (1 << P1);
-                    for (int r = 0; r < 8; ++r) ws[8 * r + k] = dcv;
-                    continue;
-                }
-                for (int r = 0; r < 8; ++r) in[r] = (int32_t)coef[8 * r + k] * (int32_t)q[8 * r + k];
-            } else {
-                for (int r = 0; r < 8; ++r) in[r] = ws[8 * k + r];                                                    // row k
-            }
-            int32_t z2 = in[2], z3 = in[6];
-            int32_t z1 = (z2 + z3) * F0_541;
-            int32_t tmp2 = z1 + z3 * (-F1_847);
-            int32_t tmp3 = z1 + z2 * F0_765;
-            int32_t tmp0 = (in[0] + in[4]) * (1 << CB), tmp1 = (in[0] - in[4]) * (1 << CB);
-            const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-            tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
-            z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-            int32_t z4 = tmp1 + tmp3;
-            const int32_t z5 = (z3 + z4) * F1_175;
-            tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-            z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
-            z3 += z5; z4 += z5;
-            tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-            const int32_t o[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
-            if (pass == 0) {
-                const int sh = CB - P1;
-                for (int r = 0; r < 8; ++r) ws[8 * r + k] = (o[r] + (1 << (sh - 1))) >> sh;
-            } else {
-                const int sh = CB + P1 + 3;
-                for (int r = 0; r < 8; ++r) out[(size_t)k * stride + r] = range_limit((o[r] + (1 << (sh - 1))) >> sh);
-            }
-        }
+    const int32_t half = 1 << (sh - 1);
+    for (int l = 0; l < 8; ++l) {
+        int32_t z2 = v[2][l], z3 = v[6][l];
+        int32_t z1 = (z2 + z3) * F0_541;
+        int32_t tmp2 = z1 + z3 * (-F1_847);
+        int32_t tmp3 = z1 + z2 * F0_765;
+        int32_t tmp0 = (v[0][l] + v[4][l]) * (1 << CB), tmp1 = (v[0][l] - v[4][l]) * (1 << CB);
+        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = v[7][l]; tmp1 = v[5][l]; tmp2 = v[3][l]; tmp3 = v[1][l];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+        int32_t z4 = tmp1 + tmp3;
+        const int32_t z5 = (z3 + z4) * F1_175;
+        tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+        z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        o[0][l] = (tmp10 + tmp3 + half) >> sh; o[7][l] = (tmp10 - tmp3 + half) >> sh;
+        o[1][l] = (tmp11 + tmp2 + half) >> sh; o[6][l] = (tmp11 - tmp2 + half) >> sh;
+        o[2][l] = (tmp12 + tmp1 + half) >> sh; o[5][l] = (tmp12 - tmp1 + half) >> sh;
+        o[3][l] = (tmp13 + tmp0 + half) >> sh; o[4][l] = (tmp13 - tmp0 + half) >> sh;
     }
+}
+
+// jidctint.c jpeg_idct_islow: coefficients (natural order) times the quantisation table -> 8 x 8 samples at out (row stride `stride`).
+// Pass 1 runs down the columns (lanes = columns) keeping 2 extra bits, pass 2 along the rows (lanes = rows).  The library's zero-coefficient
+// shortcuts are exact special cases of the same arithmetic and are not needed here.  (Cloned for AVX2 and resolved when the library is loaded.)
+__attribute__((target_clones("avx2", "default"))) void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride) {
+    enum { CB = 13, P1 = 2 };
+    alignas(32) int32_t a[8][8], w[8][8];
+    for (int r = 0; r < 8; ++r)
+        for (int k = 0; k < 8; ++k) a[r][k] = (int32_t)coef[8 * r + k] * (int32_t)q[8 * r + k];
+    idct_pass8(a, w, CB - P1);                          // w[r][k]: row r of column k
+    for (int r = 0; r < 8; ++r)
+        for (int k = 0; k < 8; ++k) a[k][r] = w[r][k];  // input k of lane (= row) r
+    idct_pass8(a, w, CB + P1 + 3);                      // w[c][r]: column c of row r
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) out[(size_t)r * stride + c] = range_limit(w[c][r]);
+}
+
+// a block without AC coefficients: both passes reduce to one value, (DC * q0 * 4 + 16) >> 5 (derived from the two descales above)
+inline void idct_dc_only(int dc, const uint16_t* q, uint8_t* out, int stride) {
+    const uint8_t v = range_limit(((int32_t)dc * (int32_t)q[0] * 4 + 16) >> 5);
+    for (int r = 0; r < 8; ++r) memset(out + (size_t)r * stride, v, 8);
 }
 
 struct Comp {
@@ -243,6 +249,7 @@ int decode_block(Decoder& d, Bits& b, Comp& c, int by, int bx) {
     if (s < 0 || s > 11) return -1;
     c.pred += s ? extend(b.get(s), s) : 0;
     blk[0] = (int16_t)c.pred;
+    bool any_ac = false;
     for (int k = 1; k < 64;) {
         const int rs = decode_sym(b, ha);
         if (rs < 0) return -1;
@@ -256,9 +263,14 @@ int decode_block(Decoder& d, Bits& b, Comp& c, int by, int bx) {
         k += r;
         if (k > 63) return -1;
         blk[ZIGZAG[k]] = (int16_t)extend(b.get(s), s);
+        any_ac = true;
         ++k;
     }
-    if (by * 8 + 8 <= c.ph && bx * 8 + 8 <= c.pw) idct_islow(blk, d.qt[c.tq], c.plane.data() + (size_t)by * 8 * c.pw + bx * 8, c.pw);
+    if (by * 8 + 8 <= c.ph && bx * 8 + 8 <= c.pw) {
+        uint8_t* o = c.plane.data() + (size_t)by * 8 * c.pw + bx * 8;
+        if (any_ac) idct_islow(blk, d.qt[c.tq], o, c.pw);
+        else idct_dc_only(blk[0], d.qt[c.tq], o, c.pw);
+    }
     return 0;
 }
 
@@ -454,10 +466,12 @@ extern "C" long long unet_tiff_jpeg_decode(const unsigned char* tables, long lon
                 o[3 * x + 2] = (uint8_t)(bl < 0 ? 0 : bl > 255 ? 255 : bl);
             }
         } else {
-            for (int c = 0; c < d.nc; ++c) {
-                const uint8_t* pc = base[c] + (size_t)y * stride[c];
-                for (int x = 0; x < d.W; ++x) o[(size_t)x * d.nc + c] = pc[x];
-            }
+            const uint8_t* pc[4];
+            for (int c = 0; c < d.nc; ++c) pc[c] = base[c] + (size_t)y * stride[c];
+            if (d.nc == 1) memcpy(o, pc[0], (size_t)d.W);
+            else if (d.nc == 4) for (int x = 0; x < d.W; ++x) { o[4 * x] = pc[0][x]; o[4 * x + 1] = pc[1][x]; o[4 * x + 2] = pc[2][x]; o[4 * x + 3] = pc[3][x]; }
+            else if (d.nc == 3) for (int x = 0; x < d.W; ++x) { o[3 * x] = pc[0][x]; o[3 * x + 1] = pc[1][x]; o[3 * x + 2] = pc[2][x]; }
+            else for (int x = 0; x < d.W; ++x) { o[2 * x] = pc[0][x]; o[2 * x + 1] = pc[1][x]; }
         }
     }
     return total;
