@@ -17,6 +17,7 @@ overwritten only after the kernels that read it have run.
 from __future__ import annotations
 
 import os
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -139,6 +140,15 @@ class BatchFeeder:
         ring = self._ring(int(batches[0][0]))
         R = len(ring)
         submitted = uploaded = 0          # batches [0, submitted) are with the pool, [0, uploaded) are on their way to the device
+        # UNET_FEED_SWITCH_S (opt-in): CPython's GIL switch interval while the feeder runs.  The decode threads hold the GIL only between their
+        # C calls, but each time they ask for it back they wait up to the interval (5 ms by default) while the consumer thread issues launches.
+        # Measured (scripts/ab_feed_switch.py, profiles/r05_ab_feed_switch.log; bf16 storage, fp32 does not move): 0.5 ms lifts JPEG tiles
+        # 582 -> 614 tiles/s and LZW 604 -> 617, and costs uncompressed tiles 642 -> 600 (the launch thread is interrupted more often) --
+        # uncompressed is what the reference's tiler writes, so the interpreter's setting is left alone unless asked.
+        old_switch = sys.getswitchinterval()
+        want = float(os.environ.get("UNET_FEED_SWITCH_S", "0") or 0)
+        if 0.0 < want < old_switch:
+            sys.setswitchinterval(want)
         try:
             for k in range(nb):
                 while submitted < nb and submitted <= k + self.depth:
@@ -155,6 +165,7 @@ class BatchFeeder:
                     torch.cuda.current_stream().wait_event(slot.h2d_done)
                 yield slot
         finally:
+            sys.setswitchinterval(old_switch)
             for s in ring:                 # a consumer that stops early: nothing may write into the slots behind its back
                 for f in s.futures:
                     f.cancel()
