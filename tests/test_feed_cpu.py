@@ -84,3 +84,33 @@ def test_flip_flags_are_the_draws_of_the_host_transforms():
             assert torch.equal(xa, xb) and torch.equal(ya, yb)
     assert FlipAugment(n_transform_imgs=1.0).flip_flags(8) == [(False, False)] * 8          # quirk Q7: the shipped default flips nothing
     assert not hasattr(A.BatchAugment(A.Compose([A.CoarseDropout()])), "flip_flags")
+
+
+def test_gil_switch_interval_is_opt_in_and_restored(monkeypatch):
+    import sys
+    before = sys.getswitchinterval()
+    batches = [list(range(b * 4, b * 4 + 4)) for b in range(6)]
+    f = BatchFeeder(_load_factory(24), bs=4, device="cpu", depth=2, workers=2)
+    monkeypatch.delenv("UNET_FEED_SWITCH_S", raising=False)
+    for slot in f.run(batches):             # unset: the interpreter's setting is left alone
+        assert sys.getswitchinterval() == before
+        slot.release()
+    monkeypatch.setenv("UNET_FEED_SWITCH_S", str(before / 10))
+    inside = []
+    for slot in f.run(batches):
+        inside.append(sys.getswitchinterval())
+        slot.release()
+    assert inside and all(abs(v - before / 10) < 1e-9 for v in inside) and sys.getswitchinterval() == before
+    for slot in f.run(batches):             # early exit restores it as well
+        break
+    assert sys.getswitchinterval() == before
+    monkeypatch.setenv("UNET_FEED_SWITCH_S", str(before * 10))      # never raised above the interpreter's own
+    for slot in f.run(batches):
+        assert sys.getswitchinterval() == before
+        slot.release()
+    bad = BatchFeeder(_load_factory(24, fail_at=5), bs=4, device="cpu", depth=2, workers=2)
+    monkeypatch.setenv("UNET_FEED_SWITCH_S", str(before / 10))
+    with pytest.raises(OSError):
+        list(bad.run(batches))
+    assert sys.getswitchinterval() == before
+    f.close(); bad.close()
