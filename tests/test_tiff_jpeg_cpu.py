@@ -7,6 +7,7 @@ import ctypes as C
 import io
 import re
 import struct
+import time
 from pathlib import Path
 
 import numpy as np
@@ -267,3 +268,10 @@ def test_refusals_are_loud(tmp_path):
     _wrap(tmp_path / "bands.tif", [s], 40, 40, 4, 2)         # 3 components in a 4-band file
     with pytest.raises(ValueError):
         read_tiff(tmp_path / "bands.tif")
+    k = s.index(b"\xff\xc0")                                 # a damaged frame header: 65535 x 65535 -- refused from the header alone
+    big = s[:k + 5] + b"\xff\xff\xff\xff" + s[k + 9:]         # (found by tests/fuzz/tiff_fuzz.cpp: it used to allocate 4 GB planes and decode for minutes)
+    _wrap(tmp_path / "huge.tif", [big], 40, 40, 3, 6)
+    t0 = time.perf_counter()
+    with pytest.raises(ValueError):
+        read_tiff(tmp_path / "huge.tif")
+    assert time.perf_counter() - t0 < 1.0

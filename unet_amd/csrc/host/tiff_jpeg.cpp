@@ -117,31 +117,34 @@ const RangeTable RANGE;
 inline uint8_t range_limit(int32_t x) { return RANGE.t[x & 1023]; }
 
 // One 1-D pass of jidctint.c jpeg_idct_islow over EIGHT independent lanes at once (v[i][l]: input i of lane l), so that the compiler turns every
-// statement into vector instructions; the integer arithmetic per lane is the library's, statement by statement.
+// statement into vector instructions; the integer arithmetic per lane is the library's, statement by statement.  Sums and products are taken
+// modulo 2^32 (unsigned) and read back as two's complement before the descale: the same bits as the library's for every stream an encoder
+// writes, and defined -- instead of signed overflow -- for the coefficients a corrupt stream can hold (found by the ASan / UBSan fuzz run).
 __attribute__((always_inline)) inline void idct_pass8(const int32_t (*v)[8], int32_t (*o)[8], const int sh) {
     enum { CB = 13 };
-    const int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
-                  F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    const int32_t half = 1 << (sh - 1);
+    typedef uint32_t U;
+    const U F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+            F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    const U half = (U)1 << (sh - 1);
     for (int l = 0; l < 8; ++l) {
-        int32_t z2 = v[2][l], z3 = v[6][l];
-        int32_t z1 = (z2 + z3) * F0_541;
-        int32_t tmp2 = z1 + z3 * (-F1_847);
-        int32_t tmp3 = z1 + z2 * F0_765;
-        int32_t tmp0 = (v[0][l] + v[4][l]) * (1 << CB), tmp1 = (v[0][l] - v[4][l]) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = v[7][l]; tmp1 = v[5][l]; tmp2 = v[3][l]; tmp3 = v[1][l];
+        U z2 = (U)v[2][l], z3 = (U)v[6][l];
+        U z1 = (z2 + z3) * F0_541;
+        U tmp2 = z1 - z3 * F1_847;
+        U tmp3 = z1 + z2 * F0_765;
+        U tmp0 = ((U)v[0][l] + (U)v[4][l]) << CB, tmp1 = ((U)v[0][l] - (U)v[4][l]) << CB;
+        const U tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = (U)v[7][l]; tmp1 = (U)v[5][l]; tmp2 = (U)v[3][l]; tmp3 = (U)v[1][l];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1_175;
+        U z4 = tmp1 + tmp3;
+        const U z5 = (z3 + z4) * F1_175;
         tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-        z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+        z1 *= (U)0 - F0_899; z2 *= (U)0 - F2_562; z3 *= (U)0 - F1_961; z4 *= (U)0 - F0_390;
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        o[0][l] = (tmp10 + tmp3 + half) >> sh; o[7][l] = (tmp10 - tmp3 + half) >> sh;
-        o[1][l] = (tmp11 + tmp2 + half) >> sh; o[6][l] = (tmp11 - tmp2 + half) >> sh;
-        o[2][l] = (tmp12 + tmp1 + half) >> sh; o[5][l] = (tmp12 - tmp1 + half) >> sh;
-        o[3][l] = (tmp13 + tmp0 + half) >> sh; o[4][l] = (tmp13 - tmp0 + half) >> sh;
+        o[0][l] = (int32_t)(tmp10 + tmp3 + half) >> sh; o[7][l] = (int32_t)(tmp10 - tmp3 + half) >> sh;
+        o[1][l] = (int32_t)(tmp11 + tmp2 + half) >> sh; o[6][l] = (int32_t)(tmp11 - tmp2 + half) >> sh;
+        o[2][l] = (int32_t)(tmp12 + tmp1 + half) >> sh; o[5][l] = (int32_t)(tmp12 - tmp1 + half) >> sh;
+        o[3][l] = (int32_t)(tmp13 + tmp0 + half) >> sh; o[4][l] = (int32_t)(tmp13 - tmp0 + half) >> sh;
     }
 }
 
@@ -163,7 +166,7 @@ __attribute__((target_clones("avx2", "default"))) void idct_islow(const int16_t*
 
 // a block without AC coefficients: both passes reduce to one value, (DC * q0 * 4 + 16) >> 5 (derived from the two descales above)
 inline void idct_dc_only(int dc, const uint16_t* q, uint8_t* out, int stride) {
-    const uint8_t v = range_limit(((int32_t)dc * (int32_t)q[0] * 4 + 16) >> 5);
+    const uint8_t v = range_limit((int32_t)((uint32_t)((int32_t)dc * (int32_t)q[0]) * 4u + 16u) >> 5);
     for (int r = 0; r < 8; ++r) memset(out + (size_t)r * stride, v, 8);
 }
 
@@ -181,6 +184,7 @@ struct Decoder {
     Huff dc[4], ac[4];
     int W = 0, H = 0, nc = 0, hmax = 1, vmax = 1, ri = 0;
     bool have_frame = false;
+    long long cap = -1;             // bytes the caller's buffer holds: a frame header that asks for more is refused before anything is allocated
     Comp comp[4];
 };
 
@@ -218,6 +222,7 @@ int parse_sof(Decoder& d, const uint8_t* p, int len) {
     if (p[0] != 8) return -2;                          // 12-bit samples
     d.H = rd16(p + 1); d.W = rd16(p + 3); d.nc = p[5];
     if (d.H <= 0 || d.W <= 0 || d.nc < 1 || d.nc > 4 || len < 6 + 3 * d.nc) return -1;
+    if (d.cap >= 0 && (long long)d.W * d.H * d.nc > d.cap) return -1;      // (a damaged header of 65535 x 65535 would otherwise cost 4 GB a plane and minutes)
     d.hmax = d.vmax = 1;
     for (int i = 0; i < d.nc; ++i) {
         Comp& c = d.comp[i];
@@ -438,9 +443,13 @@ extern "C" long long unet_tiff_jpeg_decode(const unsigned char* tables, long lon
                                            unsigned char* dst, long long cap, int* dims) {
     if (src == nullptr || dst == nullptr || n < 4 || cap < 0) return -1;
     Decoder d;
+    d.cap = cap;
     int rc;
     if (tables != nullptr && ntables > 0 && (rc = parse_stream(d, tables, ntables, true)) != 0) return rc;
-    if ((rc = parse_stream(d, src, n, false)) != 0) return rc;
+    if ((rc = parse_stream(d, src, n, false)) != 0) {
+        if (dims != nullptr) { dims[0] = d.H; dims[1] = d.W; dims[2] = d.nc; }
+        return rc;
+    }
     const long long total = (long long)d.W * d.H * d.nc;
     if (dims != nullptr) { dims[0] = d.H; dims[1] = d.W; dims[2] = d.nc; }
     if (total > cap) return -1;
