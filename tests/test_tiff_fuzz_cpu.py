@@ -90,3 +90,50 @@ def test_damaged_strips_never_leave_the_decoders_buffers(tmp_path):
         got = dict(zip(words[0::2], map(int, words[1::2])))
         assert got["streams"] == n and got["intact"] == n          # every stream decodes to its full size before it is damaged
         assert got["refused"] > 0 and got["decoded"] > 0, r.stdout
+
+
+def test_damaged_files_raise_value_error_and_nothing_else(tmp_path):
+    """Whole files (header, tags, strips) damaged at random through tiffio.read_tiff / tiff_info: the only outcomes are an array, ValueError
+    naming the file, or NotImplementedError -- no KeyError / struct.error / zlib.error / MemoryError from inside, and no read that takes
+    seconds because a damaged count or image size was believed (both were found by this loop before the checks went in)."""
+    import time
+    from unet_amd.tiffio import read_tiff, tiff_info, write_tiff
+    rng = np.random.default_rng(11)
+    im = _scene(48, 64, 4, rng)
+    files = {}
+    write_tiff(tmp_path / "u.tif", np.moveaxis(im, -1, 0), geotransform=(10.0, 0.5, 0.0, 20.0, 0.0, -0.5))
+    files["none"] = (tmp_path / "u.tif").read_bytes()
+    for comp in ("tiff_lzw", "jpeg", "packbits", "tiff_adobe_deflate"):
+        Image.fromarray(im, "RGBA").save(tmp_path / "c.tif", compression=comp)
+        files[comp] = (tmp_path / "c.tif").read_bytes()
+    Image.fromarray(im[..., :3], "RGB").save(tmp_path / "c.tif", compression="jpeg")
+    files["jpeg_ycc"] = (tmp_path / "c.tif").read_bytes()
+    names = list(files)
+    seen = {"ok": 0, "refused": 0}
+    target = tmp_path / "m.tif"
+    for it in range(4000):
+        b = bytearray(files[names[it % len(names)]])
+        m = int(rng.integers(4))
+        if m == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(len(b)))] = int(rng.integers(256))
+        elif m == 1:                                  # the tag area: libtiff / Pillow put the IFD at the end, write_tiff at the start
+            lo = max(0, len(b) - 400) if rng.integers(2) else 0
+            for _ in range(int(rng.integers(1, 4))):
+                b[lo + int(rng.integers(min(400, len(b) - lo)))] = int(rng.integers(256))
+        elif m == 2:
+            b = b[:int(rng.integers(len(b)))]
+        else:
+            a = int(rng.integers(len(b)))
+            b[a:a + 4] = b"\xff\xff\xff\xff"[:len(b) - a]
+        target.write_bytes(bytes(b))
+        t0 = time.perf_counter()
+        for fn in (tiff_info, read_tiff):
+            try:
+                fn(target)
+                seen["ok"] += 1
+            except (ValueError, NotImplementedError) as e:
+                assert isinstance(e, NotImplementedError) or str(target) in str(e) or "mmap" in str(e) or "empty" in str(e), e
+                seen["refused"] += 1
+        assert time.perf_counter() - t0 < 2.0, (names[it % len(names)], m)
+    assert seen["ok"] > 500 and seen["refused"] > 500, seen

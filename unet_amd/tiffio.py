@@ -61,6 +61,8 @@ def _parse_tags(b, path):
             data = e[4 + inl:4 + inl + total]
         else:
             o = struct.unpack(bo + cfmt, e[4 + inl:4 + 2 * inl])[0]
+            if o + total > len(b):          # (a damaged count would otherwise become a format string of that many characters)
+                raise ValueError(f"{path}: tag {tag} holds {cnt} values at offset {o}: past the end of the file ({len(b)} bytes)")
             data = bytes(b[o:o + total])
         if typ == 2:
             tags[tag] = (data.rstrip(b"\0").decode("latin1"),)
@@ -192,6 +194,25 @@ def _geo_meta(tags) -> Dict:
     return meta
 
 
+def _one_error_contract(fn):
+    """One error contract for the readers: a file this module does not implement raises NotImplementedError, a damaged one ValueError naming
+    the file -- whatever the damage tripped inside (a missing tag, an offset past the end, a count that does not fit, zlib's own error, an
+    allocation the header asks for and the file cannot justify).  GDAL, which the reference reads through, reports a read error there."""
+    import functools
+    import zlib
+
+    @functools.wraps(fn)
+    def reader(path):
+        try:
+            return fn(path)
+        except (ValueError, NotImplementedError, OSError):
+            raise
+        except (KeyError, IndexError, struct.error, zlib.error, MemoryError, ArithmeticError, TypeError, UnicodeError) as e:
+            raise ValueError(f"{path}: damaged TIFF ({type(e).__name__}: {e})") from e
+    return reader
+
+
+@_one_error_contract
 def tiff_info(path) -> Dict:
     """Header-only read (memory-mapped: the pixel data is never touched): meta of read_tiff plus 'height', 'width', 'bands'.
     What the prediction merge needs from every tile before any of them is predicted (reference predict.py:206-222 takes the same
@@ -204,6 +225,7 @@ def tiff_info(path) -> Dict:
     return meta
 
 
+@_one_error_contract
 def read_tiff(path) -> Tuple[np.ndarray, Dict]:
     """Returns (array [C,H,W] (or [H,W] for one band), meta) with meta['geotransform'] = (ulx, xres, 0, uly, 0, -yres)
     when the file is georeferenced and meta['tags'] holding the raw GeoTIFF tags.  The file is memory-mapped (copy-on-write), never slurped:
@@ -252,6 +274,10 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict]:
             raise NotImplementedError(f"{path}: JPEG-in-TIFF with {bits}-bit samples / predictor {predictor} is not supported")
         jpeg = _jpeg_decoder(tags, path)
     decode = _decoder(comp, path) if comp != 7 else None
+    # what the header asks for against what the file can hold: Deflate tops out at 1032 : 1, LZW and PackBits below that, a flat JPEG near
+    # 100 : 1 -- a damaged ImageWidth / ImageLength (65535 x 65535 x 4 is 17 GB) is refused here instead of being allocated and decoded into
+    if W <= 0 or H <= 0 or spp <= 0 or planes * H * W * pix * dt.itemsize > (1 << 20) + (b.size << (12 if comp != 1 else 0)):
+        raise ValueError(f"{path}: {planes * pix} x {H} x {W} {dt} samples cannot come out of a file of {b.size} bytes (compression {comp})")
     out = np.zeros((planes, H, W, pix), dtype=native)
 
     def block(off, nbytes, rows, cols):
